@@ -1,0 +1,87 @@
+"""In-tree build of the native libraries (gfx950 only).
+
+Two shared objects are produced next to this file:
+
+* ``libdl4j_hip.so``   – every hand-written HIP kernel (``csrc/*.hip``), compiled with
+  ``hipcc --offload-arch=gfx950`` and exposed through a flat C ABI (ctypes on the Python side,
+  the same ABI a JavaCPP preset would bind — mirrors the role of libnd4j's NativeOps.h).
+* ``libnd4jrocm_rt.so`` – the host C++ runtime (``csrc/*.cpp``): shapeInfo/TAD math, workspaces,
+  DataBuffer serde, threshold codecs (host), record readers + prefetch loader, op registry.
+
+hipcc cross-compiles without a GPU, so this runs on the CPU build box; the ``.so`` files travel
+to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OBJ = HERE / "_obj"
+ARCH = "gfx950"
+HIP_LIB = HERE / "libdl4j_hip.so"
+RT_LIB = HERE / "libnd4jrocm_rt.so"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(src: Path, dst: Path, extra=()) -> bool:
+    if not dst.exists():
+        return True
+    t = dst.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in (src, *extra))
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(map(str, cmd)), r.stdout))
+    return r.stdout
+
+
+def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> None:
+    OBJ.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    headers = list(CSRC.glob("*.h")) + list(CSRC.glob("*.hpp"))
+    jobs = jobs or min(8, os.cpu_count() or 4)
+
+    hip_srcs = sorted(CSRC.glob("*.hip"))
+    cpp_srcs = sorted(CSRC.glob("*.cpp"))
+
+    tasks = []
+    for s in hip_srcs:
+        o = OBJ / (s.stem + ".hip.o")
+        if force or _newer(s, o, headers):
+            tasks.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
+                          "-Wno-unused-result", "-I", str(CSRC), "-c", str(s), "-o", str(o)])
+    for s in cpp_srcs:
+        o = OBJ / (s.stem + ".cpp.o")
+        if force or _newer(s, o, headers):
+            tasks.append(["g++", "-O2", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-pthread", "-I", str(CSRC),
+                          "-c", str(s), "-o", str(o)])
+    if tasks:
+        with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
+            for out in ex.map(_run, tasks):
+                if verbose and out.strip():
+                    print(out)
+    hip_objs = [str(OBJ / (s.stem + ".hip.o")) for s in hip_srcs]
+    cpp_objs = [str(OBJ / (s.stem + ".cpp.o")) for s in cpp_srcs]
+    if hip_objs and (force or tasks or not HIP_LIB.exists()):
+        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(HIP_LIB), *hip_objs])
+    if cpp_objs and (force or tasks or not RT_LIB.exists()):
+        _run(["g++", "-shared", "-fPIC", "-pthread", "-o", str(RT_LIB), *cpp_objs])
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print("built:", HIP_LIB if HIP_LIB.exists() else "-", RT_LIB if RT_LIB.exists() else "-")

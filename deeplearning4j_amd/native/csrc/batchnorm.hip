@@ -1,0 +1,337 @@
+// Fused BatchNorm kernels for channels-last activations ([M, C], C contiguous; M = N*H*W).
+// Semantics follow DL4J BatchNormalization train-time math
+// (reference: deeplearning4j-nn/.../nn/layers/normalization/BatchNormalization.java:492-566 fwd,
+// :280-353 bwd incl. running-stat "gradients"), but the ~25 legacy ops issued from Java per
+// layer are replaced by: one stats pass, one tiny finalize, one apply pass (optionally fused
+// with a residual add — itself optionally batch-normalised — and ReLU), and a 2-pass backward.
+// Memory-bound: 16-byte vector accesses, fp32 accumulation, one float atomic per block/channel.
+#include "common.h"
+
+template <typename T> struct VecOf;
+template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
+template <> struct VecOf<float> { static constexpr int N = 4; };
+
+template <typename T, int V>
+__device__ __forceinline__ void load_vec(const T* p, float (&o)[V]);
+template <>
+__device__ __forceinline__ void load_vec<bf16_t, 8>(const bf16_t* p, float (&o)[8]) {
+  s16x8 v = *reinterpret_cast<const s16x8*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = bf2f((bf16_t)v[j]);
+}
+template <>
+__device__ __forceinline__ void load_vec<float, 4>(const float* p, float (&o)[4]) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = v[j];
+}
+template <>
+__device__ __forceinline__ void load_vec<bf16_t, 1>(const bf16_t* p, float (&o)[1]) { o[0] = bf2f(*p); }
+template <>
+__device__ __forceinline__ void load_vec<float, 1>(const float* p, float (&o)[1]) { o[0] = *p; }
+
+template <typename T, int V>
+__device__ __forceinline__ void store_vec(T* p, const float (&o)[V]);
+template <>
+__device__ __forceinline__ void store_vec<bf16_t, 8>(bf16_t* p, const float (&o)[8]) {
+  s16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(o[j]);
+  *reinterpret_cast<s16x8*>(p) = v;
+}
+template <>
+__device__ __forceinline__ void store_vec<float, 4>(float* p, const float (&o)[4]) {
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = o[j];
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+template <>
+__device__ __forceinline__ void store_vec<bf16_t, 1>(bf16_t* p, const float (&o)[1]) { *p = f2bf(o[0]); }
+template <>
+__device__ __forceinline__ void store_vec<float, 1>(float* p, const float (&o)[1]) { *p = o[0]; }
+
+// ---------------------------------------------------------------------------------------
+// Pass A: per-channel column reductions of up to two quantities.
+//   MODE 0: q0 = x, q1 = x*x                      (forward statistics)
+//   MODE 1: q0 = dz, q1 = dz * (x-mean)*invstd    (backward dbeta / dgamma), dz = dy*[out>0]
+// block = 256 threads: cpb channel-vectors x rpi rows per iteration.
+// ---------------------------------------------------------------------------------------
+template <typename T, int V, int MODE>
+__global__ void __launch_bounds__(256) bn_colreduce_kernel(
+    const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ out,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ sums, int64_t M, int C, int cpb, int rpi) {
+  __shared__ float red[2 * V * 256];
+  const int cv = C / V;
+  const int tid = threadIdx.x;
+  const int r_in = tid / cpb, c_in = tid - r_in * cpb;
+  const int cvec = blockIdx.x * cpb + c_in;
+  const bool active = (r_in < rpi) && (cvec < cv);
+  float a0[V], a1[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+  if (active) {
+    const int c0 = cvec * V;
+    float mu[V], is[V];
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; }
+    }
+    for (int64_t r = (int64_t)blockIdx.y * rpi + r_in; r < M; r += (int64_t)gridDim.y * rpi) {
+      const int64_t off = r * C + c0;
+      float xv[V];
+      load_vec<T, V>(x + off, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a0[j] += xv[j]; a1[j] += xv[j] * xv[j]; }
+      } else {
+        float dv[V];
+        load_vec<T, V>(dy + off, dv);
+        if (out != nullptr) {
+          float ov[V];
+          load_vec<T, V>(out + off, ov);
+#pragma unroll
+          for (int j = 0; j < V; ++j) dv[j] = ov[j] > 0.f ? dv[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) { a0[j] += dv[j]; a1[j] += dv[j] * (xv[j] - mu[j]) * is[j]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) { red[j * 256 + tid] = a0[j]; red[(V + j) * 256 + tid] = a1[j]; }
+  __syncthreads();
+  if (r_in == 0 && cvec < cv) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int r = 0; r < rpi; ++r) { s0 += red[j * 256 + r * cpb + c_in]; s1 += red[(V + j) * 256 + r * cpb + c_in]; }
+      atomicAdd(&sums[cvec * V + j], s0);
+      atomicAdd(&sums[C + cvec * V + j], s1);
+    }
+  }
+}
+
+template <typename T, int MODE>
+static int launch_colreduce(const void* x, const void* dy, const void* out, const float* mean,
+                            const float* invstd, float* sums, int64_t M, int C, hipStream_t st) {
+  hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st);
+  constexpr int VFULL = VecOf<T>::N;
+  const bool vec_ok = (C % VFULL) == 0;
+  const int V = vec_ok ? VFULL : 1;
+  const int cv = C / V;
+  const int cpb = cv < 256 ? cv : 256;
+  const int rpi = 256 / cpb;
+  const int gx = (cv + cpb - 1) / cpb;
+  int64_t gy = (M + rpi - 1) / rpi;
+  int64_t cap = 2048 / gx; if (cap < 1) cap = 1;
+  if (gy > cap) gy = cap;
+  dim3 grid(gx, (unsigned)gy);
+  if (vec_ok)
+    hipLaunchKernelGGL((bn_colreduce_kernel<T, VFULL, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
+                       (const T*)out, mean, invstd, sums, M, C, cpb, rpi);
+  else
+    hipLaunchKernelGGL((bn_colreduce_kernel<T, 1, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
+                       (const T*)out, mean, invstd, sums, M, C, cpb, rpi);
+  DL4J_RET_LAST();
+}
+
+// ---------------------------------------------------------------------------------------
+// Finalize: sums -> mean / invstd / scale / shift (+ running-stat gradient entries).
+// stat_mode: 0 = none, 1 = variance parameter, 2 = log10(stdev) parameter (DL4J useLogStd).
+// conv_bias (optional): bias of the producing conv that was folded out of x; it only shifts
+// the batch mean seen by the running statistics.
+// ---------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, const float* __restrict__ conv_bias,
+                                   const float* __restrict__ gmean, const float* __restrict__ gvar,
+                                   float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ dgmean, float* __restrict__ dgvar,
+                                   int C, float invM, float eps, float decay, int stat_mode) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = sums[c] * invM;
+  float var = sums[C + c] * invM - m * m;
+  var = var < 0.f ? 0.f : var;
+  const float is = rsqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean[c] = m; invstd[c] = is;
+  const float sc = g * is;
+  scale[c] = sc; shift[c] = b - m * sc;
+  if (stat_mode != 0) {
+    const float bm = m + (conv_bias ? conv_bias[c] : 0.f);
+    dgmean[c] = (gmean[c] - bm) * (1.f - decay);
+    if (stat_mode == 1) {
+      dgvar[c] = (gvar[c] - var) * (1.f - decay);
+    } else {
+      // parameter is log10(std); d = log10(var_t / (decay*var_t + (1-decay)*batchVar)) / 2
+      const float vt = powf(10.f, 2.f * gvar[c]);
+      const float vnew = decay * vt + (1.f - decay) * var;
+      dgvar[c] = logf(vt / vnew) * (0.5f / 2.302585092994046f);
+    }
+  }
+}
+
+// Inference-time scale/shift from global statistics.
+__global__ void bn_infer_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ gmean, const float* __restrict__ gvar,
+                                       const float* __restrict__ conv_bias,
+                                       float* __restrict__ scale, float* __restrict__ shift, int C, float eps,
+                                       int log_std) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float var = log_std ? powf(10.f, 2.f * gvar[c]) : gvar[c];
+  const float sc = (gamma ? gamma[c] : 1.f) * rsqrtf(var + eps);
+  const float m = gmean[c] - (conv_bias ? conv_bias[c] : 0.f);
+  scale[c] = sc; shift[c] = (beta ? beta[c] : 0.f) - m * sc;
+}
+
+// ---------------------------------------------------------------------------------------
+// Pass B (forward): y = act( x*scale + shift [+ res (*rscale + rshift)] )
+// ---------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const T* __restrict__ res,
+                                                       const float* __restrict__ rscale,
+                                                       const float* __restrict__ rshift, T* __restrict__ y,
+                                                       int64_t nvec, int cv, int relu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * V;
+    float xv[V];
+    load_vec<T, V>(x + i * V, xv);
+#pragma unroll
+    for (int j = 0; j < V; ++j) xv[j] = xv[j] * scale[c0 + j] + shift[c0 + j];
+    if (res != nullptr) {
+      float rv[V];
+      load_vec<T, V>(res + i * V, rv);
+      if (rscale != nullptr) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) rv[j] = rv[j] * rscale[c0 + j] + rshift[c0 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) xv[j] += rv[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) xv[j] = fmaxf(xv[j], 0.f);
+    }
+    store_vec<T, V>(y + i * V, xv);
+  }
+}
+
+template <typename T>
+static int launch_apply(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
+                        const float* rshift, void* y, int64_t M, int C, int relu, hipStream_t st) {
+  constexpr int VFULL = VecOf<T>::N;
+  if (C % VFULL == 0) {
+    const int64_t nvec = M * C / VFULL;
+    hipLaunchKernelGGL((bn_apply_kernel<T, VFULL>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x, scale,
+                       shift, (const T*)res, rscale, rshift, (T*)y, nvec, C / VFULL, relu);
+  } else {
+    const int64_t nvec = M * C;
+    hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x, scale, shift,
+                       (const T*)res, rscale, rshift, (T*)y, nvec, C, relu);
+  }
+  DL4J_RET_LAST();
+}
+
+// ---------------------------------------------------------------------------------------
+// Pass B (backward): dx = scale * (dz - dbeta/M - xhat * dgamma/M), dz = dy*[out>0]
+// optionally also writes dz (gradient for the residual branch).
+// ---------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                        const T* __restrict__ out, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ sums, T* __restrict__ dx,
+                                                        T* __restrict__ dz_out, int64_t nvec, int cv, int C,
+                                                        float invM) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cv) * V;
+    float xv[V], dv[V];
+    load_vec<T, V>(x + i * V, xv);
+    load_vec<T, V>(dy + i * V, dv);
+    if (out != nullptr) {
+      float ov[V];
+      load_vec<T, V>(out + i * V, ov);
+#pragma unroll
+      for (int j = 0; j < V; ++j) dv[j] = ov[j] > 0.f ? dv[j] : 0.f;
+    }
+    if (dz_out != nullptr) store_vec<T, V>(dz_out + i * V, dv);
+    float r[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int c = c0 + j;
+      const float is = invstd[c];
+      const float xh = (xv[j] - mean[c]) * is;
+      const float g = gamma ? gamma[c] : 1.f;
+      r[j] = g * is * (dv[j] - sums[c] * invM - xh * sums[C + c] * invM);
+    }
+    store_vec<T, V>(dx + i * V, r);
+  }
+}
+
+template <typename T>
+static int launch_bwd_dx(const void* x, const void* dy, const void* out, const float* mean, const float* invstd,
+                         const float* gamma, const float* sums, void* dx, void* dz, int64_t M, int C,
+                         hipStream_t st) {
+  constexpr int VFULL = VecOf<T>::N;
+  const float invM = 1.f / (float)M;
+  if (C % VFULL == 0) {
+    const int64_t nvec = M * C / VFULL;
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VFULL>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x,
+                       (const T*)dy, (const T*)out, mean, invstd, gamma, sums, (T*)dx, (T*)dz, nvec, C / VFULL, C,
+                       invM);
+  } else {
+    const int64_t nvec = M * C;
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x,
+                       (const T*)dy, (const T*)out, mean, invstd, gamma, sums, (T*)dx, (T*)dz, nvec, C, C, invM);
+  }
+  DL4J_RET_LAST();
+}
+
+// dtype codes: 0 = fp32, 1 = bf16
+DL4J_API int dl4j_bn_stats(const void* x, float* sums, int64_t M, int C, int dtype, hipStream_t st) {
+  if (dtype == 1) return launch_colreduce<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, sums, M, C, st);
+  return launch_colreduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, sums, M, C, st);
+}
+
+DL4J_API int dl4j_bn_finalize(const float* sums, const float* gamma, const float* beta, const float* conv_bias,
+                              const float* gmean, const float* gvar, float* mean, float* invstd, float* scale,
+                              float* shift, float* dgmean, float* dgvar, int C, int64_t M, float eps, float decay,
+                              int stat_mode, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, gamma, beta, conv_bias, gmean,
+                     gvar, mean, invstd, scale, shift, dgmean, dgvar, C, 1.f / (float)M, eps, decay, stat_mode);
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_bn_infer_coeffs(const float* gamma, const float* beta, const float* gmean, const float* gvar,
+                                  const float* conv_bias, float* scale, float* shift, int C, float eps, int log_std,
+                                  hipStream_t st) {
+  hipLaunchKernelGGL(bn_infer_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, gmean, gvar,
+                     conv_bias, scale, shift, C, eps, log_std);
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_bn_apply(const void* x, const float* scale, const float* shift, const void* res,
+                           const float* rscale, const float* rshift, void* y, int64_t M, int C, int relu, int dtype,
+                           hipStream_t st) {
+  if (dtype == 1) return launch_apply<bf16_t>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st);
+  return launch_apply<float>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st);
+}
+
+DL4J_API int dl4j_bn_bwd_reduce(const void* x, const void* dy, const void* out, const float* mean,
+                                const float* invstd, float* sums, int64_t M, int C, int dtype, hipStream_t st) {
+  if (dtype == 1) return launch_colreduce<bf16_t, 1>(x, dy, out, mean, invstd, sums, M, C, st);
+  return launch_colreduce<float, 1>(x, dy, out, mean, invstd, sums, M, C, st);
+}
+
+DL4J_API int dl4j_bn_bwd_dx(const void* x, const void* dy, const void* out, const float* mean, const float* invstd,
+                            const float* gamma, const float* sums, void* dx, void* dz, int64_t M, int C, int dtype,
+                            hipStream_t st) {
+  if (dtype == 1) return launch_bwd_dx<bf16_t>(x, dy, out, mean, invstd, gamma, sums, dx, dz, M, C, st);
+  return launch_bwd_dx<float>(x, dy, out, mean, invstd, gamma, sums, dx, dz, M, C, st);
+}

@@ -1,0 +1,109 @@
+// Fused softmax + multi-class cross entropy (LossMCXENT / LossNegativeLogLikelihood) forward,
+// score and gradient in one pass per row:  p = softmax(z), grad = p - y,
+// score_row = -sum(y * log(clip(p, 1e-10, 1)))   (reference: nd4j-api/.../lossfunctions/impl/LossMCXENT.java:96-164).
+// Also stand-alone softmax / log-softmax (reference kernel: helpers/cuda/activations.cu softMaxCuda).
+// One workgroup (256 threads = 4 waves) per row; wave64 shuffles + one LDS hop for block reductions.
+#include "common.h"
+
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_xent_kernel(const T* __restrict__ z, const T* __restrict__ y,
+                                                           const int64_t* __restrict__ ylab,
+                                                           T* __restrict__ probs, T* __restrict__ grad,
+                                                           float* __restrict__ row_loss, float* __restrict__ score,
+                                                           int N) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const T* zr = z + row * N;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 256) mx = fmaxf(mx, Cvt<T>::ld(zr, i));
+  mx = block_max(mx, red);
+  float se = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) se += __expf(Cvt<T>::ld(zr, i) - mx);
+  se = block_sum(se, red);
+  const float inv = 1.f / se;
+  float loss = 0.f;
+  const int64_t lab = ylab ? ylab[row] : -1;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float p = __expf(Cvt<T>::ld(zr, i) - mx) * inv;
+    const float yv = ylab ? (i == lab ? 1.f : 0.f) : Cvt<T>::ld(y + row * N, i);
+    if (probs) Cvt<T>::st(probs + row * N, i, p);
+    if (grad) Cvt<T>::st(grad + row * N, i, p - yv);
+    if (yv != 0.f) loss -= yv * __logf(fminf(fmaxf(p, 1e-10f), 1.f));
+  }
+  loss = block_sum(loss, red);
+  if (threadIdx.x == 0) {
+    if (row_loss) row_loss[row] = loss;
+    if (score) atomicAdd(score, loss);
+  }
+}
+
+// mode 0: softmax, 1: log-softmax
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const T* __restrict__ z, T* __restrict__ out, int N,
+                                                           int mode) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const T* zr = z + row * N;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 256) mx = fmaxf(mx, Cvt<T>::ld(zr, i));
+  mx = block_max(mx, red);
+  float se = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) se += __expf(Cvt<T>::ld(zr, i) - mx);
+  se = block_sum(se, red);
+  const float inv = 1.f / se, lse = __logf(se);
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float v = Cvt<T>::ld(zr, i) - mx;
+    Cvt<T>::st(out + row * N, i, mode == 0 ? __expf(v) * inv : v - lse);
+  }
+}
+
+// softmax backward: dz = p * (dy - sum(dy*p))
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const T* __restrict__ p, const T* __restrict__ dy,
+                                                          T* __restrict__ dz, int N) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) s += Cvt<T>::ld(p + row * N, i) * Cvt<T>::ld(dy + row * N, i);
+  s = block_sum(s, red);
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float pv = Cvt<T>::ld(p + row * N, i);
+    Cvt<T>::st(dz + row * N, i, pv * (Cvt<T>::ld(dy + row * N, i) - s));
+  }
+}
+
+DL4J_API int dl4j_softmax_xent(const void* z, const void* y, const int64_t* ylab, void* probs, void* grad,
+                               float* row_loss, float* score, int64_t M, int N, int dtype, hipStream_t st) {
+  if (score) hipMemsetAsync(score, 0, sizeof(float), st);
+  if (M <= 0) return 0;
+  if (dtype == 1)
+    hipLaunchKernelGGL(softmax_xent_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, st, (const bf16_t*)z,
+                       (const bf16_t*)y, ylab, (bf16_t*)probs, (bf16_t*)grad, row_loss, score, N);
+  else
+    hipLaunchKernelGGL(softmax_xent_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (const float*)z,
+                       (const float*)y, ylab, (float*)probs, (float*)grad, row_loss, score, N);
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_softmax_rows(const void* z, void* out, int64_t M, int N, int mode, int dtype, hipStream_t st) {
+  if (M <= 0) return 0;
+  if (dtype == 1)
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, st, (const bf16_t*)z,
+                       (bf16_t*)out, N, mode);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (const float*)z,
+                       (float*)out, N, mode);
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_softmax_bwd(const void* p, const void* dy, void* dz, int64_t M, int N, int dtype,
+                              hipStream_t st) {
+  if (M <= 0) return 0;
+  if (dtype == 1)
+    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, st, (const bf16_t*)p,
+                       (const bf16_t*)dy, (bf16_t*)dz, N);
+  else
+    hipLaunchKernelGGL(softmax_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (const float*)p,
+                       (const float*)dy, (float*)dz, N);
+  DL4J_RET_LAST();
+}

@@ -1,0 +1,208 @@
+// Segmented fused updater over the flat parameter / gradient / updater-state vectors.
+//
+// The reference fragments the flat vector into >100 UpdaterBlocks for ResNet-50 and issues, per
+// block and per iteration, a divide-by-minibatch op, 1-2 regularisation Axpy ops, one fused
+// updater op (+ stream sync) and a final params -= update step function
+// (deeplearning4j-nn/.../nn/updater/BaseMultiLayerUpdater.java:83-141,329-382, UpdaterBlock.java:131-211,
+// libnd4j/include/ops/declarable/helpers/cuda/updater*.cu). Here the whole chain is ONE launch:
+// a device-resident segment table carries per-block hyper-parameters and a block table maps each
+// workgroup to (segment, chunk). Formulas follow SURVEY Appendix B.5 / the reference kernels.
+// The iteration counter lives in device memory so the launch is hipGraph-replayable.
+#include "common.h"
+
+struct __attribute__((packed, aligned(8))) UpdSeg {
+  int64_t off;        // offset into params/grads
+  int64_t len;
+  int64_t state_off;  // offset into the flat updater state
+  int32_t kind;       // 0 NoOp 1 Sgd 2 Nesterovs 3 Adam 4 RmsProp 5 AdaGrad 6 AdaDelta 7 AdaMax 8 Nadam 9 AMSGrad 10 AdaBelief
+  int32_t flags;      // bit0: divide grad by minibatch; bit1: weight decay scaled by lr; bit2: emit update only
+  float lr, a, b, eps;  // a/b: momentum | beta1,beta2 | rmsDecay | rho
+  float l1, l2, wd, pad;
+};
+static_assert(sizeof(UpdSeg) == 64, "UpdSeg layout is part of the ctypes ABI");
+
+#define UPD_CHUNK 2048
+
+__global__ void __launch_bounds__(256) segmented_updater_kernel(
+    float* __restrict__ params, float* __restrict__ grads, float* __restrict__ state,
+    bf16_t* __restrict__ shadow, const UpdSeg* __restrict__ segs, const int32_t* __restrict__ blk_seg,
+    const int32_t* __restrict__ blk_chunk, const int64_t* __restrict__ iter_dev, float inv_batch,
+    int write_update) {
+  const UpdSeg s = segs[blk_seg[blockIdx.x]];
+  const int64_t start = (int64_t)blk_chunk[blockIdx.x] * UPD_CHUNK;
+  const int64_t end = (start + UPD_CHUNK < s.len) ? start + UPD_CHUNK : s.len;
+  const float t = (float)(iter_dev[0] + 1);
+  const bool div = s.flags & 1, wd_lr = s.flags & 2, upd_only = s.flags & 4;
+  const int64_t n = s.len;
+  float* st = state + s.state_off;
+  // per-launch scalars
+  float alpha_t = s.lr;
+  const float eps = (s.eps == 0.f && s.kind >= 3) ? 1e-7f : s.eps;
+  if (s.kind == 3 || s.kind == 9 || s.kind == 10) {
+    const float b1t = powf(s.a, t), b2t = powf(s.b, t);
+    alpha_t = s.lr * sqrtf(1.f - b2t) / (1.f - b1t);
+    if (isnan(alpha_t) || alpha_t == 0.f || isinf(alpha_t)) alpha_t = eps;
+  } else if (s.kind == 7) {
+    alpha_t = s.lr / (1.f - powf(s.a, t));
+    if (isnan(alpha_t) || alpha_t == 0.f || isinf(alpha_t)) alpha_t = eps;
+  } else if (s.kind == 8) {
+    alpha_t = 1.f / (1.f - powf(s.a, t));
+  }
+  for (int64_t i = start + threadIdx.x; i < end; i += 256) {
+    const int64_t gi = s.off + i;
+    float g = grads[gi];
+    if (div) g *= inv_batch;
+    const float w = upd_only ? 0.f : params[gi];
+    if (s.l1 != 0.f) g += s.l1 * (w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f));
+    if (s.l2 != 0.f) g += s.l2 * w;
+    float u;
+    switch (s.kind) {
+      case 0: u = g; break;
+      case 1: u = s.lr * g; break;
+      case 2: {  // Nesterovs
+        const float vprev = s.a * st[i];
+        const float v = vprev - s.lr * g;
+        st[i] = v;
+        u = vprev - (s.a + 1.f) * v;
+      } break;
+      case 3: {  // Adam, state [m | v]
+        const float m = s.a * st[i] + (1.f - s.a) * g;
+        const float v = s.b * st[n + i] + (1.f - s.b) * g * g;
+        st[i] = m; st[n + i] = v;
+        u = m * alpha_t / (sqrtf(v) + eps);
+      } break;
+      case 4: {  // RmsProp
+        const float r = s.a * st[i] + (1.f - s.a) * g * g;
+        st[i] = r;
+        u = s.lr * g / (sqrtf(r) + eps);
+      } break;
+      case 5: {  // AdaGrad
+        const float h = st[i] + g * g;
+        st[i] = h;
+        u = s.lr * g / (sqrtf(h) + eps);
+      } break;
+      case 6: {  // AdaDelta, state [msg | msdx]
+        const float msg = s.a * st[i] + (1.f - s.a) * g * g;
+        const float msdx0 = st[n + i];
+        u = g * sqrtf(msdx0 + eps) / sqrtf(msg + eps);
+        st[i] = msg; st[n + i] = s.a * msdx0 + (1.f - s.a) * u * u;
+      } break;
+      case 7: {  // AdaMax, state [m | u]
+        const float m = s.a * st[i] + (1.f - s.a) * g;
+        const float ui = fmaxf(s.b * st[n + i], fabsf(g)) + 1e-32f;
+        st[i] = m; st[n + i] = ui;
+        u = m * alpha_t / ui;
+      } break;
+      case 8: {  // Nadam, state [m | v]
+        const float m = s.a * st[i] + (1.f - s.a) * g;
+        const float v = s.b * st[n + i] + (1.f - s.b) * g * g;
+        st[i] = m; st[n + i] = v;
+        u = s.lr * ((s.a * m + (1.f - s.a) * g) * alpha_t) / (sqrtf(v) + eps);
+      } break;
+      case 9: {  // AMSGrad, state [m | v | vHat]
+        const float m = s.a * st[i] + (1.f - s.a) * g;
+        const float v = s.b * st[n + i] + (1.f - s.b) * g * g;
+        const float h = fmaxf(st[2 * n + i], v);
+        st[i] = m; st[n + i] = v; st[2 * n + i] = h;
+        u = alpha_t * m / (sqrtf(h) + eps);
+      } break;
+      default: {  // AdaBelief, state [m | s]
+        const float m = s.a * st[i] + (1.f - s.a) * g;
+        const float d = g - m;
+        const float sv = s.b * st[n + i] + (1.f - s.b) * d * d + eps;
+        st[i] = m; st[n + i] = sv;
+        u = alpha_t * m / (sqrtf(sv) + eps);
+      } break;
+    }
+    if (s.wd != 0.f) u += s.wd * (wd_lr ? s.lr : 1.f) * w;
+    if (upd_only) {
+      grads[gi] = u;
+    } else {
+      const float wn = w - u;
+      params[gi] = wn;
+      if (shadow != nullptr) shadow[gi] = f2bf(wn);
+      if (write_update) grads[gi] = u;
+    }
+  }
+}
+
+__global__ void incr_iter_kernel(int64_t* it) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) it[0] += 1;
+}
+
+DL4J_API int dl4j_segmented_update(float* params, float* grads, float* state, void* shadow_bf16,
+                                   const void* segs, const int32_t* blk_seg, const int32_t* blk_chunk,
+                                   int num_blocks, int64_t* iter_dev, float inv_batch, int write_update,
+                                   int increment_iter, hipStream_t st) {
+  if (num_blocks > 0)
+    hipLaunchKernelGGL(segmented_updater_kernel, dim3(num_blocks), dim3(256), 0, st, params, grads, state,
+                       (bf16_t*)shadow_bf16, (const UpdSeg*)segs, blk_seg, blk_chunk, iter_dev, inv_batch,
+                       write_update);
+  if (increment_iter) hipLaunchKernelGGL(incr_iter_kernel, dim3(1), dim3(64), 0, st, iter_dev);
+  DL4J_RET_LAST();
+}
+
+// ---------------------------------------------------------------------------------------
+// Layout-aware cast table: refresh compute-dtype (bf16) weight replicas from the fp32 master
+// vector in one launch. Each entry copies a [O, I, K] (DL4J OIHW, K = kH*kW) block to
+// [O, K, I] (channels-last filter layout used by the implicit-GEMM kernels) or straight.
+// ---------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(8))) CastSeg {
+  int64_t src_off;   // into fp32 master vector
+  int64_t dst_off;   // into bf16 arena
+  int64_t len;
+  int32_t I, K;      // if K > 1: permute [O][I][K] -> [O][K][I]
+};
+static_assert(sizeof(CastSeg) == 32, "CastSeg layout is part of the ctypes ABI");
+
+__global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                         const CastSeg* __restrict__ segs,
+                                                         const int32_t* __restrict__ blk_seg,
+                                                         const int32_t* __restrict__ blk_chunk) {
+  const CastSeg s = segs[blk_seg[blockIdx.x]];
+  const int64_t start = (int64_t)blk_chunk[blockIdx.x] * UPD_CHUNK;
+  const int64_t end = (start + UPD_CHUNK < s.len) ? start + UPD_CHUNK : s.len;
+  const int64_t IK = (int64_t)s.I * s.K;
+  for (int64_t d = start + threadIdx.x; d < end; d += 256) {
+    int64_t si = d;
+    if (s.K > 1) {  // d indexes destination [o][k][i]
+      const int64_t o = d / IK, rem = d - o * IK;
+      const int64_t k = rem / s.I, i = rem - k * s.I;
+      si = o * IK + i * s.K + k;
+    }
+    dst[s.dst_off + d] = f2bf(src[s.src_off + si]);
+  }
+}
+
+DL4J_API int dl4j_cast_table(const float* src, void* dst_bf16, const void* segs, const int32_t* blk_seg,
+                             const int32_t* blk_chunk, int num_blocks, hipStream_t st) {
+  if (num_blocks > 0)
+    hipLaunchKernelGGL(cast_table_kernel, dim3(num_blocks), dim3(256), 0, st, src, (bf16_t*)dst_bf16,
+                       (const CastSeg*)segs, blk_seg, blk_chunk);
+  DL4J_RET_LAST();
+}
+
+// Sum of squares over the flat gradient (global L2 norm for gradient clipping), two-stage.
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const float* __restrict__ x, int64_t n,
+                                                            float* __restrict__ partial) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += x[i] * x[i];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+__global__ void __launch_bounds__(256) sum_final_kernel(const float* __restrict__ partial, int n,
+                                                        float* __restrict__ out) {
+  __shared__ float red[16];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += partial[i];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) out[0] = a;
+}
+DL4J_API int dl4j_sumsq(const float* x, int64_t n, float* partial /* >=1024 floats */, float* out, hipStream_t st) {
+  int g = grid_for(n, 256 * 8);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(g), dim3(256), 0, st, x, n, partial);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, partial, g, out);
+  DL4J_RET_LAST();
+}

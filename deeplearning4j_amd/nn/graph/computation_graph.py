@@ -1,0 +1,655 @@
+"""ComputationGraph (reference: deeplearning4j-nn/.../nn/graph/ComputationGraph.java, 4917 LoC).
+
+DAG of layers and vertices executed in topological order (ComputationGraph.java:1187) with
+epsilons summed at fan-out on the way back (:2795-2803). On top of the reference semantics the
+init-time *fusion planner* rewrites the execution plan (never the configuration / parameter
+layout) the way a ResNet wants it on MI355X:
+
+* Conv(+bias) -> BatchNorm           : bias folded out of the conv (it only shifts BN's mean);
+* BatchNorm -> ReLU                  : one fused normalise+ReLU pass, ReLU mask reused in backward;
+* BatchNorm -> Add(shortcut) -> ReLU : one fused normalise+add+ReLU pass; the shortcut may itself be
+                                       a BatchNorm (conv blocks) and is then normalised on the fly.
+
+This removes ~6 elementwise launches and ~4 full-tensor copies per bottleneck tail that the
+reference issues.
+"""
+from __future__ import annotations
+
+import copy
+import time
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+
+from ...nd4j.activations import ActivationReLU, ActivationIdentity
+from ..conf import graph as G
+from ..conf import layers as C
+from ..conf.base import BackpropType
+from ..conf.configuration import ComputationGraphConfiguration
+from ..layers import registry
+from ..layers.core import BatchNormalizationImpl, ConvolutionLayerImpl, ActivationLayerImpl
+from ..layers.recurrent import LSTMImpl, SimpleRnnImpl
+from ..network_base import BaseNetwork
+from .vertices import create_vertex, VertexImpl, ElementWiseVertexImpl, LastTimeStepVertexImpl, \
+    DuplicateToTimeSeriesVertexImpl, ReverseTimeSeriesVertexImpl
+
+
+class _Node:
+    __slots__ = ("out", "inputs", "impl", "pre", "is_layer", "is_output", "names")
+
+    def __init__(self, out, inputs, impl, pre=None, is_layer=True, is_output=False, names=None):
+        self.out, self.inputs, self.impl, self.pre = out, list(inputs), impl, pre
+        self.is_layer, self.is_output, self.names = is_layer, is_output, names or [out]
+
+    def forward(self, xs, train, mode=None):
+        if self.is_layer:
+            x = xs[0]
+            if self.pre is not None:
+                x = self.pre.preProcess(x, x.shape[0], train)
+            l = self.impl
+            if mode is not None and isinstance(l, (LSTMImpl, SimpleRnnImpl)):
+                if mode == "timestep":
+                    st = l.stateMap
+                    init = None
+                    if st:
+                        init = (st["prevActivation"], st["prevMemCell"]) if "prevMemCell" in st else (st["prevActivation"],)
+                    return l.forward(x, False, initial_state=init, store_state=True)
+                if mode == "tbptt" and isinstance(l, LSTMImpl):
+                    y = l.forward(x, train, initial_state=l.tbpttState.get("s"))
+                    l.tbpttState["s"] = tuple(t.detach() for t in l._last_state)
+                    return y
+            return l.forward(x, train)
+        return self.impl.forward(xs, train)
+
+    def backward(self, eps, mb):
+        if self.is_layer:
+            dx = self.impl.backward(eps)
+            if dx is not None and self.pre is not None:
+                dx = self.pre.backprop(dx, mb)
+            return [dx]
+        return self.impl.backward(eps)
+
+
+class _FusedBNNode(_Node):
+    """BN [-> Add(shortcut [BN'])] -> ReLU executed as one fused node."""
+    __slots__ = ("bn", "bn2", "has_res")
+
+    def __init__(self, out, inputs, bn, bn2, has_res, names):
+        super().__init__(out, inputs, bn, None, False, False, names)
+        self.bn, self.bn2, self.has_res = bn, bn2, has_res
+
+    def forward(self, xs, train, mode=None):
+        bn = self.bn
+        if not self.has_res:
+            return bn.forward(xs[0], train, relu=True)
+        if self.bn2 is None:
+            return bn.forward(xs[0], train, relu=True, residual=xs[1])
+        rs, rt = self.bn2.stats_only(xs[1], train)
+        return bn.forward(xs[0], train, relu=True, residual=xs[1], res_coeffs=(rs, rt))
+
+    def backward(self, eps, mb):
+        if not self.has_res:
+            return [self.bn.backward(eps)]
+        dxa, dz = self.bn.backward(eps, return_dz=True)
+        if self.bn2 is None:
+            return [dxa, dz]
+        return [dxa, self.bn2.backward(dz)]
+
+
+def _stats_only(self, x, train):
+    """Batch statistics / coefficients for a BN whose normalisation is applied inside another fused node."""
+    x2, shp = self._to2d(x)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    scale, shift = self.coefficients(x2, train)
+    if train:
+        self._x2, self._shp, self._out2, self._z2, self._want_dz = x2, shp, None, None, False
+    return scale, shift
+
+
+BatchNormalizationImpl.stats_only = _stats_only
+
+
+class ComputationGraph(BaseNetwork):
+    def __init__(self, conf: ComputationGraphConfiguration, device=None):
+        super().__init__()
+        if isinstance(conf, str):
+            conf = ComputationGraphConfiguration.fromJson(conf)
+        self.conf = conf
+        self._seed = conf.defaultConfiguration.seed
+        self._minibatch = conf.defaultConfiguration.miniBatch
+        self._device = device
+        self.iterationCount, self.epochCount = conf.iterationCount, conf.epochCount
+        self.vertices: "OrderedDict[str, object]" = OrderedDict()
+        self._inputs = self._labels = None
+        self.fusion_enabled = True
+
+    # ------------------------------------------------------------------ init
+    def init(self, params=None, cloneParametersArray=True):
+        if self._initialized:
+            return self
+        conf = self.conf
+        self.ctx = self._make_ctx(conf, self._device)
+        self.ctx.iteration, self.ctx.epoch = self.iterationCount, self.epochCount
+        self.topologicalOrder = [n for n in conf.topological_order() if n not in conf.networkInputs]
+        self._impls: "OrderedDict[str, object]" = OrderedDict()
+        for n in self.topologicalOrder:
+            v = conf.vertices[n]
+            if isinstance(v, G.LayerVertex):
+                impl = registry.create(v.layer, self.ctx)
+                impl.name = n
+            else:
+                impl = create_vertex(v, self.ctx)
+                impl.name = n
+            self._impls[n] = impl
+        self.vertices = self._impls
+        ins = set(conf.networkInputs)
+        for n, impl in self._impls.items():
+            if all(i in ins for i in conf.vertexInputs[n]) and hasattr(impl, "conf") and isinstance(conf.vertices[n], G.LayerVertex):
+                impl.needs_input_grad = False
+        self._alloc_params(params, cloneParametersArray)
+        self._plan = self._build_plan()
+        return self
+
+    def _ordered_layers(self):
+        return list(self._impls.values())
+
+    def _layer_key(self, idx):
+        return list(self._impls.keys())[idx]
+
+    def _consumers(self):
+        cons: Dict[str, List[str]] = {}
+        for n, ins in self.conf.vertexInputs.items():
+            for i in ins:
+                cons.setdefault(i, []).append(n)
+        return cons
+
+    def _build_plan(self):
+        conf = self.conf
+        cons = self._consumers()
+        outs = set(conf.networkOutputs)
+        impls = self._impls
+        fused_away = {}
+        nodes: "OrderedDict[str, _Node]" = OrderedDict()
+
+        def single(n):
+            return len(cons.get(n, [])) == 1 and n not in outs
+
+        def is_relu_layer(n):
+            l = impls.get(n)
+            return (isinstance(l, ActivationLayerImpl) and isinstance(l.conf.activationFn, ActivationReLU)
+                    and l.conf.idropout is None and conf.vertices[n].preProcessor is None)
+
+        def is_plain_bn(n):
+            l = impls.get(n)
+            return (isinstance(l, BatchNormalizationImpl) and isinstance(l.conf.activationFn, (ActivationIdentity, type(None)))
+                    and l.conf.idropout is None and conf.vertices[n].preProcessor is None)
+
+        for impl in impls.values():
+            if isinstance(impl, ConvolutionLayerImpl):
+                impl.fold_bias = False
+            elif isinstance(impl, BatchNormalizationImpl):
+                impl.conv_bias = None
+        if self.fusion_enabled:
+            for n in self.topologicalOrder:
+                if n in fused_away or not is_plain_bn(n) or not single(n):
+                    continue
+                c = cons[n][0]
+                if is_relu_layer(c):
+                    fused_away[n] = c
+                    fused_away[c] = c
+                    nodes[c] = _FusedBNNode(c, conf.vertexInputs[n], impls[n], None, False, [n, c])
+                    continue
+                ci = impls.get(c)
+                if (isinstance(ci, ElementWiseVertexImpl) and ci.conf.op == "Add" and len(conf.vertexInputs[c]) == 2
+                        and single(c) and is_relu_layer(cons[c][0])):
+                    r = cons[c][0]
+                    other = [i for i in conf.vertexInputs[c] if i != n]
+                    if len(other) != 1:
+                        continue
+                    o = other[0]
+                    if o in fused_away:
+                        continue
+                    bn2 = None
+                    in2 = o
+                    if o in impls and is_plain_bn(o) and single(o):
+                        bn2 = impls[o]
+                        in2 = conf.vertexInputs[o][0]
+                        fused_away[o] = r
+                    fused_away[n] = r
+                    fused_away[c] = r
+                    fused_away[r] = r
+                    nodes[r] = _FusedBNNode(r, [conf.vertexInputs[n][0], in2], impls[n], bn2, True, [n, c, r] + ([o] if bn2 else []))
+            # conv bias folding
+            for n in self.topologicalOrder:
+                a = impls[n]
+                if (isinstance(a, ConvolutionLayerImpl) and "b" in a.params and isinstance(a.conf.activationFn, ActivationIdentity)
+                        and single(n)):
+                    b = impls.get(cons[n][0])
+                    if isinstance(b, BatchNormalizationImpl) and conf.vertices[cons[n][0]].preProcessor is None and b.conf.idropout is None:
+                        a.fold_bias = True
+                        b.conv_bias = (lambda a=a: a.params["b"].reshape(-1))
+        plan = []
+        for n in self.topologicalOrder:
+            if n in fused_away:
+                if fused_away[n] == n or (n in nodes):
+                    pass
+                if n in nodes:
+                    plan.append(nodes[n])
+                continue
+            v = conf.vertices[n]
+            impl = impls[n]
+            if isinstance(v, G.LayerVertex):
+                plan.append(_Node(n, conf.vertexInputs[n], impl, v.preProcessor, True, getattr(impl, "is_output", False) and n in outs))
+            else:
+                plan.append(_Node(n, conf.vertexInputs[n], impl, None, False, False))
+        self._fused_alias = fused_away
+        # last-use table for freeing activations in inference
+        last = {}
+        for k, nd in enumerate(plan):
+            for i in nd.inputs:
+                last[i] = k
+        self._last_use = last
+        return plan
+
+    # ------------------------------------------------------------------ accessors
+    def getLayer(self, name):
+        if isinstance(name, int):
+            return [l for l in self._impls.values() if not isinstance(l, VertexImpl)][name]
+        return self._impls[name]
+
+    def getLayers(self):
+        return [l for l in self._impls.values() if not isinstance(l, VertexImpl)]
+
+    def getVertex(self, name):
+        return self._impls[name]
+
+    def getVertices(self):
+        return list(self._impls.values())
+
+    def getConfiguration(self):
+        return self.conf
+
+    def getNumInputArrays(self):
+        return len(self.conf.networkInputs)
+
+    def getNumOutputArrays(self):
+        return len(self.conf.networkOutputs)
+
+    def getOutputLayer(self, i=0):
+        return self._impls[self.conf.networkOutputs[i]]
+
+    def topologicalSortOrder(self):
+        return list(self.topologicalOrder)
+
+    def setInputs(self, *xs):
+        self._inputs = list(xs)
+
+    def setInput(self, i, x):
+        if self._inputs is None:
+            self._inputs = [None] * len(self.conf.networkInputs)
+        self._inputs[i] = x
+
+    def setLabels(self, *ys):
+        self._labels = list(ys)
+
+    def clear(self):
+        self._inputs = self._labels = None
+        for l in self._impls.values():
+            l.clear()
+
+    def clearLayerMaskArrays(self):
+        for l in self._impls.values():
+            if hasattr(l, "maskArray"):
+                l.maskArray = None
+            if hasattr(l, "mask"):
+                l.mask = None
+
+    def _check_init(self):
+        if not self._initialized:
+            self.init()
+
+    # ------------------------------------------------------------------ forward / backward
+    def _set_masks(self, fmasks):
+        if not fmasks or all(m is None for m in fmasks):
+            return
+        masks = {n: self._to_dev(m) for n, m in zip(self.conf.networkInputs, fmasks) if m is not None}
+        # propagate time-series masks along the graph (first-input rule, ComputationGraph.setLayerMaskArrays)
+        for n in self.topologicalOrder:
+            ins = self.conf.vertexInputs[n]
+            m = next((masks[i] for i in ins if i in masks), None)
+            impl = self._impls[n]
+            if m is None:
+                continue
+            if isinstance(impl, (LastTimeStepVertexImpl, ReverseTimeSeriesVertexImpl)):
+                nm = impl.conf.maskArrayInputName
+                impl.mask = masks.get(nm, m) if nm else m
+                if isinstance(impl, LastTimeStepVertexImpl):
+                    continue
+                masks[n] = m
+            elif hasattr(impl, "feedForwardMaskArray"):
+                v = self.conf.vertices[n]
+                mm = m
+                if isinstance(v, G.LayerVertex) and v.preProcessor is not None:
+                    mm = v.preProcessor.feedForwardMaskArray(m, m.shape[0])
+                out = impl.feedForwardMaskArray(mm, m.shape[0])
+                if out is not None:
+                    masks[n] = out
+            else:
+                masks[n] = m
+
+    def _forward(self, inputs, train, mode=None, keep_all=False, fmasks=None):
+        acts = dict(zip(self.conf.networkInputs, inputs))
+        self._set_masks(fmasks)
+        for n in self.topologicalOrder:
+            impl = self._impls[n]
+            if isinstance(impl, DuplicateToTimeSeriesVertexImpl):
+                ref = impl.conf.inputName
+                impl.ref_T = acts[ref].shape[2] if ref in acts else 1
+        last = self._last_use
+        outs = set(self.conf.networkOutputs)
+        for k, nd in enumerate(self._plan):
+            xs = [acts[i] for i in nd.inputs]
+            acts[nd.out] = nd.forward(xs, train, mode)
+            if not train and not keep_all:
+                for i in nd.inputs:
+                    if last.get(i) == k and i not in outs:
+                        acts.pop(i, None)
+        return acts
+
+    def _prep_inputs(self, xs):
+        if isinstance(xs, torch.Tensor) or not isinstance(xs, (list, tuple)):
+            xs = [xs]
+        return [self._prep_features(x) for x in xs]
+
+    def output(self, *xs, train=False, featureMasks=None):
+        self._check_init()
+        if len(xs) == 1 and isinstance(xs[0], (list, tuple)):
+            xs = xs[0]
+        if len(xs) == 1 and hasattr(xs[0], "hasNext"):
+            it = xs[0]
+            it.reset()
+            res = []
+            while it.hasNext():
+                d = it.next()
+                f = d.getFeatures()
+                res.append(self.output(*(f if isinstance(f, (list, tuple)) else [f])))
+            return [torch.cat([r[i] for r in res], 0) for i in range(len(res[0]))]
+        with torch.no_grad():
+            acts = self._forward(self._prep_inputs(list(xs)), train, fmasks=featureMasks)
+        self.clearLayerMaskArrays()
+        return [self._wrap(acts[o]) for o in self.conf.networkOutputs]
+
+    def outputSingle(self, *xs, train=False):
+        return self.output(*xs, train=train)[0]
+
+    def _wrap(self, y):
+        if y.is_floating_point() and y.dtype != self.ctx.dtype:
+            y = y.to(self.ctx.dtype)
+        if y.dim() == 4 and not y.is_contiguous():
+            y = y.contiguous()
+        return y
+
+    def feedForward(self, *xs, train=False):
+        """Map of ALL vertex activations (unfused execution, API parity)."""
+        self._check_init()
+        if len(xs) == 1 and isinstance(xs[0], (list, tuple)):
+            xs = xs[0]
+        old_plan, old_last = self._plan, self._last_use
+        fe = self.fusion_enabled
+        try:
+            self.fusion_enabled = False
+            self._plan = self._build_plan()
+            with torch.no_grad():
+                acts = self._forward(self._prep_inputs(list(xs)), train, keep_all=True)
+        finally:
+            self.fusion_enabled = fe
+            self._plan, self._last_use = old_plan, old_last
+            self._build_plan_restore()
+        return acts
+
+    def _build_plan_restore(self):
+        # restore fold flags after an unfused feedForward
+        self._plan = self._build_plan()
+
+    def _backward(self, mb):
+        eps: Dict[str, torch.Tensor] = {}
+        net_in = set(self.conf.networkInputs)
+        prog = self._on_backward_progress
+        if prog is not None:
+            if self._on_backward_begin is not None:
+                self._on_backward_begin()
+            offs = self._node_min_offsets()
+        for k_rev, nd in enumerate(reversed(self._plan)):
+            if prog is not None and k_rev > 0:
+                prog(offs[len(self._plan) - k_rev])
+            if nd.is_output:
+                dxs = [nd.impl.backward(None)]
+                if dxs[0] is not None and nd.pre is not None:
+                    dxs[0] = nd.pre.backprop(dxs[0], mb)
+            else:
+                e = eps.pop(nd.out, None)
+                if e is None:
+                    continue
+                dxs = nd.backward(e, mb)
+            for inp, dx in zip(nd.inputs, dxs):
+                if dx is None or inp in net_in:
+                    continue
+                prev = eps.get(inp)
+                eps[inp] = dx if prev is None else prev + dx
+        return eps
+
+    def _node_min_offsets(self):
+        """offs[k] = lowest flat-gradient offset owned by plan nodes k..end (all finished once node k ran backward)."""
+        if getattr(self, "_node_offs", None) is not None and len(self._node_offs) == len(self._plan) + 1:
+            return self._node_offs
+        by_impl = {}
+        for e in self._entries:
+            by_impl.setdefault(id(e.layer), []).append(e.off)
+        offs = [self._num_params] * (len(self._plan) + 1)
+        for k in range(len(self._plan) - 1, -1, -1):
+            nd = self._plan[k]
+            cand = [offs[k + 1]]
+            for impl in ([nd.impl] + ([nd.bn2] if getattr(nd, "bn2", None) is not None else [])):
+                cand += by_impl.get(id(impl), [])
+            offs[k] = min(cand)
+        self._node_offs = offs
+        return offs
+
+    def computeGradientAndScore(self, inputs=None, labels=None, fmasks=None, lmasks=None, mode=None):
+        self._check_init()
+        inputs = self._prep_inputs(self._inputs if inputs is None else inputs)
+        labels = self._labels if labels is None else labels
+        if isinstance(labels, torch.Tensor) or not isinstance(labels, (list, tuple)):
+            labels = [labels]
+        labels = [self._prep_labels(y) for y in labels]
+        mb = inputs[0].shape[0]
+        self._last_batch = mb
+        self._forward(inputs, True, mode, fmasks=fmasks)
+        total = None
+        for i, o in enumerate(self.conf.networkOutputs):
+            ol = self._impls[o]
+            if not getattr(ol, "is_output", False):
+                raise RuntimeError("Cannot compute score: output vertex '%s' is not an output layer" % o)
+            lm = self._to_dev(lmasks[i]) if lmasks is not None and lmasks[i] is not None else None
+            ol.setLabels(labels[i], lm)
+            s = ol.compute_score_sum()
+            total = s if total is None else total + s
+        self._score = (total / mb) if self._minibatch else total
+        self._backward(mb)
+        for lst in self.listeners:
+            if hasattr(lst, "onGradientCalculation"):
+                lst.onGradientCalculation(self)
+        return self._grads, self._score
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, data, labels=None, numEpochs=1):
+        self._check_init()
+        if labels is not None or isinstance(data, torch.Tensor):
+            self._fit_batch(data if isinstance(data, (list, tuple)) else [data],
+                            labels if isinstance(labels, (list, tuple)) else [labels], None, None)
+            return self
+        if hasattr(data, "getFeatures") and not hasattr(data, "hasNext"):
+            self._fit_ds(data)
+            return self
+        from ...datasets.iterators import AsyncDataSetIterator
+        it = data
+        for _ in range(numEpochs):
+            if it.resetSupported():
+                it.reset()
+            src = it
+            if it.asyncSupported() and not isinstance(it, AsyncDataSetIterator):
+                src = AsyncDataSetIterator(it, 2, device=self.ctx.device)
+            for l in self.listeners:
+                if hasattr(l, "onEpochStart"):
+                    l.onEpochStart(self)
+            t0 = time.time()
+            while src.hasNext():
+                ds = src.next()
+                self.lastEtlTime = int((time.time() - t0) * 1000)
+                self._fit_ds(ds)
+                t0 = time.time()
+            if src is not it and hasattr(src, "shutdown"):
+                src.shutdown()
+            for l in self.listeners:
+                if hasattr(l, "onEpochEnd"):
+                    l.onEpochEnd(self)
+            self.incrementEpochCount()
+        return self
+
+    def _fit_ds(self, ds):
+        f, l = ds.getFeatures(), ds.getLabels()
+        fm = getattr(ds, "getFeaturesMaskArrays", None)
+        if isinstance(f, (list, tuple)):
+            self._fit_batch(list(f), list(l), ds.getFeaturesMaskArrays(), ds.getLabelsMaskArrays())
+        else:
+            fmk, lmk = ds.getFeaturesMaskArray(), ds.getLabelsMaskArray()
+            self._fit_batch([f], [l], [fmk] if fmk is not None else None, [lmk] if lmk is not None else None)
+
+    def _fit_batch(self, xs, ys, fmasks, lmasks):
+        x0 = torch.as_tensor(xs[0]) if not hasattr(xs[0], "shape") else xs[0]
+        if (self.conf.backpropType == BackpropType.TruncatedBPTT and len(x0.shape) == 3
+                and x0.shape[2] > self.conf.tbpttFwdLength):
+            return self._fit_tbptt(xs, ys, fmasks, lmasks)
+        if self._graph_step is not None and fmasks is None and lmasks is None and len(xs) == 1 and len(ys) == 1:
+            self._graph_step.run(xs[0], ys[0])
+        else:
+            self.computeGradientAndScore(xs, ys, fmasks, lmasks)
+            self._apply_update(self._last_batch)
+        self.clearLayerMaskArrays()
+        self._after_iteration()
+
+    def _fit_tbptt(self, xs, ys, fmasks, lmasks):
+        xs = [self._to_dev(x) for x in xs]
+        ys = [self._to_dev(y) for y in ys]
+        T, L = xs[0].shape[2], self.conf.tbpttFwdLength
+        self.rnnClearPreviousState()
+        for s in range(0, T, L):
+            e = min(s + L, T)
+            sx = [x[:, :, s:e] if x.dim() == 3 else x for x in xs]
+            sy = [y[:, :, s:e] if y.dim() == 3 else y for y in ys]
+            fm = [m[:, s:e] if m is not None else None for m in fmasks] if fmasks else None
+            lm = [m[:, s:e] if m is not None and m.dim() == 2 and m.shape[1] == T else m for m in lmasks] if lmasks else None
+            self.computeGradientAndScore(sx, sy, fm, lm, mode="tbptt")
+            self._apply_update(self._last_batch)
+            self._after_iteration()
+        self.rnnClearPreviousState()
+        self.clearLayerMaskArrays()
+
+    # ------------------------------------------------------------------ rnn
+    def rnnTimeStep(self, *xs):
+        self._check_init()
+        ins = self._prep_inputs(list(xs))
+        squeeze = ins[0].dim() == 2
+        if squeeze:
+            ins = [x.unsqueeze(2) for x in ins]
+        with torch.no_grad():
+            acts = self._forward(ins, False, mode="timestep")
+        outs = [self._wrap(acts[o]) for o in self.conf.networkOutputs]
+        if squeeze:
+            outs = [o[:, :, 0] if o.dim() == 3 else o for o in outs]
+        return outs
+
+    def rnnClearPreviousState(self):
+        for l in self._impls.values():
+            if hasattr(l, "rnnClearPreviousState"):
+                l.rnnClearPreviousState()
+
+    # ------------------------------------------------------------------ scoring / evaluation
+    def _score_dataset(self, ds, training=False):
+        f, l = ds.getFeatures(), ds.getLabels()
+        f = list(f) if isinstance(f, (list, tuple)) else [f]
+        l = list(l) if isinstance(l, (list, tuple)) else [l]
+        with torch.no_grad():
+            ins = self._prep_inputs(f)
+            self._forward(ins, training)
+            tot = 0.0
+            for i, o in enumerate(self.conf.networkOutputs):
+                ol = self._impls[o]
+                ol.setLabels(self._prep_labels(l[i]), None)
+                tot = tot + ol.compute_score_sum()
+            s = tot / ins[0].shape[0]
+            r = self.calcRegularizationScore()
+        return float(s + r) if r is not None else float(s)
+
+    def evaluate(self, iterator, labelsList=None, topN=1):
+        from ...eval.evaluation import Evaluation
+        return self.doEvaluation(iterator, Evaluation(labels=labelsList, topN=topN))[0]
+
+    def evaluateRegression(self, iterator):
+        from ...eval.evaluation import RegressionEvaluation
+        return self.doEvaluation(iterator, RegressionEvaluation())[0]
+
+    def evaluateROC(self, iterator, thresholdSteps=0):
+        from ...eval.evaluation import ROC
+        return self.doEvaluation(iterator, ROC(thresholdSteps))[0]
+
+    def doEvaluation(self, iterator, *evals):
+        if iterator.resetSupported():
+            iterator.reset()
+        while iterator.hasNext():
+            ds = iterator.next()
+            f = ds.getFeatures()
+            out = self.output(*(f if isinstance(f, (list, tuple)) else [f]))[0]
+            lab = ds.getLabels()
+            lab = lab[0] if isinstance(lab, (list, tuple)) else lab
+            lm = ds.getLabelsMaskArray() if hasattr(ds, "getLabelsMaskArray") else None
+            for e in evals:
+                e.eval(self._to_dev(lab), out, self._to_dev(lm))
+        return list(evals)
+
+    # ------------------------------------------------------------------ misc
+    def summary(self):
+        lines = ["=" * 110, "%-36s %-22s %-12s %-14s %s" % ("VertexName (VertexType)", "nIn,nOut", "TotalParams", "ParamsShape", "Inputs"),
+                 "=" * 110]
+        tot = 0
+        for n, impl in self._impls.items():
+            c = impl.conf
+            np_ = sum(s.numel for s in impl.param_specs())
+            tot += np_
+            lines.append("%-36s %-22s %-12d %-14s %s" % ("%s (%s)" % (n, type(c).__name__), "%s,%s" % (getattr(c, "nIn", "-"), getattr(c, "nOut", "-")),
+                                                         np_, ",".join(s.key for s in impl.param_specs()), self.conf.vertexInputs[n]))
+        lines += ["-" * 110, "%30s %d" % ("Total Parameters:", tot), "=" * 110]
+        return "\n".join(lines)
+
+    def clone(self):
+        net = ComputationGraph(self.conf.clone(), device=self.ctx.device if self._initialized else self._device)
+        if self._initialized:
+            net.init(self._params, True)
+            net.setUpdaterState(self.getUpdaterState())
+        return net
+
+    def save(self, path, saveUpdater=True):
+        from ...utils.model_serializer import ModelSerializer
+        ModelSerializer.writeModel(self, path, saveUpdater)
+
+    @staticmethod
+    def load(path, loadUpdater=True, device=None):
+        from ...utils.model_serializer import ModelSerializer
+        return ModelSerializer.restoreComputationGraph(path, loadUpdater, device=device)
+
+    def enableGraphCapture(self, enabled=True):
+        from ..graph_capture import CapturedTrainStep
+        self._graph_step = CapturedTrainStep(self) if enabled and self.ctx.device.type == "cuda" else None
+        return self

@@ -1,0 +1,153 @@
+"""Fused BatchNorm forward/backward on channels-last activations viewed as [M, C].
+
+GPU (fp32 / bf16): hand-written HIP kernels in ``native/csrc/batchnorm.hip``.
+CPU or fp64 (gradient checks): the same math in plain PyTorch — this is also the numerics
+oracle for the GPU tests.
+
+Math = DL4J BatchNormalization (reference
+deeplearning4j-nn/.../nn/layers/normalization/BatchNormalization.java:280-353,492-566):
+biased batch variance, running statistics updated *through the gradient vector*.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from ..native import lib as L
+
+_LN10 = math.log(10.0)
+
+
+class BNContext:
+    """Per-call saved state for the backward pass."""
+    __slots__ = ("x", "out", "mean", "invstd", "scale", "shift", "relu", "M", "C", "res_ctx")
+
+
+def _hip_ok(x):
+    return L.use_hip(x) and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous()
+
+
+def running_stat_grads(mean, var, gmean, gvar, decay, log_std, conv_bias=None):
+    bm = mean if conv_bias is None else mean + conv_bias
+    dmean = (gmean - bm) * (1.0 - decay)
+    if log_std:
+        vt = torch.pow(10.0, 2.0 * gvar)
+        vnew = decay * vt + (1.0 - decay) * var
+        dvar = torch.log(vt / vnew) / (2.0 * _LN10)
+    else:
+        dvar = (gvar - var) * (1.0 - decay)
+    return dmean, dvar
+
+
+def infer_coeffs(gamma, beta, gmean, gvar, eps, log_std, conv_bias=None):
+    """scale/shift for inference from the global statistics."""
+    C = gmean.numel()
+    if L.use_hip(gmean) and gmean.dtype == torch.float32:
+        scale = torch.empty(C, device=gmean.device, dtype=torch.float32)
+        shift = torch.empty_like(scale)
+        L.check(L.hip().dl4j_bn_infer_coeffs(L.ptr(gamma), L.ptr(beta), L.ptr(gmean), L.ptr(gvar), L.ptr(conv_bias),
+                                             L.ptr(scale), L.ptr(shift), L.c_int(C), L.c_float(eps),
+                                             L.c_int(1 if log_std else 0), L.stream()), "bn_infer_coeffs")
+        return scale, shift
+    var = torch.pow(10.0, 2.0 * gvar) if log_std else gvar
+    g = gamma if gamma is not None else torch.ones_like(gmean)
+    b = beta if beta is not None else torch.zeros_like(gmean)
+    scale = g / torch.sqrt(var + eps)
+    m = gmean if conv_bias is None else gmean - conv_bias
+    return scale, b - m * scale
+
+
+def apply(x2d, scale, shift, residual=None, rscale=None, rshift=None, relu=False):
+    """y = act(x*scale + shift [+ residual(*rscale + rshift)])."""
+    M, C = x2d.shape
+    if _hip_ok(x2d):
+        y = torch.empty_like(x2d)
+        L.check(L.hip().dl4j_bn_apply(L.ptr(x2d), L.ptr(scale), L.ptr(shift), L.ptr(residual), L.ptr(rscale),
+                                      L.ptr(rshift), L.ptr(y), L.c_int64(M), L.c_int(C), L.c_int(1 if relu else 0),
+                                      L.c_int(L.dtype_code(x2d)), L.stream()), "bn_apply")
+        return y
+    cd = torch.float32 if x2d.dtype == torch.bfloat16 else x2d.dtype
+    y = x2d.to(cd) * scale.to(cd) + shift.to(cd)
+    if residual is not None:
+        r = residual.to(cd)
+        if rscale is not None:
+            r = r * rscale.to(cd) + rshift.to(cd)
+        y = y + r
+    if relu:
+        y = torch.relu(y)
+    return y.to(x2d.dtype)
+
+
+def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std=False, conv_bias=None,
+                dgmean_out=None, dgvar_out=None):
+    """Batch statistics + affine coefficients. Returns (mean, invstd, scale, shift)."""
+    M, C = x2d.shape
+    stat_mode = 0 if dgmean_out is None else (2 if log_std else 1)
+    if _hip_ok(x2d):
+        dev = x2d.device
+        buf = torch.empty(6 * C, device=dev, dtype=torch.float32)
+        sums, mean, invstd, scale, shift = buf[:2 * C], buf[2 * C:3 * C], buf[3 * C:4 * C], buf[4 * C:5 * C], buf[5 * C:]
+        h = L.hip()
+        L.check(h.dl4j_bn_stats(L.ptr(x2d), L.ptr(sums), L.c_int64(M), L.c_int(C), L.c_int(L.dtype_code(x2d)),
+                                L.stream()), "bn_stats")
+        L.check(h.dl4j_bn_finalize(L.ptr(sums), L.ptr(gamma), L.ptr(beta), L.ptr(conv_bias), L.ptr(gmean),
+                                   L.ptr(gvar), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift),
+                                   L.ptr(dgmean_out), L.ptr(dgvar_out), L.c_int(C), L.c_int64(M), L.c_float(eps),
+                                   L.c_float(decay), L.c_int(stat_mode), L.stream()), "bn_finalize")
+        return mean, invstd, scale, shift
+    cd = torch.float32 if x2d.dtype == torch.bfloat16 else x2d.dtype
+    xf = x2d.to(cd)
+    mean = xf.mean(0)
+    var = xf.var(0, unbiased=False)
+    invstd = torch.rsqrt(var + eps)
+    g = gamma.to(cd) if gamma is not None else torch.ones_like(mean)
+    b = beta.to(cd) if beta is not None else torch.zeros_like(mean)
+    scale = g * invstd
+    shift = b - mean * scale
+    if stat_mode:
+        dm, dv = running_stat_grads(mean, var, gmean.to(cd), gvar.to(cd), decay, log_std,
+                                    None if conv_bias is None else conv_bias.to(cd))
+        dgmean_out.copy_(dm)
+        dgvar_out.copy_(dv)
+    return mean, invstd, scale, shift
+
+
+def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_dz=False):
+    """BatchNorm backward. ``out2d`` (optional) is the fused ReLU output used as mask.
+
+    Returns (dx, dz) where dz = dy*[out>0] (only materialised when want_dz).
+    dgamma/dbeta are written into the given fp32 gradient views (may be None for lockGammaBeta).
+    """
+    M, C = x2d.shape
+    if _hip_ok(x2d) and dy2d.is_contiguous() and (out2d is None or out2d.is_contiguous()):
+        h = L.hip()
+        sums = torch.empty(2 * C, device=x2d.device, dtype=torch.float32)
+        dt = L.c_int(L.dtype_code(x2d))
+        L.check(h.dl4j_bn_bwd_reduce(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd),
+                                     L.ptr(sums), L.c_int64(M), L.c_int(C), dt, L.stream()), "bn_bwd_reduce")
+        dx = torch.empty_like(x2d)
+        dz = torch.empty_like(x2d) if want_dz else None
+        L.check(h.dl4j_bn_bwd_dx(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                 L.ptr(sums), L.ptr(dx), L.ptr(dz), L.c_int64(M), L.c_int(C), dt, L.stream()),
+                "bn_bwd_dx")
+        if dbeta_out is not None:
+            dbeta_out.copy_(sums[:C])
+        if dgamma_out is not None:
+            dgamma_out.copy_(sums[C:])
+        return dx, dz
+    cd = torch.float32 if x2d.dtype == torch.bfloat16 else x2d.dtype
+    xf, dz = x2d.to(cd), dy2d.to(cd)
+    if out2d is not None:
+        dz = dz * (out2d > 0).to(cd)
+    xhat = (xf - mean.to(cd)) * invstd.to(cd)
+    dbeta = dz.sum(0)
+    dgamma = (dz * xhat).sum(0)
+    g = gamma.to(cd) if gamma is not None else torch.ones_like(dbeta)
+    dx = (g * invstd.to(cd)) * (dz - dbeta / M - xhat * dgamma / M)
+    if dbeta_out is not None:
+        dbeta_out.copy_(dbeta)
+    if dgamma_out is not None:
+        dgamma_out.copy_(dgamma)
+    return dx.to(x2d.dtype), (dz.to(x2d.dtype) if want_dz else None)

@@ -1,0 +1,233 @@
+"""Segmented fused updater over flat params / grads / state (see native/csrc/updaters.hip).
+
+``SegmentedUpdater`` is built once from the network's UpdaterBlocks (contiguous parameter ranges
+sharing one IUpdater config — reference: deeplearning4j-nn/.../nn/updater/BaseMultiLayerUpdater.java:83-141)
+and applies {÷minibatch, L1/L2, updater, weight decay, params -= update} in ONE launch on GPU.
+The CPU path applies the identical formulas with PyTorch ops per segment (oracle for tests).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from ..native import lib as L
+
+KIND = {"NoOp": 0, "Sgd": 1, "Nesterovs": 2, "Adam": 3, "RmsProp": 4, "AdaGrad": 5, "AdaDelta": 6, "AdaMax": 7,
+        "Nadam": 8, "AMSGrad": 9, "AdaBelief": 10}
+STATE_MULT = {0: 0, 1: 0, 2: 1, 3: 2, 4: 1, 5: 1, 6: 2, 7: 2, 8: 2, 9: 3, 10: 2}
+CHUNK = 2048
+
+
+@dataclass
+class Segment:
+    off: int
+    length: int
+    state_off: int
+    kind: int
+    lr: float = 0.0
+    a: float = 0.0
+    b: float = 0.0
+    eps: float = 0.0
+    l1: float = 0.0
+    l2: float = 0.0
+    wd: float = 0.0
+    divide_by_batch: bool = True
+    wd_apply_lr: bool = True
+    update_only: bool = False
+
+    def pack(self) -> bytes:
+        flags = (1 if self.divide_by_batch else 0) | (2 if self.wd_apply_lr else 0) | (4 if self.update_only else 0)
+        return struct.pack("<qqqiifffffffxxxx", self.off, self.length, self.state_off, self.kind, flags, self.lr,
+                           self.a, self.b, self.eps, self.l1, self.l2, self.wd)
+
+
+def _block_tables(lengths):
+    seg_ids, chunks = [], []
+    for si, n in enumerate(lengths):
+        nb = (n + CHUNK - 1) // CHUNK
+        seg_ids.append(np.full(nb, si, dtype=np.int32))
+        chunks.append(np.arange(nb, dtype=np.int32))
+    if not seg_ids:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32)
+    return np.concatenate(seg_ids), np.concatenate(chunks)
+
+
+class SegmentedUpdater:
+    def __init__(self, segments: List[Segment], device):
+        self.segments = segments
+        self.device = torch.device(device)
+        self._tables_dirty = True
+        self._seg_dev = None
+        bs, bc = _block_tables([s.length for s in segments])
+        self.num_blocks = int(bs.shape[0])
+        self._blk_seg = torch.from_numpy(bs).to(self.device)
+        self._blk_chunk = torch.from_numpy(bc).to(self.device)
+        self.iter_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._upload()
+
+    def _upload(self):
+        raw = b"".join(s.pack() for s in self.segments)
+        arr = torch.frombuffer(bytearray(raw), dtype=torch.uint8) if raw else torch.zeros(0, dtype=torch.uint8)
+        if self._seg_dev is None or self._seg_dev.numel() != arr.numel():
+            self._seg_dev = arr.to(self.device)
+        else:
+            self._seg_dev.copy_(arr, non_blocking=True)
+        self._tables_dirty = False
+
+    def set_learning_rates(self, lrs):
+        """Update per-segment learning rates (ISchedule support); table re-uploaded lazily."""
+        changed = False
+        for s, lr in zip(self.segments, lrs):
+            if lr is not None and s.lr != lr:
+                s.lr = float(lr)
+                changed = True
+        if changed:
+            self._tables_dirty = True
+
+    def set_iteration(self, it: int):
+        self.iter_dev.fill_(int(it))
+
+    def step(self, params, grads, state, batch_size: int, write_update: bool = False, shadow=None):
+        if self._tables_dirty:
+            self._upload()
+        inv_b = 1.0 / float(max(batch_size, 1))
+        if L.use_hip(params) and params.dtype == torch.float32:
+            L.check(L.hip().dl4j_segmented_update(
+                L.ptr(params), L.ptr(grads), L.ptr(state), L.ptr(shadow), L.ptr(self._seg_dev), L.ptr(self._blk_seg),
+                L.ptr(self._blk_chunk), L.c_int(self.num_blocks), L.ptr(self.iter_dev), L.c_float(inv_b),
+                L.c_int(1 if write_update else 0), L.c_int(1), L.stream()), "segmented_update")
+            return
+        t = float(self.iter_dev.item() + 1)
+        for s in self.segments:
+            apply_segment_reference(s, params, grads, state, inv_b, t, write_update)
+        self.iter_dev += 1
+
+
+def apply_segment_reference(s: Segment, params, grads, state, inv_b, t, write_update=False):
+    """PyTorch implementation of one segment (CPU path, fp64 gradient checks and GPU test oracle)."""
+    n = s.length
+    g = grads[s.off:s.off + n].clone()
+    w = params[s.off:s.off + n] if not s.update_only else torch.zeros_like(g)
+    if s.divide_by_batch:
+        g = g * inv_b
+    if s.l1:
+        g = g + s.l1 * torch.sign(w)
+    if s.l2:
+        g = g + s.l2 * w
+    st = state[s.state_off:s.state_off + STATE_MULT[s.kind] * n] if STATE_MULT[s.kind] else None
+    k = s.kind
+    eps = 1e-7 if (s.eps == 0.0 and k >= 3) else s.eps
+
+    def fix(alpha):
+        if alpha != alpha or alpha == 0.0 or alpha in (float("inf"), float("-inf")):
+            return eps
+        return alpha
+    if k == 0:
+        u = g
+    elif k == 1:
+        u = s.lr * g
+    elif k == 2:
+        vprev = s.a * st[:n]
+        v = vprev - s.lr * g
+        st[:n] = v
+        u = vprev - (s.a + 1.0) * v
+    elif k in (3, 9, 10):
+        alpha = fix(s.lr * (1.0 - s.b ** t) ** 0.5 / (1.0 - s.a ** t)) if (1.0 - s.a ** t) != 0 else eps
+        m = s.a * st[:n] + (1.0 - s.a) * g
+        st[:n] = m
+        if k == 3:
+            v = s.b * st[n:2 * n] + (1.0 - s.b) * g * g
+            st[n:2 * n] = v
+            u = m * alpha / (torch.sqrt(v) + eps)
+        elif k == 9:
+            v = s.b * st[n:2 * n] + (1.0 - s.b) * g * g
+            hh = torch.maximum(st[2 * n:3 * n], v)
+            st[n:2 * n] = v
+            st[2 * n:3 * n] = hh
+            u = alpha * m / (torch.sqrt(hh) + eps)
+        else:
+            d = g - m
+            sv = s.b * st[n:2 * n] + (1.0 - s.b) * d * d + eps
+            st[n:2 * n] = sv
+            u = alpha * m / (torch.sqrt(sv) + eps)
+    elif k == 4:
+        r = s.a * st[:n] + (1.0 - s.a) * g * g
+        st[:n] = r
+        u = s.lr * g / (torch.sqrt(r) + eps)
+    elif k == 5:
+        hh = st[:n] + g * g
+        st[:n] = hh
+        u = s.lr * g / (torch.sqrt(hh) + eps)
+    elif k == 6:
+        msg = s.a * st[:n] + (1.0 - s.a) * g * g
+        msdx0 = st[n:2 * n].clone()
+        u = g * torch.sqrt(msdx0 + eps) / torch.sqrt(msg + eps)
+        st[:n] = msg
+        st[n:2 * n] = s.a * msdx0 + (1.0 - s.a) * u * u
+    elif k == 7:
+        alpha = fix(s.lr / (1.0 - s.a ** t)) if (1.0 - s.a ** t) != 0 else eps
+        m = s.a * st[:n] + (1.0 - s.a) * g
+        ui = torch.maximum(s.b * st[n:2 * n], g.abs()) + 1e-32
+        st[:n] = m
+        st[n:2 * n] = ui
+        u = m * alpha / ui
+    elif k == 8:
+        m = s.a * st[:n] + (1.0 - s.a) * g
+        v = s.b * st[n:2 * n] + (1.0 - s.b) * g * g
+        st[:n] = m
+        st[n:2 * n] = v
+        u = s.lr * ((s.a * m + (1.0 - s.a) * g) / (1.0 - s.a ** t)) / (torch.sqrt(v) + eps)
+    else:
+        raise ValueError(k)
+    if s.wd:
+        u = u + s.wd * (s.lr if s.wd_apply_lr else 1.0) * w
+    if s.update_only:
+        grads[s.off:s.off + n] = u
+    else:
+        params[s.off:s.off + n] = w - u
+        if write_update:
+            grads[s.off:s.off + n] = u
+
+
+# ---------------------------------------------------------------------------------------------
+class CastTable:
+    """One-launch refresh of compute-dtype (bf16) weight replicas from the fp32 master vector,
+    with optional OIHW -> OHWI (channels-last filter) permutation per entry."""
+
+    def __init__(self, entries, device):
+        # entries: list of (src_off, dst_off, len, I, K)
+        self.entries = list(entries)
+        self.device = torch.device(device)
+        raw = b"".join(struct.pack("<qqqii", *e) for e in self.entries)
+        self._seg = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device) if raw
+                     else torch.zeros(0, dtype=torch.uint8, device=self.device))
+        bs, bc = _block_tables([e[2] for e in self.entries])
+        self.num_blocks = int(bs.shape[0])
+        self._blk_seg = torch.from_numpy(bs).to(self.device)
+        self._blk_chunk = torch.from_numpy(bc).to(self.device)
+
+    def run(self, src_f32, dst_bf16):
+        if L.use_hip(src_f32):
+            L.check(L.hip().dl4j_cast_table(L.ptr(src_f32), L.ptr(dst_bf16), L.ptr(self._seg), L.ptr(self._blk_seg),
+                                            L.ptr(self._blk_chunk), L.c_int(self.num_blocks), L.stream()),
+                    "cast_table")
+            return
+        for (so, do, n, I, K) in self.entries:
+            s = src_f32[so:so + n]
+            if K > 1:
+                s = s.view(-1, I, K).permute(0, 2, 1).reshape(-1)
+            dst_bf16[do:do + n] = s.to(dst_bf16.dtype)
+
+
+def global_sumsq(x: torch.Tensor) -> torch.Tensor:
+    """sum(x^2) over a flat fp32 vector as a 1-element device tensor (no host sync)."""
+    if L.use_hip(x) and x.dtype == torch.float32:
+        partial = torch.empty(1024, device=x.device, dtype=torch.float32)
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+        L.check(L.hip().dl4j_sumsq(L.ptr(x), L.c_int64(x.numel()), L.ptr(partial), L.ptr(out), L.stream()), "sumsq")
+        return out
+    return (x.double() * x.double()).sum().to(x.dtype).reshape(1)

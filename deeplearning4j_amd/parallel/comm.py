@@ -1,0 +1,157 @@
+"""Collective communication layer: RCCL over xGMI through torch.distributed (backend "nccl" IS RCCL
+on ROCm); gloo for CPU tests. One process per GPU.
+
+Replaces the reference's single-kernel peer averaging (`average(..., propagate=true)`,
+libnd4j/include/loops/cuda/specials/averagingKernel.cu:29-76, NativeOps.cu:1677-1704: ONE device
+reads all peers over P2P, no overlap) with bucketed all-reduce of the flat gradient vector. Bucket
+sizes are chosen for xGMI's point-to-point links (7 x ~153 GB/s per GPU): few, large messages
+(default 32 MiB) so the per-collective launch/sync cost is amortised and RCCL can stripe over links.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_process_group(backend: Optional[str] = None, timeout_s: int = 600):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* env (no-op for world size 1 unless forced)."""
+    if dist.is_initialized():
+        return
+    rank, local_rank, world = env_world()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    import datetime
+    kw = {}
+    if backend == "nccl" and torch.cuda.is_available():
+        kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+    dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=timeout_s), **kw)
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def broadcast_(t: torch.Tensor, src=0):
+    if world_size() > 1:
+        dist.broadcast(t, src)
+    return t
+
+
+def all_reduce_avg_(t: torch.Tensor, async_op=False):
+    """In-place average across ranks."""
+    if world_size() == 1:
+        return None
+    if dist.get_backend() == "nccl":
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)
+    w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+    if async_op:
+        return _ScaledWork(w, t, 1.0 / world_size())
+    t.mul_(1.0 / world_size())
+    return None
+
+
+class _ScaledWork:
+    def __init__(self, work, t, s):
+        self.work, self.t, self.s = work, t, s
+
+    def wait(self):
+        self.work.wait()
+        self.t.mul_(self.s)
+
+
+def all_reduce_sum_(t, async_op=False):
+    if world_size() == 1:
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def all_gather(t: torch.Tensor) -> List[torch.Tensor]:
+    if world_size() == 1:
+        return [t]
+    out = [torch.empty_like(t) for _ in range(world_size())]
+    dist.all_gather(out, t)
+    return out
+
+
+def reduce_scatter_avg(flat: torch.Tensor) -> torch.Tensor:
+    """Reduce-scatter of a flat vector whose length is divisible by world size; returns this rank's shard."""
+    w = world_size()
+    if w == 1:
+        return flat
+    shard = torch.empty(flat.numel() // w, dtype=flat.dtype, device=flat.device)
+    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+    return shard.mul_(1.0 / w)
+
+
+class GradientBuckets:
+    """Contiguous ranges of the flat gradient vector reduced as separate collectives.
+
+    Backward fills the flat vector from its tail (last layer) to its head, so bucket ``k`` can be
+    launched as soon as every parameter at offset >= bucket_start has its gradient — the overlap
+    hook calls :meth:`ready` with the lowest finished offset."""
+
+    def __init__(self, flat_grads: torch.Tensor, bucket_bytes: int = 32 << 20):
+        n = flat_grads.numel()
+        per = max(1, bucket_bytes // flat_grads.element_size())
+        self.flat = flat_grads
+        bounds = list(range(0, n, per)) + [n]
+        self.ranges = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
+        self._next = len(self.ranges) - 1
+        self._works = []
+        self.comm_stream = torch.cuda.Stream() if flat_grads.is_cuda else None
+
+    def begin(self):
+        self._next = len(self.ranges) - 1
+        self._works = []
+
+    def ready(self, min_done_offset: int):
+        """Launch every not-yet-launched bucket whose range is complete."""
+        while self._next >= 0 and self.ranges[self._next][0] >= min_done_offset:
+            self._launch(self._next)
+            self._next -= 1
+
+    def _launch(self, k):
+        s, e = self.ranges[k]
+        seg = self.flat[s:e]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                w = all_reduce_avg_(seg, async_op=True)
+        else:
+            w = all_reduce_avg_(seg, async_op=True)
+        if w is not None:
+            self._works.append(w)
+
+    def finish(self):
+        self.ready(0)
+        for w in self._works:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._works = []
+
+    def reduce_all(self):
+        """Non-overlapped path: reduce every bucket on the current stream."""
+        for s, e in self.ranges:
+            all_reduce_avg_(self.flat[s:e])

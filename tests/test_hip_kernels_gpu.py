@@ -1,0 +1,182 @@
+"""GPU numerics tests: every hand-written HIP kernel vs a plain PyTorch fp32 reference of the same op."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def test_native_lib_loaded():
+    from deeplearning4j_amd.native import lib
+    assert lib.hip() is not None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C", [(4096, 64), (1000, 256), (777, 24), (50, 2048), (3000, 7)])
+def test_batchnorm_forward_backward(dtype, M, C):
+    from deeplearning4j_amd.ops import batchnorm as BN
+    torch.manual_seed(0)
+    x = (torch.randn(M, C, device=dev()) * 2 + 0.5).to(dtype)
+    res = torch.randn(M, C, device=dev()).to(dtype)
+    dy = torch.randn(M, C, device=dev()).to(dtype)
+    gamma = torch.rand(C, device=dev()) + 0.5
+    beta = torch.randn(C, device=dev())
+    gmean = torch.randn(C, device=dev()) * 0.1
+    gvar = torch.rand(C, device=dev()) * 0.2
+    for log_std in (False, True):
+        dgm, dgv = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+        mean, invstd, scale, shift = BN.batch_stats(x, gamma, beta, 1e-5, 0.9, gmean, gvar, log_std, None, dgm, dgv)
+        xc = x.float().cpu()
+        rm, rv = xc.mean(0), xc.var(0, unbiased=False)
+        tol = 1e-4 if dtype == torch.float32 else 2e-3
+        assert torch.allclose(mean.cpu(), rm, atol=tol, rtol=tol)
+        assert torch.allclose(invstd.cpu(), torch.rsqrt(rv + 1e-5), atol=tol, rtol=1e-3)
+        rdm, rdv = BN.running_stat_grads(rm, rv, gmean.cpu(), gvar.cpu(), 0.9, log_std)
+        assert torch.allclose(dgm.cpu(), rdm, atol=1e-3, rtol=1e-3)
+        assert torch.allclose(dgv.cpu(), rdv, atol=1e-3, rtol=1e-3)
+    y = BN.apply(x, scale, shift, res, None, None, True)
+    yr = torch.relu(x.float() * scale + shift + res.float())
+    atol = 1e-5 if dtype == torch.float32 else 3e-2
+    assert torch.allclose(y.float(), yr, atol=atol, rtol=1e-2)
+    # dual-BN residual
+    y2 = BN.apply(x, scale, shift, res, scale * 0.5, shift + 1.0, False)
+    y2r = x.float() * scale + shift + (res.float() * scale * 0.5 + shift + 1.0)
+    assert torch.allclose(y2.float(), y2r, atol=atol * 2, rtol=1e-2)
+    # backward vs CPU reference implementation of the same math
+    dg, db = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    dx, dz = BN.backward(x, dy, y, mean, invstd, gamma, dg, db, want_dz=True)
+    dgr, dbr = torch.empty(C), torch.empty(C)
+    dxr, dzr = BN.backward(x.float().cpu(), dy.float().cpu(), y.float().cpu(), mean.cpu(), invstd.cpu(), gamma.cpu(),
+                           dgr, dbr, want_dz=True)
+    t = 1e-3 if dtype == torch.float32 else 5e-2
+    assert torch.allclose(db.cpu(), dbr, atol=t * (M ** 0.5), rtol=2e-2)
+    assert torch.allclose(dg.cpu(), dgr, atol=t * (M ** 0.5), rtol=2e-2)
+    assert torch.allclose(dz.float().cpu(), dzr, atol=1e-6, rtol=1e-6)
+    assert torch.allclose(dx.float().cpu(), dxr, atol=t, rtol=5e-2)
+
+
+@pytest.mark.parametrize("kind", ["NoOp", "Sgd", "Nesterovs", "Adam", "RmsProp", "AdaGrad", "AdaDelta", "AdaMax", "Nadam",
+                                  "AMSGrad", "AdaBelief"])
+def test_segmented_updater_matches_reference(kind):
+    from deeplearning4j_amd.ops import updater as U
+    torch.manual_seed(1)
+    n1, n2 = 5000, 3333
+    n = n1 + n2
+    k = U.KIND[kind]
+    mult = U.STATE_MULT[k]
+    segs = [U.Segment(0, n1, 0, k, 0.01, 0.9, 0.999, 1e-8, l1=1e-4, l2=1e-3, wd=0.0, divide_by_batch=True),
+            U.Segment(n1, n2, mult * n1, k, 0.02, 0.8, 0.99, 1e-6, l1=0.0, l2=0.0, wd=1e-2, divide_by_batch=False)]
+    p = torch.randn(n, device=dev())
+    st = torch.rand(max(mult * n, 1), device=dev()) * 0.1
+    pr, sr = p.cpu().clone(), st.cpu().clone()
+    su = U.SegmentedUpdater(segs, dev())
+    for it in range(3):
+        g = torch.randn(n, device=dev())
+        gr = g.cpu().clone()
+        su.step(p, g, st, 16)
+        for s in segs:
+            U.apply_segment_reference(s, pr, gr, sr, 1.0 / 16, float(it + 1))
+    assert torch.allclose(p.cpu(), pr, atol=2e-5, rtol=1e-4)
+    if mult:
+        assert torch.allclose(st.cpu()[:mult * n], sr[:mult * n], atol=2e-5, rtol=1e-4)
+    assert int(su.iter_dev.item()) == 3
+
+
+def test_cast_table_permute():
+    from deeplearning4j_amd.ops import updater as U
+    O, I, kh, kw = 6, 5, 3, 3
+    src = torch.randn(100 + O * I * kh * kw + 40, device=dev())
+    ct = U.CastTable([(0, 0, 100, 1, 1), (100, 104, O * I * kh * kw, I, kh * kw)], dev())
+    dst = torch.zeros(104 + O * I * kh * kw, dtype=torch.bfloat16, device=dev())
+    ct.run(src, dst)
+    assert torch.equal(dst[:100], src[:100].bfloat16())
+    w = src[100:100 + O * I * kh * kw].view(O, I, kh, kw)
+    ohwi = dst[104:].view(O, kh, kw, I).permute(0, 3, 1, 2)
+    assert torch.equal(ohwi, w.bfloat16())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N", [(256, 1000), (33, 10), (7, 4099)])
+def test_softmax_xent(dtype, M, N):
+    from deeplearning4j_amd.ops import softmax as S
+    torch.manual_seed(2)
+    z = (torch.randn(M, N, device=dev()) * 3).to(dtype)
+    idx = torch.randint(0, N, (M,), device=dev())
+    y = torch.zeros(M, N, device=dev(), dtype=dtype)
+    y[torch.arange(M), idx] = 1
+    score, grad, probs = S.softmax_xent(z, y, want_probs=True)
+    p = torch.softmax(z.float(), 1)
+    ref_score = -(y.float() * torch.log(p.clamp(1e-10, 1))).sum()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert torch.allclose(probs.float(), p, atol=tol)
+    assert torch.allclose(grad.float(), p - y.float(), atol=tol)
+    assert abs(float(score) - float(ref_score)) < 1e-3 * max(1.0, abs(float(ref_score)))
+    s2, g2, _ = S.softmax_xent(z, None, idx)
+    assert abs(float(s2) - float(ref_score)) < 1e-3 * max(1.0, abs(float(ref_score)))
+    assert torch.allclose(g2.float(), p - y.float(), atol=tol)
+    assert torch.allclose(S.softmax(z).float(), p, atol=tol)
+    assert torch.allclose(S.softmax(z, log=True).float(), torch.log_softmax(z.float(), 1), atol=tol * 10, rtol=1e-2)
+    dy = torch.randn(M, N, device=dev()).to(dtype)
+    ref = p * (dy.float() - (dy.float() * p).sum(1, keepdim=True))
+    assert torch.allclose(S.softmax_bp(probs, dy).float(), ref, atol=tol * 5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["max", "avg"])
+@pytest.mark.parametrize("cfg", [((2, 16, 13, 13), (3, 3), (2, 2), (0, 0)), ((3, 8, 9, 10), (2, 2), (2, 2), (1, 1)),
+                                 ((2, 5, 8, 8), (3, 3), (1, 1), (1, 1)), ((2, 64, 28, 28), (3, 3), (2, 2), (0, 0))])
+def test_pool2d(dtype, mode, cfg):
+    import torch.nn.functional as F
+    from deeplearning4j_amd.ops import pooling as P
+    shape, k, s, p = cfg
+    torch.manual_seed(3)
+    x = torch.randn(shape, device=dev()).to(dtype).contiguous(memory_format=torch.channels_last)
+    y, ctx = P.pool2d_forward(x, mode, k, s, p, train=True)
+    assert ctx.geom is not None, "HIP pooling path not taken"
+    xf = x.float().requires_grad_(True)
+    yr = F.max_pool2d(xf, k, s, p) if mode == "max" else F.avg_pool2d(xf, k, s, p, count_include_pad=True)
+    assert torch.allclose(y.float(), yr, atol=1e-6 if dtype == torch.float32 else 2e-2)
+    dy = torch.randn_like(yr).to(dtype)
+    dx = P.pool2d_backward(dy, ctx)
+    (dxr,) = torch.autograd.grad(yr, xf, dy.float())
+    assert torch.allclose(dx.float(), dxr, atol=1e-5 if dtype == torch.float32 else 3e-2)
+
+
+def test_resnet_block_gpu_matches_cpu_fp32():
+    """Fused BN/add/ReLU graph on the GPU (HIP kernels) vs the same network on CPU (PyTorch math)."""
+    from tests.test_networks_cpu import _onehot
+    from deeplearning4j_amd.models.resnet50 import ResNet50
+    m = ResNet50(numClasses=5, inputShape=(3, 160, 160))
+    a = m.init(device="cpu")
+    b = m.init(device=dev())
+    assert torch.equal(a.params(), b.params().cpu())
+    x = torch.rand(2, 3, 160, 160)
+    y = _onehot(2, 5).float()
+    a.computeGradientAndScore([x], [y])
+    b.computeGradientAndScore([x.to(dev())], [y.to(dev())])
+    assert abs(float(a._score) - float(b._score)) < 2e-2 * max(1.0, abs(float(a._score)))
+    ga, gb = a._grads, b._grads.cpu()
+    rel = (ga - gb).norm() / ga.norm().clamp_min(1e-12)
+    assert rel < 5e-2, "relative gradient error %g" % float(rel)
+
+
+def test_lenet_bf16_graph_capture_trains():
+    from deeplearning4j_amd.models.lenet import LeNet
+    from deeplearning4j_amd.nd4j.learning import Adam
+    net = LeNet(inputShape=(1, 28, 28), numClasses=10, updater=Adam(1e-3), computeDataType="BFLOAT16").init(device=dev())
+    net.enableGraphCapture(True)
+    torch.manual_seed(0)
+    x = torch.rand(64, 784, device=dev())
+    lab = torch.randint(0, 10, (64,), device=dev())
+    y = torch.zeros(64, 10, device=dev())
+    y[torch.arange(64), lab] = 1
+    net.fit(x, y)
+    s0 = net.score()
+    for _ in range(60):
+        net.fit(x, y)
+    assert net._graph_step.graph_a is not None
+    assert net.score() < 0.5 * s0
+    assert net.getIterationCount() == 61
