@@ -63,7 +63,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
         o = OBJ / (s.stem + ".hip.o")
         if force or _newer(s, o, headers):
             tasks.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
-                          "-Wno-unused-result", "-I", str(CSRC), "-c", str(s), "-o", str(o)])
+                          "-Wno-unused-result", "-Wno-unused-value", "-I", str(CSRC), "-c", str(s), "-o", str(o)])
     for s in cpp_srcs:
         o = OBJ / (s.stem + ".cpp.o")
         if force or _newer(s, o, headers):

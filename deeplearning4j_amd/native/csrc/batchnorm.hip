@@ -61,7 +61,7 @@ template <typename T, int V, int MODE>
 __global__ void __launch_bounds__(256) bn_colreduce_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ out,
     const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ sums, int64_t M, int C, int cpb, int rpi) {
+    float* __restrict__ partial, int64_t M, int C, int cpb, int rpi) {
   __shared__ float red[2 * V * 256];
   const int cv = C / V;
   const int tid = threadIdx.x;
@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
 #pragma unroll
       for (int j = 0; j < V; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; }
     }
+#pragma unroll 2
     for (int64_t r = (int64_t)blockIdx.y * rpi + r_in; r < M; r += (int64_t)gridDim.y * rpi) {
       const int64_t off = r * C + c0;
       float xv[V];
@@ -107,16 +108,53 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
     for (int j = 0; j < V; ++j) {
       float s0 = 0.f, s1 = 0.f;
       for (int r = 0; r < rpi; ++r) { s0 += red[j * 256 + r * cpb + c_in]; s1 += red[(V + j) * 256 + r * cpb + c_in]; }
-      atomicAdd(&sums[cvec * V + j], s0);
-      atomicAdd(&sums[C + cvec * V + j], s1);
+      partial[((int64_t)blockIdx.y * 2) * C + cvec * V + j] = s0;
+      partial[((int64_t)blockIdx.y * 2 + 1) * C + cvec * V + j] = s1;
     }
   }
 }
 
+// Stage 2: sums[q*C + c] = sum over row-blocks of partial[(y*2+q)*C + c]; optional extra outputs
+// (gradient views for dbeta / dgamma) are written in the same pass.
+__global__ void __launch_bounds__(256) bn_sum_partials_kernel(const float* __restrict__ partial, int gy, int C,
+                                                              float* __restrict__ sums, float* __restrict__ out0,
+                                                              float* __restrict__ out1) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;  // 32 columns x 8 row groups
+  const int col = blockIdx.x * 32 + cl;                     // column in [0, 2C)
+  float a = 0.f;
+  if (col < 2 * C) {
+    const int q = col / C, c = col - q * C;
+    const float* p = partial + (int64_t)q * C + c;
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int y = rg;
+    for (; y + 24 < gy; y += 32) {
+      a += p[(int64_t)y * 2 * C]; a1 += p[(int64_t)(y + 8) * 2 * C];
+      a2 += p[(int64_t)(y + 16) * 2 * C]; a3 += p[(int64_t)(y + 24) * 2 * C];
+    }
+    for (; y < gy; y += 8) a += p[(int64_t)y * 2 * C];
+    a += a1 + a2 + a3;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (rg == 0 && col < 2 * C) {
+    a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += red[k * 32 + cl];
+    sums[col] = a;
+    if (col < C) { if (out0) out0[col] = a; }
+    else if (out1) out1[col - C] = a;
+  }
+}
+
+#define BN_MAX_ROWBLOCKS 512
+// workspace floats needed for the partials of one call
+static inline int64_t colreduce_ws_floats(int C) { return (int64_t)BN_MAX_ROWBLOCKS * 2 * C; }
+
 template <typename T, int MODE>
 static int launch_colreduce(const void* x, const void* dy, const void* out, const float* mean,
-                            const float* invstd, float* sums, int64_t M, int C, hipStream_t st) {
-  hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st);
+                            const float* invstd, float* partial, float* sums, float* out0, float* out1, int64_t M,
+                            int C, hipStream_t st) {
   constexpr int VFULL = VecOf<T>::N;
   const bool vec_ok = (C % VFULL) == 0;
   const int V = vec_ok ? VFULL : 1;
@@ -124,16 +162,19 @@ static int launch_colreduce(const void* x, const void* dy, const void* out, cons
   const int cpb = cv < 256 ? cv : 256;
   const int rpi = 256 / cpb;
   const int gx = (cv + cpb - 1) / cpb;
-  int64_t gy = (M + rpi - 1) / rpi;
-  int64_t cap = 2048 / gx; if (cap < 1) cap = 1;
+  int64_t gy = (M + (int64_t)rpi * 16 - 1) / ((int64_t)rpi * 16);   // >= 16 row-iterations per block
+  if (gy < 1) gy = 1;
+  int64_t cap = BN_MAX_ROWBLOCKS / gx; if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   dim3 grid(gx, (unsigned)gy);
   if (vec_ok)
     hipLaunchKernelGGL((bn_colreduce_kernel<T, VFULL, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
-                       (const T*)out, mean, invstd, sums, M, C, cpb, rpi);
+                       (const T*)out, mean, invstd, partial, M, C, cpb, rpi);
   else
     hipLaunchKernelGGL((bn_colreduce_kernel<T, 1, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
-                       (const T*)out, mean, invstd, sums, M, C, cpb, rpi);
+                       (const T*)out, mean, invstd, partial, M, C, cpb, rpi);
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)gy, C, sums, out0,
+                     out1);
   DL4J_RET_LAST();
 }
 
@@ -189,29 +230,62 @@ __global__ void bn_infer_coeffs_kernel(const float* __restrict__ gamma, const fl
 }
 
 // ---------------------------------------------------------------------------------------
-// Pass B (forward): y = act( x*scale + shift [+ res (*rscale + rshift)] )
+// Pass B kernels are grid-stride over 16-byte vectors. When the total thread count is a multiple
+// of the number of channel-vectors (always true for power-of-two channel counts), a thread sees
+// the SAME channels in every iteration, so the per-channel coefficients are hoisted into
+// registers (HOIST): the loop body is then pure streaming (loads, FMAs, stores) instead of
+// issuing 16-40 scalar coefficient loads per vector.
 // ---------------------------------------------------------------------------------------
-template <typename T, int V>
+static inline int hoist_grid(int64_t nvec, int cv, bool* hoist) {
+  int g = grid_for(nvec, 256);
+  *hoist = false;
+  if (cv <= 256) {
+    if (256 % cv == 0) *hoist = true;
+  } else if (cv % 256 == 0) {
+    const int m = cv / 256;
+    g = (g + m - 1) / m * m;
+    *hoist = true;
+  }
+  return g;
+}
+
+// Pass B (forward): y = act( x*scale + shift [+ res (*rscale + rshift)] )
+template <typename T, int V, bool HOIST>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const T* __restrict__ res,
                                                        const float* __restrict__ rscale,
                                                        const float* __restrict__ rshift, T* __restrict__ y,
                                                        int64_t nvec, int cv, int relu) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cv) * V;
+  const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float sc[V], sh[V], rs[V], rt[V];
+  const bool has_rs = (res != nullptr) && (rscale != nullptr);
+  if (HOIST) {
+    const int c0 = (int)(tid0 % cv) * V;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
+      rs[j] = has_rs ? rscale[c0 + j] : 1.f; rt[j] = has_rs ? rshift[c0 + j] : 0.f;
+    }
+  }
+  for (int64_t i = tid0; i < nvec; i += stride) {
+    if (!HOIST) {
+      const int c0 = (int)(i % cv) * V;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
+        rs[j] = has_rs ? rscale[c0 + j] : 1.f; rt[j] = has_rs ? rshift[c0 + j] : 0.f;
+      }
+    }
     float xv[V];
     load_vec<T, V>(x + i * V, xv);
 #pragma unroll
-    for (int j = 0; j < V; ++j) xv[j] = xv[j] * scale[c0 + j] + shift[c0 + j];
+    for (int j = 0; j < V; ++j) xv[j] = xv[j] * sc[j] + sh[j];
     if (res != nullptr) {
       float rv[V];
       load_vec<T, V>(res + i * V, rv);
-      if (rscale != nullptr) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) rv[j] = rv[j] * rscale[c0 + j] + rshift[c0 + j];
-      }
-#pragma unroll
-      for (int j = 0; j < V; ++j) xv[j] += rv[j];
+      for (int j = 0; j < V; ++j) xv[j] += rv[j] * rs[j] + rt[j];
     }
     if (relu) {
 #pragma unroll
@@ -227,21 +301,28 @@ static int launch_apply(const void* x, const float* scale, const float* shift, c
   constexpr int VFULL = VecOf<T>::N;
   if (C % VFULL == 0) {
     const int64_t nvec = M * C / VFULL;
-    hipLaunchKernelGGL((bn_apply_kernel<T, VFULL>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x, scale,
-                       shift, (const T*)res, rscale, rshift, (T*)y, nvec, C / VFULL, relu);
+    bool hoist;
+    const int g = hoist_grid(nvec, C / VFULL, &hoist);
+    if (hoist)
+      hipLaunchKernelGGL((bn_apply_kernel<T, VFULL, true>), dim3(g), dim3(256), 0, st, (const T*)x, scale, shift,
+                         (const T*)res, rscale, rshift, (T*)y, nvec, C / VFULL, relu);
+    else
+      hipLaunchKernelGGL((bn_apply_kernel<T, VFULL, false>), dim3(g), dim3(256), 0, st, (const T*)x, scale, shift,
+                         (const T*)res, rscale, rshift, (T*)y, nvec, C / VFULL, relu);
   } else {
     const int64_t nvec = M * C;
-    hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x, scale, shift,
-                       (const T*)res, rscale, rshift, (T*)y, nvec, C, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<T, 1, false>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x, scale,
+                       shift, (const T*)res, rscale, rshift, (T*)y, nvec, C, relu);
   }
   DL4J_RET_LAST();
 }
 
 // ---------------------------------------------------------------------------------------
-// Pass B (backward): dx = scale * (dz - dbeta/M - xhat * dgamma/M), dz = dy*[out>0]
+// Pass B (backward): dx = g*is*(dz - dbeta/M - xhat*dgamma/M) = A*dz + B*x + K per channel with
+//   A = g*is, B = -A*is*dgamma/M, K = -A*dbeta/M - B*mean;   dz = dy*[out>0]
 // optionally also writes dz (gradient for the residual branch).
 // ---------------------------------------------------------------------------------------
-template <typename T, int V>
+template <typename T, int V, bool HOIST>
 __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                         const T* __restrict__ out, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd,
@@ -249,8 +330,22 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ sums, T* __restrict__ dx,
                                                         T* __restrict__ dz_out, int64_t nvec, int cv, int C,
                                                         float invM) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cv) * V;
+  const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float A[V], B[V], K[V];
+  auto coeffs = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int c = c0 + j;
+      const float is = invstd[c];
+      const float a = (gamma ? gamma[c] : 1.f) * is;
+      const float bq = -a * is * sums[C + c] * invM;
+      A[j] = a; B[j] = bq; K[j] = -a * sums[c] * invM - bq * mean[c];
+    }
+  };
+  if (HOIST) coeffs((int)(tid0 % cv) * V);
+  for (int64_t i = tid0; i < nvec; i += stride) {
+    if (!HOIST) coeffs((int)(i % cv) * V);
     float xv[V], dv[V];
     load_vec<T, V>(x + i * V, xv);
     load_vec<T, V>(dy + i * V, dv);
@@ -263,13 +358,7 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
     if (dz_out != nullptr) store_vec<T, V>(dz_out + i * V, dv);
     float r[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const int c = c0 + j;
-      const float is = invstd[c];
-      const float xh = (xv[j] - mean[c]) * is;
-      const float g = gamma ? gamma[c] : 1.f;
-      r[j] = g * is * (dv[j] - sums[c] * invM - xh * sums[C + c] * invM);
-    }
+    for (int j = 0; j < V; ++j) r[j] = A[j] * dv[j] + B[j] * xv[j] + K[j];
     store_vec<T, V>(dx + i * V, r);
   }
 }
@@ -282,21 +371,30 @@ static int launch_bwd_dx(const void* x, const void* dy, const void* out, const f
   const float invM = 1.f / (float)M;
   if (C % VFULL == 0) {
     const int64_t nvec = M * C / VFULL;
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VFULL>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x,
-                       (const T*)dy, (const T*)out, mean, invstd, gamma, sums, (T*)dx, (T*)dz, nvec, C / VFULL, C,
-                       invM);
+    bool hoist;
+    const int g = hoist_grid(nvec, C / VFULL, &hoist);
+    if (hoist)
+      hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VFULL, true>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)dy,
+                         (const T*)out, mean, invstd, gamma, sums, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM);
+    else
+      hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VFULL, false>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)dy,
+                         (const T*)out, mean, invstd, gamma, sums, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM);
   } else {
     const int64_t nvec = M * C;
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x,
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1, false>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x,
                        (const T*)dy, (const T*)out, mean, invstd, gamma, sums, (T*)dx, (T*)dz, nvec, C, C, invM);
   }
   DL4J_RET_LAST();
 }
 
 // dtype codes: 0 = fp32, 1 = bf16
-DL4J_API int dl4j_bn_stats(const void* x, float* sums, int64_t M, int C, int dtype, hipStream_t st) {
-  if (dtype == 1) return launch_colreduce<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, sums, M, C, st);
-  return launch_colreduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, sums, M, C, st);
+DL4J_API int64_t dl4j_bn_ws_floats(int C) { return colreduce_ws_floats(C); }
+
+DL4J_API int dl4j_bn_stats(const void* x, float* partial_ws, float* sums, int64_t M, int C, int dtype,
+                           hipStream_t st) {
+  if (dtype == 1)
+    return launch_colreduce<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, partial_ws, sums, nullptr, nullptr, M, C, st);
+  return launch_colreduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, partial_ws, sums, nullptr, nullptr, M, C, st);
 }
 
 DL4J_API int dl4j_bn_finalize(const float* sums, const float* gamma, const float* beta, const float* conv_bias,
@@ -324,9 +422,11 @@ DL4J_API int dl4j_bn_apply(const void* x, const float* scale, const float* shift
 }
 
 DL4J_API int dl4j_bn_bwd_reduce(const void* x, const void* dy, const void* out, const float* mean,
-                                const float* invstd, float* sums, int64_t M, int C, int dtype, hipStream_t st) {
-  if (dtype == 1) return launch_colreduce<bf16_t, 1>(x, dy, out, mean, invstd, sums, M, C, st);
-  return launch_colreduce<float, 1>(x, dy, out, mean, invstd, sums, M, C, st);
+                                const float* invstd, float* partial_ws, float* sums, float* dbeta_out,
+                                float* dgamma_out, int64_t M, int C, int dtype, hipStream_t st) {
+  if (dtype == 1)
+    return launch_colreduce<bf16_t, 1>(x, dy, out, mean, invstd, partial_ws, sums, dbeta_out, dgamma_out, M, C, st);
+  return launch_colreduce<float, 1>(x, dy, out, mean, invstd, partial_ws, sums, dbeta_out, dgamma_out, M, C, st);
 }
 
 DL4J_API int dl4j_bn_bwd_dx(const void* x, const void* dy, const void* out, const float* mean, const float* invstd,

@@ -37,6 +37,7 @@ def hip():
     if _HIP is None:
         try:
             _HIP = _load(HERE / "libdl4j_hip.so")
+            _HIP.dl4j_bn_ws_floats.restype = ctypes.c_int64
         except Exception as e:  # pragma: no cover - depends on box
             _HIP_ERR = e
             raise RuntimeError(

@@ -144,10 +144,15 @@ class ComputationGraph(BaseNetwork):
                 impl.name = n
             self._impls[n] = impl
         self.vertices = self._impls
-        ins = set(conf.networkInputs)
+        # an activation "requires grad" only if a trainable parameter sits upstream of it; layers whose
+        # input does not require grad skip their backward-data pass (e.g. the stem conv behind ZeroPadding)
+        req = {i: False for i in conf.networkInputs}
         for n, impl in self._impls.items():
-            if all(i in ins for i in conf.vertexInputs[n]) and hasattr(impl, "conf") and isinstance(conf.vertices[n], G.LayerVertex):
-                impl.needs_input_grad = False
+            in_req = any(req[i] for i in conf.vertexInputs[n])
+            if isinstance(conf.vertices[n], G.LayerVertex):
+                impl.needs_input_grad = in_req
+            req[n] = in_req or len(impl.param_specs()) > 0
+        self._requires_grad = req
         self._alloc_params(params, cloneParametersArray)
         self._plan = self._build_plan()
         return self
@@ -434,7 +439,7 @@ class ComputationGraph(BaseNetwork):
                     continue
                 dxs = nd.backward(e, mb)
             for inp, dx in zip(nd.inputs, dxs):
-                if dx is None or inp in net_in:
+                if dx is None or inp in net_in or not self._requires_grad.get(inp, True):
                     continue
                 prev = eps.get(inp)
                 eps[inp] = dx if prev is None else prev + dx

@@ -409,8 +409,8 @@ class ConvolutionLayerImpl(LayerImpl):
         if "b" in self.grads:
             if has_b:
                 self.grads["b"].copy_(db.reshape(1, -1))
-            else:
-                self.grads["b"].zero_()  # analytically zero: d(BN)/d(bias) == 0 when bias is folded into BN
+            # else: analytically zero (d(BN)/d(bias) == 0 when the bias is folded into the following
+            # BatchNorm); the flat gradient vector is zero-initialised and this slot is never written
         if dx is None:
             return None
         if self._extra is not None:

@@ -53,8 +53,10 @@ class MultiLayerNetwork(BaseNetwork):
             l.index = i
             if l.name is None:
                 l.name = "layer%d" % i
-        if self.layers:
-            self.layers[0].needs_input_grad = False
+        seen_params = False
+        for l in self.layers:
+            l.needs_input_grad = seen_params
+            seen_params = seen_params or len(l.param_specs()) > 0
         self._alloc_params(params, cloneParametersArray)
         self._plan = self._build_plan()
         return self
@@ -248,6 +250,8 @@ class MultiLayerNetwork(BaseNetwork):
             else:
                 if eps is None:
                     break
+                if not l.needs_input_grad and not l.param_specs():
+                    break   # nothing trainable at or below this layer
                 eps = l.backward(eps)
             if eps is not None and i in pre:
                 eps = pre[i].backprop(eps, mb)

@@ -25,6 +25,21 @@ class BNContext:
     __slots__ = ("x", "out", "mean", "invstd", "scale", "shift", "relu", "M", "C", "res_ctx")
 
 
+_WS = {}
+
+
+def _workspace(C, device):
+    """Per-device scratch for the two-stage column reductions (stream-ordered reuse is safe: every
+    producer/consumer pair of a call runs back-to-back on the same stream)."""
+    n = int(L.hip().dl4j_bn_ws_floats(L.c_int(C)))
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 20), device=device, dtype=torch.float32)
+        _WS[key] = ws
+    return ws
+
+
 def _hip_ok(x):
     return L.use_hip(x) and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous()
 
@@ -90,8 +105,9 @@ def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std
         buf = torch.empty(6 * C, device=dev, dtype=torch.float32)
         sums, mean, invstd, scale, shift = buf[:2 * C], buf[2 * C:3 * C], buf[3 * C:4 * C], buf[4 * C:5 * C], buf[5 * C:]
         h = L.hip()
-        L.check(h.dl4j_bn_stats(L.ptr(x2d), L.ptr(sums), L.c_int64(M), L.c_int(C), L.c_int(L.dtype_code(x2d)),
-                                L.stream()), "bn_stats")
+        ws = _workspace(C, dev)
+        L.check(h.dl4j_bn_stats(L.ptr(x2d), L.ptr(ws), L.ptr(sums), L.c_int64(M), L.c_int(C),
+                                L.c_int(L.dtype_code(x2d)), L.stream()), "bn_stats")
         L.check(h.dl4j_bn_finalize(L.ptr(sums), L.ptr(gamma), L.ptr(beta), L.ptr(conv_bias), L.ptr(gmean),
                                    L.ptr(gvar), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift),
                                    L.ptr(dgmean_out), L.ptr(dgvar_out), L.c_int(C), L.c_int64(M), L.c_float(eps),
@@ -125,17 +141,23 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
         h = L.hip()
         sums = torch.empty(2 * C, device=x2d.device, dtype=torch.float32)
         dt = L.c_int(L.dtype_code(x2d))
-        L.check(h.dl4j_bn_bwd_reduce(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd),
-                                     L.ptr(sums), L.c_int64(M), L.c_int(C), dt, L.stream()), "bn_bwd_reduce")
+        ws = _workspace(C, x2d.device)
+        direct = (dbeta_out is None or (dbeta_out.is_contiguous() and dbeta_out.dtype == torch.float32)) and \
+                 (dgamma_out is None or (dgamma_out.is_contiguous() and dgamma_out.dtype == torch.float32))
+        L.check(h.dl4j_bn_bwd_reduce(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(ws),
+                                     L.ptr(sums), L.ptr(dbeta_out if direct else None),
+                                     L.ptr(dgamma_out if direct else None), L.c_int64(M), L.c_int(C), dt, L.stream()),
+                "bn_bwd_reduce")
         dx = torch.empty_like(x2d)
         dz = torch.empty_like(x2d) if want_dz else None
         L.check(h.dl4j_bn_bwd_dx(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
                                  L.ptr(sums), L.ptr(dx), L.ptr(dz), L.c_int64(M), L.c_int(C), dt, L.stream()),
                 "bn_bwd_dx")
-        if dbeta_out is not None:
-            dbeta_out.copy_(sums[:C])
-        if dgamma_out is not None:
-            dgamma_out.copy_(sums[C:])
+        if not direct:
+            if dbeta_out is not None:
+                dbeta_out.copy_(sums[:C])
+            if dgamma_out is not None:
+                dgamma_out.copy_(sums[C:])
         return dx, dz
     cd = torch.float32 if x2d.dtype == torch.bfloat16 else x2d.dtype
     xf, dz = x2d.to(cd), dy2d.to(cd)

@@ -136,13 +136,14 @@ def test_pool2d(dtype, mode, cfg):
     x = torch.randn(shape, device=dev()).to(dtype).contiguous(memory_format=torch.channels_last)
     y, ctx = P.pool2d_forward(x, mode, k, s, p, train=True)
     assert ctx.geom is not None, "HIP pooling path not taken"
-    xf = x.float().requires_grad_(True)
+    # reference on the CPU (plain PyTorch fp32, NCHW-contiguous)
+    xf = x.float().cpu().contiguous().requires_grad_(True)
     yr = F.max_pool2d(xf, k, s, p) if mode == "max" else F.avg_pool2d(xf, k, s, p, count_include_pad=True)
-    assert torch.allclose(y.float(), yr, atol=1e-6 if dtype == torch.float32 else 2e-2)
+    assert torch.allclose(y.float().cpu(), yr, atol=1e-6 if dtype == torch.float32 else 2e-2)
     dy = torch.randn_like(yr).to(dtype)
-    dx = P.pool2d_backward(dy, ctx)
+    dx = P.pool2d_backward(dy.to(dev()), ctx)
     (dxr,) = torch.autograd.grad(yr, xf, dy.float())
-    assert torch.allclose(dx.float(), dxr, atol=1e-5 if dtype == torch.float32 else 3e-2)
+    assert torch.allclose(dx.float().cpu(), dxr, atol=1e-5 if dtype == torch.float32 else 3e-2)
 
 
 def test_resnet_block_gpu_matches_cpu_fp32():
