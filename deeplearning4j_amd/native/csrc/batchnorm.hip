@@ -390,6 +390,14 @@ static int launch_bwd_dx(const void* x, const void* dy, const void* out, const f
 // dtype codes: 0 = fp32, 1 = bf16
 DL4J_API int64_t dl4j_bn_ws_floats(int C) { return colreduce_ws_floats(C); }
 
+// Reduce [gy][2][C] partials (e.g. produced by the conv epilogue) to sums[2C].
+DL4J_API int dl4j_bn_sum_partials(const float* partial, int gy, int C, float* sums, float* out0, float* out1,
+                                  hipStream_t st) {
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, gy, C, sums, out0,
+                     out1);
+  DL4J_RET_LAST();
+}
+
 DL4J_API int dl4j_bn_stats(const void* x, float* partial_ws, float* sums, int64_t M, int C, int dtype,
                            hipStream_t st) {
   if (dtype == 1)

@@ -1,0 +1,448 @@
+// Implicit-GEMM 2-D convolution for gfx950 (MI355X / CDNA4): bf16 NHWC activations, OHWI filters,
+// fp32 accumulation on the matrix cores (v_mfma_f32_32x32x16_bf16), no im2col buffer.
+//
+// The reference conv2d is im2col -> cuBLAS GEMM -> permute -> addBias with a materialised column
+// buffer and a stream sync per GEMM (libnd4j/include/ops/declarable/helpers/cuda/convolutions_conv2d.cu:78-100,
+// helpers/cuda_off/MmulHelper.cu:347); backprop recomputes im2col (ConvolutionLayer.java:132-138).
+// Here:
+//   * forward  : C[M=N*OH*OW, K] = A[M, R*S*C] x B[K, R*S*C]^T with A gathered on the fly (zero
+//                fill for padding). Epilogue fuses bias, bf16 rounding, and — for a following
+//                BatchNorm — the per-channel sum / sum-of-squares partials (one pass over y saved).
+//   * dgrad    : the same kernel on dy with spatially flipped, transposed filters ([C][R][S][K]);
+//                1x1 stride-s convs scatter rows into a pre-zeroed dx.
+//   * wgrad    : dW[K, R*S*C] += dy[P, K]^T x gather(x)[P, C] per filter tap; both operands have the
+//                reduction (pixel) index as the slow memory index, so tiles are staged row-major in
+//                LDS and read with the hardware transposing load ds_read_b64_tr_b16. Split over
+//                pixels across workgroups, fp32 atomics into the (pre-zeroed) gradient.
+// Tiling: 256 threads = 4 waves (2x2), wave tile (BM/2)x(BN/2) of 32x32 MFMA blocks, BK = 64,
+// double-buffered LDS with register staging (global loads for tile t+1 issued before the MFMAs of
+// tile t, LDS write after), XOR-swizzled 16-byte chunks so ds_read_b128 / tr reads are bank
+// conflict free, XCD-aware workgroup->tile map so tiles sharing an A panel share an L2.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+struct IGemmP {
+  const bf16_t* x;
+  const bf16_t* w;
+  bf16_t* y;
+  const float* bias;
+  float* stats;       // [mtiles][2][K] partial sums (or null)
+  int N, H, W, C;     // input tensor
+  int OH, OW, K;      // logical output pixels grid / out channels
+  int R, S, sh, sw, ph, pw, dh, dw;
+  int OHs, OWs, oys, oxs;  // physical output tensor spatial dims and pixel strides (scatter for strided dgrad)
+  int M;              // N*OH*OW
+  int mtiles, ntiles;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+}
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
+  constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA blocks per wave in M / N
+  constexpr int AI = BM / 32, BI = BN / 32;   // 16-byte loads per thread per tile for A / B
+  constexpr int PITCH_C = BN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sB = smem + 2 * BM * 128;
+
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / p.ntiles, nt = lid - mt * p.ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int chunk = tid & 7, lrow = tid >> 3;
+
+  int a_base[AI], a_ih0[AI], a_iw0[AI];
+  const int OHW = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    if (m < p.M) {
+      const int n = m / OHW, rem = m - n * OHW;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      a_ih0[i] = oh * p.sh - p.ph;
+      a_iw0[i] = ow * p.sw - p.pw;
+      a_base[i] = ((n * p.H + a_ih0[i]) * p.W + a_iw0[i]) * p.C;
+    } else {
+      a_ih0[i] = -(1 << 20); a_iw0[i] = -(1 << 20); a_base[i] = 0;
+    }
+  }
+  const int CT = p.C >> 6;
+  const int KT = p.R * p.S * CT;
+  const int64_t wrow = (int64_t)p.R * p.S * p.C;
+
+  s16x8 ra[AI], rb[BI];
+  auto gload = [&](int t) {
+    const int rs = t / CT, c0 = (t - rs * CT) << 6;
+    const int r = rs / p.S, s = rs - r * p.S;
+    const int doff = ((r * p.dh) * p.W + s * p.dw) * p.C + c0 + chunk * 8;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int ih = a_ih0[i] + r * p.dh, iw = a_iw0[i] + s * p.dw;
+      const bool ok = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok) v = *reinterpret_cast<const s16x8*>(p.x + (int64_t)(a_base[i] + doff));
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+      rb[i] = *reinterpret_cast<const s16x8*>(p.w + (int64_t)(n0 + lrow + 32 * i) * wrow + rs * p.C + c0 + chunk * 8);
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int row = lrow + 32 * i;
+      *reinterpret_cast<s16x8*>(sA + buf * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int row = lrow + 32 * i;
+      *reinterpret_cast<s16x8*>(sB + buf * (BN * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int t = 0; t < KT; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < KT) gload(t + 1);
+    const char* cA = sA + cur * (BM * 128);
+    const char* cB = sB + cur * (BN * 128);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t af[TM], bfr[TN];
+      const int q = ks * 2 + lh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / 2) + i * 32 + l31;
+        af[i] = *reinterpret_cast<const bf16x8_t*>(cA + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (BN / 2) + j * 32 + l31;
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(cB + row * 128 + ((q ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < KT) swrite(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: bias, bf16 rounding, BN-stat partials, LDS transpose, coalesced store
+  char* sC = smem;
+  float* sS = reinterpret_cast<float*>(smem + ((BM * PITCH_C + 255) & ~255));
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * (BN / 2) + j * 32 + l31;
+    const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+    float s = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const bf16_t b = f2bf(acc[i][j][e] + bv);
+        *reinterpret_cast<bf16_t*>(sC + row * PITCH_C + col * 2) = b;
+        const float v = (m0 + row < p.M) ? bf2f(b) : 0.f;
+        s += v; q2 += v * v;
+      }
+    }
+    csum[j] = s + __shfl_xor(s, 32, 64);
+    csq[j] = q2 + __shfl_xor(q2, 32, 64);
+  }
+  if (p.stats != nullptr && lane < 32) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * (BN / 2) + j * 32 + lane;
+      sS[(wm * 2 + 0) * BN + col] = csum[j];
+      sS[(wm * 2 + 1) * BN + col] = csq[j];
+    }
+  }
+  __syncthreads();
+  if (p.stats != nullptr && tid < 2 * BN) {
+    const int qs = tid / BN, col = tid - qs * BN;
+    p.stats[((int64_t)mt * 2 + qs) * p.K + n0 + col] = sS[(0 * 2 + qs) * BN + col] + sS[(1 * 2 + qs) * BN + col];
+  }
+  constexpr int CPR = BN / 8;
+  for (int idx = tid; idx < BM * CPR; idx += 256) {
+    const int row = idx / CPR, ch = idx - row * CPR;
+    const int m = m0 + row;
+    if (m < p.M) {
+      const int n = m / OHW, rem = m - n * OHW;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      const int64_t o = (((int64_t)n * p.OHs + oh * p.oys) * p.OWs + ow * p.oxs) * p.K + n0 + ch * 8;
+      *reinterpret_cast<s16x8*>(p.y + o) = *reinterpret_cast<const s16x8*>(sC + row * PITCH_C + ch * 16);
+    }
+  }
+}
+
+template <int BM, int BN>
+static int launch_fwd(IGemmP& p, hipStream_t st) {
+  p.mtiles = (p.M + BM - 1) / BM;
+  p.ntiles = p.K / BN;
+  const int smem = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+  DL4J_RET_LAST();
+}
+
+// geom = [N,H,W,C, OH,OW,K, R,S, sh,sw, ph,pw, dh,dw, OHs,OWs,oys,oxs]
+// returns the number of M tiles used (needed to reduce the BN-stat partials) via *mtiles_out.
+DL4J_API int dl4j_igemm_conv(const void* x, const void* w, void* y, const float* bias, float* stats,
+                             const int* g, int tile, int* mtiles_out, hipStream_t st) {
+  IGemmP p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.bias = bias; p.stats = stats;
+  p.N = g[0]; p.H = g[1]; p.W = g[2]; p.C = g[3]; p.OH = g[4]; p.OW = g[5]; p.K = g[6]; p.R = g[7]; p.S = g[8];
+  p.sh = g[9]; p.sw = g[10]; p.ph = g[11]; p.pw = g[12]; p.dh = g[13]; p.dw = g[14];
+  p.OHs = g[15]; p.OWs = g[16]; p.oys = g[17]; p.oxs = g[18];
+  p.M = p.N * p.OH * p.OW;
+  if (p.C % 64 != 0 || p.K % 64 != 0) return -2;
+  int rc;
+  if (tile == 0) { if (p.K % 128) return -2; rc = launch_fwd<128, 128>(p, st); }
+  else if (tile == 1) rc = launch_fwd<128, 64>(p, st);
+  else rc = launch_fwd<64, 64>(p, st);
+  if (mtiles_out) *mtiles_out = p.mtiles;
+  return rc;
+}
+
+// number of M tiles for a tile id (so the caller can size the stats workspace before launching)
+DL4J_API int dl4j_igemm_mtiles(int64_t M, int tile) {
+  const int bm = (tile == 2) ? 64 : 128;
+  return (int)((M + bm - 1) / bm);
+}
+
+// =====================================================================================
+// wgrad
+// =====================================================================================
+struct WGradP {
+  const bf16_t* dy;   // [P][K]
+  const bf16_t* x;    // [N][H][W][C]
+  float* dw;          // [K][R*S][C] fp32 (accumulated)
+  int N, H, W, C, OH, OW, K, R, S, sh, sw, ph, pw, dh, dw_;
+  int P;              // N*OH*OW
+  int ktiles, ctiles, splits, pps;   // pps: pixels per split (multiple of 64)
+  int use_atomic;
+};
+
+template <int PITCH>
+__device__ __forceinline__ int tr_swz(int pixel) {
+  return PITCH == 256 ? ((pixel & 3) << 2) : (((pixel >> 1) & 1) << 2);
+}
+
+// LDS tile [64 pixels][BC channels] (row pitch BC*2 bytes); fragment for the 32 channels starting at
+// cb, pixels ks*16 .. ks*16+15 as a 32x32x16 MFMA A/B operand via two transposing reads.
+template <int PITCH>
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int cb, int ks, int lane) {
+  const int g = lane >> 4, h = g >> 1;
+  const int q = (lane & 15) >> 2, pp = lane & 3;
+  const int ch = cb + 16 * (g & 1) + 4 * pp;
+  const int p0 = ks * 16 + 8 * h + q;
+  const int a0 = p0 * PITCH + ((((ch >> 3) ^ tr_swz<PITCH>(p0))) << 4) + (ch & 7) * 2;
+  const int p1 = p0 + 4;
+  const int a1 = p1 * PITCH + ((((ch >> 3) ^ tr_swz<PITCH>(p1))) << 4) + (ch & 7) * 2;
+  typedef s16x4_t __attribute__((address_space(3))) * lds_ptr_t;
+  const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + a0));
+  const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(tile + a1));
+  s16x8 r;
+  r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3];
+  r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <int BK_, int BC_>   // BK_: out-channel tile (dy), BC_: in-channel tile (x)
+__global__ void __launch_bounds__(256) igemm_wgrad_kernel(const WGradP p) {
+  constexpr int PA = BK_ * 2, PB = BC_ * 2;          // row pitches in bytes
+  constexpr int CPA = BK_ / 8, CPB = BC_ / 8;        // 16-byte chunks per pixel row
+  constexpr int RPA = 256 / CPA, RPB = 256 / CPB;    // pixel rows covered per pass
+  constexpr int NA = 64 / RPA, NB = 64 / RPB;        // passes per 64-pixel tile
+  constexpr int TM = BK_ / 64, TN = BC_ / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sB = smem + 2 * 64 * PA;
+
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int RS = p.R * p.S;
+  const int ct = lid % p.ctiles; lid /= p.ctiles;
+  const int kt = lid % p.ktiles; lid /= p.ktiles;
+  const int rs = lid % RS;
+  const int split = lid / RS;
+  const int k0 = kt * BK_, c0 = ct * BC_;
+  const int r = rs / p.S, s = rs - r * p.S;
+  const int pstart = split * p.pps;
+  const int pend = (pstart + p.pps < p.P) ? pstart + p.pps : p.P;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int chA = tid % CPA, prA = tid / CPA;
+  const int chB = tid % CPB, prB = tid / CPB;
+  const int OHW = p.OH * p.OW;
+
+  s16x8 ra[NA], rb[NB];
+  auto gload = [&](int pb) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int pp = pb + prA + i * RPA;
+      s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (pp < pend) v = *reinterpret_cast<const s16x8*>(p.dy + (int64_t)pp * p.K + k0 + chA * 8);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int pp = pb + prB + i * RPB;
+      s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (pp < pend) {
+        const int n = pp / OHW, rem = pp - n * OHW;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih = oh * p.sh - p.ph + r * p.dh, iw = ow * p.sw - p.pw + s * p.dw_;
+        if (((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W))
+          v = *reinterpret_cast<const s16x8*>(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.C + c0 + chB * 8);
+      }
+      rb[i] = v;
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int pl = prA + i * RPA;
+      *reinterpret_cast<s16x8*>(sA + buf * (64 * PA) + pl * PA + ((chA ^ tr_swz<PA>(pl)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int pl = prB + i * RPB;
+      *reinterpret_cast<s16x8*>(sB + buf * (64 * PB) + pl * PB + ((chB ^ tr_swz<PB>(pl)) << 4)) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nsteps = (pend - pstart + 63) / 64;
+  if (nsteps > 0) {
+    gload(pstart);
+    swrite(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nsteps; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nsteps) gload(pstart + (t + 1) * 64);
+    const char* cA = sA + cur * (64 * PA);
+    const char* cB = sB + cur * (64 * PB);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = tr_frag<PA>(cA, wm * (BK_ / 2) + i * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = tr_frag<PB>(cB, wn * (BC_ / 2) + j * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nsteps) swrite(cur ^ 1);
+    __syncthreads();
+  }
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = k0 + wm * (BK_ / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int c = c0 + wn * (BC_ / 2) + j * 32 + l31;
+        float* dst = p.dw + ((int64_t)k * RS + rs) * p.C + c;
+        if (p.use_atomic) atomicAdd(dst, acc[i][j][e]);
+        else *dst = acc[i][j][e];
+      }
+}
+
+template <int BK_, int BC_>
+static int launch_wgrad(WGradP& p, int target_blocks, hipStream_t st) {
+  p.ktiles = p.K / BK_;
+  p.ctiles = p.C / BC_;
+  const int tiles = p.ktiles * p.ctiles * p.R * p.S;
+  int splits = (target_blocks + tiles - 1) / tiles;
+  int maxs = (p.P + 255) / 256;
+  if (splits > maxs) splits = maxs;
+  if (splits < 1) splits = 1;
+  int pps = (p.P + splits - 1) / splits;
+  pps = (pps + 63) / 64 * 64;
+  splits = (p.P + pps - 1) / pps;
+  p.splits = splits; p.pps = pps;
+  p.use_atomic = splits > 1;
+  if (p.use_atomic) hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.K * p.R * p.S * p.C, st);
+  const int smem = 2 * 64 * (BK_ + BC_) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BK_, BC_>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BK_, BC_>), dim3(tiles * splits), dim3(256), smem, st, p);
+  DL4J_RET_LAST();
+}
+
+// geom = [N,H,W,C, OH,OW,K, R,S, sh,sw, ph,pw, dh,dw]; dw_out fp32 [K][R*S][C]
+DL4J_API int dl4j_igemm_wgrad(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks,
+                              hipStream_t st) {
+  WGradP p;
+  p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw_out;
+  p.N = g[0]; p.H = g[1]; p.W = g[2]; p.C = g[3]; p.OH = g[4]; p.OW = g[5]; p.K = g[6]; p.R = g[7]; p.S = g[8];
+  p.sh = g[9]; p.sw = g[10]; p.ph = g[11]; p.pw = g[12]; p.dh = g[13]; p.dw_ = g[14];
+  p.P = p.N * p.OH * p.OW;
+  if (p.C % 64 != 0 || p.K % 64 != 0) return -2;
+  const bool k128 = (p.K % 128) == 0, c128 = (p.C % 128) == 0;
+  if (k128 && c128) return launch_wgrad<128, 128>(p, target_blocks, st);
+  if (k128) return launch_wgrad<128, 64>(p, target_blocks, st);
+  if (c128) return launch_wgrad<64, 128>(p, target_blocks, st);
+  return launch_wgrad<64, 64>(p, target_blocks, st);
+}
+
+// fp32 [K][RS][C] -> [K][C][RS]  (OHWI -> DL4J OIHW gradient view)
+__global__ void __launch_bounds__(256) ohwi_to_oihw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int64_t total, int RS, int C) {
+  for (int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x; d < total; d += (int64_t)gridDim.x * 256) {
+    const int64_t k = d / ((int64_t)C * RS);
+    const int64_t rem = d - k * (int64_t)C * RS;
+    const int c = (int)(rem / RS), rs = (int)(rem - (int64_t)c * RS);
+    dst[d] = src[(k * RS + rs) * C + c];
+  }
+}
+
+DL4J_API int dl4j_ohwi_to_oihw(const float* src, float* dst, int K, int RS, int C, hipStream_t st) {
+  const int64_t total = (int64_t)K * RS * C;
+  hipLaunchKernelGGL(ohwi_to_oihw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, src, dst, total, RS, C);
+  DL4J_RET_LAST();
+}

@@ -151,9 +151,10 @@ struct __attribute__((packed, aligned(8))) CastSeg {
   int64_t src_off;   // into fp32 master vector
   int64_t dst_off;   // into bf16 arena
   int64_t len;
-  int32_t I, K;      // if K > 1: permute [O][I][K] -> [O][K][I]
+  int32_t I, K;      // mode 0, K > 1: permute [O][I][K] -> [O][K][I]
+  int32_t O, mode;   // mode 1: [O][I][K] -> [I][K flipped][O]  (filters for the dgrad implicit GEMM)
 };
-static_assert(sizeof(CastSeg) == 32, "CastSeg layout is part of the ctypes ABI");
+static_assert(sizeof(CastSeg) == 40, "CastSeg layout is part of the ctypes ABI");
 
 __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                          const CastSeg* __restrict__ segs,
@@ -165,7 +166,12 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
   const int64_t IK = (int64_t)s.I * s.K;
   for (int64_t d = start + threadIdx.x; d < end; d += 256) {
     int64_t si = d;
-    if (s.K > 1) {  // d indexes destination [o][k][i]
+    if (s.mode == 1) {  // d indexes destination [i][k'][o], k' = K-1-k
+      const int64_t KO = (int64_t)s.K * s.O;
+      const int64_t i = d / KO, rem = d - i * KO;
+      const int64_t kf = rem / s.O, o = rem - kf * s.O;
+      si = o * IK + i * s.K + (s.K - 1 - kf);
+    } else if (s.K > 1) {  // d indexes destination [o][k][i]
       const int64_t o = d / IK, rem = d - o * IK;
       const int64_t k = rem / s.I, i = rem - k * s.I;
       si = o * IK + i * s.K + k;

@@ -164,6 +164,11 @@ class BaseNetwork:
                     O, I, kh, kw = e.spec.shape
                     ents.append((e.off, off, n, I, kh * kw))
                     views.append((l, key, off, ("ohwi", (O, I, kh, kw))))
+                elif layout == "dgrad" and len(e.spec.shape) == 4:
+                    # [I][kh*kw flipped][O]: filters as consumed by the dgrad implicit GEMM
+                    O, I, kh, kw = e.spec.shape
+                    ents.append((e.off, off, n, I, kh * kw, O, 1))
+                    views.append((l, key + "_dgrad", off, ("dgrad", (O, I, kh, kw))))
                 else:
                     ents.append((e.off, off, n, 1, 1))
                     views.append((l, key, off, ("plain", e.spec)))
@@ -173,6 +178,9 @@ class BaseNetwork:
             if kind == "ohwi":
                 O, I, kh, kw = info
                 l.cparams[key] = self._cparams_flat[o:o + O * I * kh * kw].view(O, kh, kw, I).permute(0, 3, 1, 2)
+            elif kind == "dgrad":
+                O, I, kh, kw = info
+                l.cparams[key] = self._cparams_flat[o:o + O * I * kh * kw].view(I, kh, kw, O)
             else:
                 l.cparams[key] = _strided_view(self._cparams_flat, o, info)
         self._cast_table = U.CastTable(ents, ctx.device)

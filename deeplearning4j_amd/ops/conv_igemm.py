@@ -1,0 +1,152 @@
+"""Python side of the hand-written gfx950 implicit-GEMM convolution (native/csrc/conv_igemm.hip).
+
+forward / dgrad / wgrad on bf16 channels-last activations with OHWI bf16 filters and fp32
+accumulation. ``forward`` can return the per-channel (sum, sum of squares) of its output so a
+following BatchNorm skips its statistics pass.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ..native import lib as L
+
+_TILES = ((128, 128), (128, 64), (64, 64))
+_MAX_ELEMS = (1 << 31) - 1
+_WS = {}
+
+
+def _ws(n_floats, device, tag):
+    key = (tag, device.index, torch.cuda.current_stream().cuda_stream)
+    t = _WS.get(key)
+    if t is None or t.numel() < n_floats:
+        t = torch.empty(max(int(n_floats), 1 << 18), device=device, dtype=torch.float32)
+        _WS[key] = t
+    return t
+
+
+def _ohwi_contig(w):
+    return w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()
+
+
+def supported(x, w, stride, padding, dilation):
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 4):
+        return False
+    K, C = w.shape[0], w.shape[1]
+    if C % 64 or K % 64 or x.shape[1] != C:
+        return False
+    if not x.is_contiguous(memory_format=torch.channels_last) or not _ohwi_contig(w):
+        return False
+    if x.numel() > _MAX_ELEMS:
+        return False
+    return True
+
+
+def pick_tile(M, K):
+    best, best_blocks = None, -1
+    for t, (bm, bn) in enumerate(_TILES):
+        if K % bn:
+            continue
+        blocks = ((M + bm - 1) // bm) * (K // bn)
+        if blocks >= 512:
+            return t
+        if blocks > best_blocks:
+            best, best_blocks = t, blocks
+    return best
+
+
+def _out_hw(H, W, R, S, stride, padding, dilation):
+    OH = (H + 2 * padding[0] - dilation[0] * (R - 1) - 1) // stride[0] + 1
+    OW = (W + 2 * padding[1] - dilation[1] * (S - 1) - 1) // stride[1] + 1
+    return OH, OW
+
+
+def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M):
+    tile = pick_tile(M, Kout)
+    stats = None
+    mt = int(L.hip().dl4j_igemm_mtiles(L.c_int64(M), L.c_int(tile)))
+    if want_stats:
+        stats = _ws(mt * 2 * Kout, x_t.device, "igemm_stats")
+    g = (ctypes.c_int * 19)(*geom)
+    L.check(L.hip().dl4j_igemm_conv(L.ptr(x_t), L.ptr(w_t), L.ptr(y_t), L.ptr(bias), L.ptr(stats), g, L.c_int(tile),
+                                    None, L.stream()), "igemm_conv")
+    if not want_stats:
+        return None
+    sums = torch.empty(2 * Kout, device=x_t.device, dtype=torch.float32)
+    L.check(L.hip().dl4j_bn_sum_partials(L.ptr(stats), L.c_int(mt), L.c_int(Kout), L.ptr(sums), None, None, L.stream()),
+            "bn_sum_partials")
+    return sums
+
+
+def forward(x, w, b, stride, padding, dilation, want_stats=False):
+    """Returns (y, sums) — sums is a [2*K] fp32 tensor (sum, sumsq per channel) when want_stats."""
+    N, C, H, W = x.shape
+    K, _, R, S = w.shape
+    OH, OW = _out_hw(H, W, R, S, stride, padding, dilation)
+    y = torch.empty((N, K, OH, OW), device=x.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    M = N * OH * OW
+    geom = (N, H, W, C, OH, OW, K, R, S, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+            OH, OW, 1, 1)
+    bias = b.float().contiguous() if b is not None else None
+    sums = _launch(x, w, y, bias, geom, want_stats, K, M)
+    return y, sums
+
+
+def dgrad_supported(w, stride, padding):
+    R, S = w.shape[2], w.shape[3]
+    if tuple(stride) == (1, 1):
+        return True
+    return R == 1 and S == 1 and tuple(padding) == (0, 0)
+
+
+def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation):
+    """dx for y = conv(x, w). ``w_dgrad``: [C][R][S][K] spatially flipped filters (bf16, contiguous)."""
+    N, C, H, W = x_shape
+    _, K, OH, OW = dz.shape
+    R, S = w_dgrad.shape[1], w_dgrad.shape[2]
+    if not dz.is_contiguous(memory_format=torch.channels_last):
+        dz = dz.contiguous(memory_format=torch.channels_last)
+    if tuple(stride) == (1, 1):
+        dx = torch.empty((N, C, H, W), device=dz.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        ph = (R - 1) * dilation[0] - padding[0]
+        pw = (S - 1) * dilation[1] - padding[1]
+        geom = (N, OH, OW, K, H, W, C, R, S, 1, 1, ph, pw, dilation[0], dilation[1], H, W, 1, 1)
+        _launch(dz, w_dgrad, dx, None, geom, False, C, N * H * W)
+        return dx
+    # 1x1 strided: rows scatter into a zeroed dx
+    dx = torch.empty((N, C, H, W), device=dz.device, dtype=torch.bfloat16, memory_format=torch.channels_last).zero_()
+    geom = (N, OH, OW, K, OH, OW, C, 1, 1, 1, 1, 0, 0, 1, 1, H, W, stride[0], stride[1])
+    _launch(dz, w_dgrad, dx, None, geom, False, C, N * OH * OW)
+    return dx
+
+
+def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=512):
+    """dW. If ``dw_out`` (fp32, contiguous, logical [K,C,R,S]) is given the result is written there and
+    None is returned; otherwise a new fp32 [K,C,R,S] tensor is returned."""
+    N, C, H, W = x.shape
+    K, _, R, S = w_shape
+    OH, OW = dz.shape[2], dz.shape[3]
+    if not dz.is_contiguous(memory_format=torch.channels_last):
+        dz = dz.contiguous(memory_format=torch.channels_last)
+    ret = None
+    if dw_out is None or not (dw_out.dtype == torch.float32 and dw_out.is_contiguous()):
+        ret = torch.empty((K, C, R, S), device=x.device, dtype=torch.float32)
+        tgt = ret
+    else:
+        tgt = dw_out
+    g = (ctypes.c_int * 15)(N, H, W, C, OH, OW, K, R, S, stride[0], stride[1], padding[0], padding[1], dilation[0],
+                            dilation[1])
+    if R * S == 1:
+        L.check(L.hip().dl4j_igemm_wgrad(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.stream()),
+                "igemm_wgrad")
+    else:
+        scratch = _ws(K * R * S * C, x.device, "igemm_wgrad")
+        L.check(L.hip().dl4j_igemm_wgrad(L.ptr(dz), L.ptr(x), L.ptr(scratch), g, L.c_int(target_blocks), L.stream()),
+                "igemm_wgrad")
+        L.check(L.hip().dl4j_ohwi_to_oihw(L.ptr(scratch), L.ptr(tgt), L.c_int(K), L.c_int(R * S), L.c_int(C), L.stream()),
+                "ohwi_to_oihw")
+    if ret is not None and dw_out is not None:
+        dw_out.copy_(ret)
+        return None
+    return ret

@@ -199,10 +199,10 @@ class CastTable:
     with optional OIHW -> OHWI (channels-last filter) permutation per entry."""
 
     def __init__(self, entries, device):
-        # entries: list of (src_off, dst_off, len, I, K)
-        self.entries = list(entries)
+        # entries: list of (src_off, dst_off, len, I, K[, O, mode]); mode 1 = [O][I][K] -> [I][K flipped][O]
+        self.entries = [tuple(e) + (0, 0) if len(e) == 5 else tuple(e) for e in entries]
         self.device = torch.device(device)
-        raw = b"".join(struct.pack("<qqqii", *e) for e in self.entries)
+        raw = b"".join(struct.pack("<qqqiiii", *e) for e in self.entries)
         self._seg = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device) if raw
                      else torch.zeros(0, dtype=torch.uint8, device=self.device))
         bs, bc = _block_tables([e[2] for e in self.entries])
@@ -216,9 +216,11 @@ class CastTable:
                                             L.ptr(self._blk_chunk), L.c_int(self.num_blocks), L.stream()),
                     "cast_table")
             return
-        for (so, do, n, I, K) in self.entries:
+        for (so, do, n, I, K, O, mode) in self.entries:
             s = src_f32[so:so + n]
-            if K > 1:
+            if mode == 1:
+                s = torch.flip(s.view(O, I, K), dims=[2]).permute(1, 2, 0).reshape(-1)
+            elif K > 1:
                 s = s.view(-1, I, K).permute(0, 2, 1).reshape(-1)
             dst_bf16[do:do + n] = s.to(dst_bf16.dtype)
 

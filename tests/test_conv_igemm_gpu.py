@@ -1,0 +1,92 @@
+"""GPU numerics: implicit-GEMM MFMA conv kernels (forward + fused BN-stat epilogue, dgrad, wgrad)
+vs a plain PyTorch fp32 reference of the same op (reference computed on the bf16-rounded inputs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, C, H, W, K, R, stride, pad, dil
+    (4, 64, 14, 14, 64, 1, 1, 0, 1),
+    (3, 64, 13, 13, 128, 3, 1, 1, 1),
+    (2, 128, 9, 11, 64, 3, 1, 1, 1),
+    (2, 64, 15, 15, 256, 1, 2, 0, 1),
+    (5, 256, 7, 7, 128, 1, 1, 0, 1),
+    (2, 64, 12, 12, 64, 3, 1, 2, 2),
+    (2, 128, 8, 8, 128, 3, 2, 1, 1),
+    (16, 64, 28, 28, 64, 3, 1, 1, 1),
+]
+
+
+def _mk(N, C, H, W, K, R, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(N, C, H, W, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, R, R, device="cuda", generator=g) / (C * R * R) ** 0.5).bfloat16()
+    w = w.contiguous(memory_format=torch.channels_last)   # OHWI memory
+    return x, w
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_and_stats(case):
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    N, C, H, W, K, R, s, p, d = case
+    x, w = _mk(N, C, H, W, K, R)
+    b = torch.randn(K, device="cuda")
+    assert IG.supported(x, w, (s, s), (p, p), (d, d))
+    y, sums = IG.forward(x, w, b, (s, s), (p, p), (d, d), want_stats=True)
+    ref = F.conv2d(x.float(), w.float(), b, s, p, d)
+    assert y.shape == ref.shape
+    err = (y.float() - ref).abs().max().item()
+    assert err < 2e-2 * max(1.0, ref.abs().max().item()), err
+    yf = y.float()
+    rs = yf.sum((0, 2, 3))
+    rq = (yf * yf).sum((0, 2, 3))
+    assert torch.allclose(sums[:K], rs, rtol=1e-3, atol=1e-2 * yf.abs().sum((0, 2, 3)).max().item() / 100)
+    assert torch.allclose(sums[K:], rq, rtol=1e-3, atol=1e-3 * rq.max().item())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dgrad(case):
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    N, C, H, W, K, R, s, p, d = case
+    x, w = _mk(N, C, H, W, K, R, 1)
+    if not IG.dgrad_supported(w, (s, s), (p, p)):
+        pytest.skip("strided non-1x1 dgrad uses the library path")
+    xf = x.float().requires_grad_(True)
+    ref_y = F.conv2d(xf, w.float(), None, s, p, d)
+    dz = torch.randn_like(ref_y).bfloat16().contiguous(memory_format=torch.channels_last)
+    (ref_dx,) = torch.autograd.grad(ref_y, xf, dz.float())
+    w_dgrad = torch.flip(w, dims=[2, 3]).permute(1, 2, 3, 0).contiguous()   # [C][R][S][K]
+    dx = IG.dgrad(dz, x.shape, w_dgrad, (s, s), (p, p), (d, d))
+    err = (dx.float() - ref_dx).abs().max().item()
+    assert err < 2e-2 * max(1.0, ref_dx.abs().max().item()), err
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wgrad(case):
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    N, C, H, W, K, R, s, p, d = case
+    x, w = _mk(N, C, H, W, K, R, 2)
+    wf = w.float().requires_grad_(True)
+    ref_y = F.conv2d(x.float(), wf, None, s, p, d)
+    dz = torch.randn_like(ref_y).bfloat16().contiguous(memory_format=torch.channels_last)
+    (ref_dw,) = torch.autograd.grad(ref_y, wf, dz.float())
+    for tb in (1, 64):    # no split (plain stores) and split-K (atomics)
+        out = torch.full((K, C, R, R), float("nan"), device="cuda")
+        assert IG.wgrad(dz, x, w.shape, (s, s), (p, p), (d, d), dw_out=out, target_blocks=tb) is None
+        err = (out - ref_dw).abs().max().item()
+        assert err < 1e-2 * max(1.0, ref_dw.abs().max().item()), (tb, err)
+
+
+def test_cast_table_dgrad_layout():
+    from deeplearning4j_amd.ops import updater as U
+    O, I, kh, kw = 6, 5, 3, 3
+    n = O * I * kh * kw
+    src = torch.randn(n, device="cuda")
+    ct = U.CastTable([(0, 0, n, I, kh * kw, O, 1)], "cuda")
+    dst = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    ct.run(src, dst)
+    w = src.view(O, I, kh, kw)
+    ref = torch.flip(w, dims=[2, 3]).permute(1, 2, 3, 0).contiguous().bfloat16()
+    assert torch.equal(dst.view(I, kh, kw, O), ref)
