@@ -194,8 +194,10 @@ class ComputationGraph(BaseNetwork):
         for impl in impls.values():
             if isinstance(impl, ConvolutionLayerImpl):
                 impl.fold_bias = False
+                impl.want_stats = False
             elif isinstance(impl, BatchNormalizationImpl):
                 impl.conv_bias = None
+                impl.producer = None
         if self.fusion_enabled:
             for n in self.topologicalOrder:
                 if n in fused_away or not is_plain_bn(n) or not single(n):
@@ -235,6 +237,15 @@ class ComputationGraph(BaseNetwork):
                     if isinstance(b, BatchNormalizationImpl) and conf.vertices[cons[n][0]].preProcessor is None and b.conf.idropout is None:
                         a.fold_bias = True
                         b.conv_bias = (lambda a=a: a.params["b"].reshape(-1))
+            # conv -> BN (any bias handling): fuse the BN statistics into the conv epilogue
+            for n in self.topologicalOrder:
+                a = impls[n]
+                if isinstance(a, ConvolutionLayerImpl) and isinstance(a.conf.activationFn, ActivationIdentity) and single(n):
+                    b = impls.get(cons[n][0])
+                    if (isinstance(b, BatchNormalizationImpl) and conf.vertices[cons[n][0]].preProcessor is None
+                            and b.conf.idropout is None and (a.fold_bias or "b" not in a.params)):
+                        a.want_stats = True
+                        b.producer = a
         plan = []
         for n in self.topologicalOrder:
             if n in fused_away:

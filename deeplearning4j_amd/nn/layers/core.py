@@ -299,8 +299,9 @@ class BatchNormalizationImpl(LayerImpl):
         gamma, beta, gmean, gvar, dgm, dgv = self._views()
         cb = self.conv_bias() if self.conv_bias is not None else None
         if train:
+            pre = self.producer.out_sums if getattr(self, "producer", None) is not None else None
             mean, invstd, scale, shift = BN.batch_stats(x2, gamma, beta, self.conf.eps, self.conf.decay, gmean, gvar,
-                                                        self.conf.useLogStd, cb, dgm, dgv)
+                                                        self.conf.useLogStd, cb, dgm, dgv, sums=pre)
             self._mean, self._invstd = mean, invstd
             return scale, shift
         return BN.infer_coeffs(gamma, beta, gmean, gvar, self.conf.eps, self.conf.useLogStd, cb)
@@ -358,9 +359,11 @@ class ConvolutionLayerImpl(LayerImpl):
     def __init__(self, conf, ctx):
         super().__init__(conf, ctx)
         self.fold_bias = False   # bias folded into a following BatchNorm (fusion planner)
+        self.want_stats = False  # emit per-channel sum/sumsq for the following BatchNorm (conv epilogue fusion)
+        self.out_sums = None
 
     def compute_replicas(self):
-        r = [("W", "ohwi")]
+        r = [("W", "ohwi"), ("W", "dgrad")]
         if "b" in self.params:
             r.append(("b", "plain"))
         return r
@@ -388,7 +391,8 @@ class ConvolutionLayerImpl(LayerImpl):
         self.input, self._pad = x, pad
         c = self.conf
         b = None if (self.fold_bias or "b" not in self.params) else self.w("b").reshape(-1)
-        z = CONV.conv2d_forward(x, self.w("W"), b, c.stride, pad, c.dilation)
+        z, self.out_sums = CONV.conv2d_forward(x, self.w("W"), b, c.stride, pad, c.dilation,
+                                               want_stats=self.want_stats and train)
         act = c.activationFn
         if act is None or isinstance(act, ActivationIdentity):
             self.z = None
@@ -404,8 +408,10 @@ class ConvolutionLayerImpl(LayerImpl):
         has_b = "b" in self.params and not self.fold_bias
         need_dx = getattr(self, "needs_input_grad", True)
         dx, dW, db = CONV.conv2d_backward(dz, self.input, self.w("W"), c.stride, self._pad, c.dilation,
-                                          need_dx, True, has_b)
-        self.grads["W"].copy_(dW)
+                                          need_dx, True, has_b, w_dgrad=self.cparams.get("W_dgrad"),
+                                          dw_out=self.grads["W"])
+        if dW is not None:
+            self.grads["W"].copy_(dW)
         if "b" in self.grads:
             if has_b:
                 self.grads["b"].copy_(db.reshape(1, -1))

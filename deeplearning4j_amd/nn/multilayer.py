@@ -87,6 +87,11 @@ class MultiLayerNetwork(BaseNetwork):
                     and b.conf.idropout is None):
                 a.fold_bias = True
                 b.conv_bias = (lambda a=a: a.params["b"].reshape(-1))
+            if (isinstance(a, ConvolutionLayerImpl) and isinstance(b, BatchNormalizationImpl)
+                    and isinstance(a.conf.activationFn, ActivationIdentity) and (i + 1) not in pre
+                    and b.conf.idropout is None and (a.fold_bias or "b" not in a.params)):
+                a.want_stats = True
+                b.producer = a
         return plan
 
     # ------------------------------------------------------------------ accessors

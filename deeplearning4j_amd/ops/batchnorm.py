@@ -96,18 +96,22 @@ def apply(x2d, scale, shift, residual=None, rscale=None, rshift=None, relu=False
 
 
 def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std=False, conv_bias=None,
-                dgmean_out=None, dgvar_out=None):
-    """Batch statistics + affine coefficients. Returns (mean, invstd, scale, shift)."""
+                dgmean_out=None, dgvar_out=None, sums=None):
+    """Batch statistics + affine coefficients. Returns (mean, invstd, scale, shift).
+    ``sums`` ([2C] fp32: per-channel sum and sum of squares), when given, comes from the producing
+    conv's epilogue and the statistics pass over x is skipped."""
     M, C = x2d.shape
     stat_mode = 0 if dgmean_out is None else (2 if log_std else 1)
     if _hip_ok(x2d):
         dev = x2d.device
         buf = torch.empty(6 * C, device=dev, dtype=torch.float32)
-        sums, mean, invstd, scale, shift = buf[:2 * C], buf[2 * C:3 * C], buf[3 * C:4 * C], buf[4 * C:5 * C], buf[5 * C:]
+        mean, invstd, scale, shift = buf[2 * C:3 * C], buf[3 * C:4 * C], buf[4 * C:5 * C], buf[5 * C:]
         h = L.hip()
-        ws = _workspace(C, dev)
-        L.check(h.dl4j_bn_stats(L.ptr(x2d), L.ptr(ws), L.ptr(sums), L.c_int64(M), L.c_int(C),
-                                L.c_int(L.dtype_code(x2d)), L.stream()), "bn_stats")
+        if sums is None:
+            sums = buf[:2 * C]
+            ws = _workspace(C, dev)
+            L.check(h.dl4j_bn_stats(L.ptr(x2d), L.ptr(ws), L.ptr(sums), L.c_int64(M), L.c_int(C),
+                                    L.c_int(L.dtype_code(x2d)), L.stream()), "bn_stats")
         L.check(h.dl4j_bn_finalize(L.ptr(sums), L.ptr(gamma), L.ptr(beta), L.ptr(conv_bias), L.ptr(gmean),
                                    L.ptr(gvar), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift),
                                    L.ptr(dgmean_out), L.ptr(dgvar_out), L.c_int(C), L.c_int64(M), L.c_float(eps),

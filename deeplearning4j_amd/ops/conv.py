@@ -36,19 +36,34 @@ def _hip_eligible(x, w, stride, padding, dilation):
     return conv_igemm.supported(x, w, stride, padding, dilation)
 
 
-def conv2d_forward(x, w, b, stride, padding, dilation, stats_out=None):
-    """x: [N,C,H,W] logical (channels_last memory on GPU). Returns z (same memory format)."""
+def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False):
+    """x: [N,C,H,W] logical (channels_last memory on GPU). Returns (z, sums): ``sums`` is the [2K] fp32
+    per-channel (sum, sum of squares) of z when the HIP path fused it into its epilogue, else None."""
     if _hip_eligible(x, w, stride, padding, dilation):
         from . import conv_igemm
-        return conv_igemm.forward(x, w, b, stride, padding, dilation, stats_out)
-    return F.conv2d(x, w, b, tuple(stride), tuple(padding), tuple(dilation))
+        return conv_igemm.forward(x, w, b, stride, padding, dilation, want_stats)
+    return F.conv2d(x, w, b, tuple(stride), tuple(padding), tuple(dilation)), None
 
 
-def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=True, need_db=False):
-    """Returns (dx, dW, db); dW has logical shape [nOut, nIn, kH, kW]."""
-    if _hip_eligible(x, w, stride, padding, dilation):
-        from . import conv_igemm
-        return conv_igemm.backward(dz, x, w, stride, padding, dilation, need_dx, need_dw, need_db)
+def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=True, need_db=False, w_dgrad=None,
+                    dw_out=None):
+    """Returns (dx, dW, db); dW has logical shape [nOut, nIn, kH, kW] — or None when it was written
+    straight into ``dw_out`` (fp32 gradient view) by the HIP wgrad kernel."""
+    if _hip_eligible(x, w, stride, padding, dilation) and dz.dtype == torch.bfloat16:
+        from . import conv_igemm as IG
+        dx = dW = db = None
+        if need_db:
+            db = dz.float().sum((0, 2, 3))
+        if need_dw:
+            dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out)
+        if need_dx:
+            if w_dgrad is not None and IG.dgrad_supported(w, stride, padding):
+                dx = IG.dgrad(dz, x.shape, w_dgrad, stride, padding, dilation)
+            else:
+                dx = torch.ops.aten.convolution_backward(
+                    dz.contiguous(memory_format=torch.channels_last), x, w, None, list(stride), list(padding),
+                    list(dilation), False, [0, 0], 1, [True, False, False])[0]
+        return dx, dW, db
     if x.is_cuda and not dz.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last):
         dz = dz.contiguous(memory_format=torch.channels_last)
     dx, dw, db = torch.ops.aten.convolution_backward(
