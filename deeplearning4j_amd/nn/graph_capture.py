@@ -52,12 +52,13 @@ class CapturedTrainStep:
                 net._apply_update(net._last_batch)
                 return
             net._on_backward_progress = None   # overlap hooks cannot run inside a captured region
+            # thread_local: the RCCL watchdog thread's event queries must not invalidate the capture
             torch.cuda.synchronize()
             ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 self._compute(self._x, self._y)
             gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb, pool=ga.pool()):
+            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
                 net._apply_update(net._last_batch, sync=False)
             self.graph_a, self.graph_b = ga, gb
         self.graph_a.replay()
