@@ -248,8 +248,17 @@ class MultiLayerNetwork(BaseNetwork):
         pre = self.conf.inputPreProcessors
         eps = None
         steps = list(self._plan)
+        prog = self._on_backward_progress
+        if prog is not None:
+            if self._on_backward_begin is not None:
+                self._on_backward_begin()
+            offs = self._layer_min_offsets()
+        first = True
         for kind, i in reversed(steps):
             l = self.layers[i]
+            if prog is not None and not first:
+                prog(offs[i + 1])       # layers i+1.. have finished writing their gradients
+            first = False
             if getattr(l, "is_output", False) and i == len(self.layers) - 1:
                 eps = l.backward(None)
             else:
@@ -263,6 +272,18 @@ class MultiLayerNetwork(BaseNetwork):
             if eps is None:
                 break
         return eps
+
+    def _layer_min_offsets(self):
+        """offs[i] = lowest flat-gradient offset owned by layers i..end."""
+        if getattr(self, "_layer_offs", None) is None:
+            by_impl = {}
+            for e in self._entries:
+                by_impl.setdefault(id(e.layer), []).append(e.off)
+            offs = [self._num_params] * (len(self.layers) + 1)
+            for i in range(len(self.layers) - 1, -1, -1):
+                offs[i] = min([offs[i + 1]] + by_impl.get(id(self.layers[i]), []))
+            self._layer_offs = offs
+        return self._layer_offs
 
     def computeGradientAndScore(self, x=None, y=None, fmask=None, lmask=None, mode=None):
         """Forward + backward; fills the flat gradient vector and the device-resident score."""

@@ -149,7 +149,7 @@ class GradientBuckets:
             w.wait()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        self._works = []
+        self.begin()          # self-resetting: the next iteration starts from the tail bucket again
 
     def reduce_all(self):
         """Non-overlapped path: reduce every bucket on the current stream."""
