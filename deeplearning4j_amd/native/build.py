@@ -52,7 +52,7 @@ def _run(cmd):
 def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> None:
     OBJ.mkdir(exist_ok=True)
     hipcc = _hipcc()
-    headers = list(CSRC.glob("*.h")) + list(CSRC.glob("*.hpp"))
+    headers = list(CSRC.glob("*.h")) + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc"))
     jobs = jobs or min(8, os.cpu_count() or 4)
 
     hip_srcs = sorted(CSRC.glob("*.hip"))

@@ -1,0 +1,734 @@
+// "Legacy" op families for gfx950: pairwise / broadcast / scalar / transform / reduce / reduce3 /
+// indexreduce / summarystats, dispatched by functor id.
+//
+// Reference role: libnd4j loops/cuda/{pairwise,broadcasting,scalar,transform/*,reduce/*,reduce3,
+// indexreduce,summarystatsreduce}.* + ops/ops.h functors + legacy/cuda/NativeOpExecutioner.cu
+// (SURVEY §2.2). The opNum tables (ABI, Appendix E) live on the Python side
+// (nd4j/ops/legacy.py) and map each family's opNum to the functor ids below.
+//
+// Own design (not a port of the TAD/shapeInfo-pointer kernels):
+//  * strides travel BY VALUE in the kernel argument block (rank <= 8 after dimension coalescing on
+//    the host), so there are no device-side shapeInfo buffers, no constant caches to sync;
+//  * broadcast == pairwise with zero strides; scalar == pairwise with a by-value scalar;
+//  * reductions never use the "last block done" threadfence idiom of reduce_float.chpp:142-223
+//    (not safe across XCD L2s): long reductions are split into segments -> partial accumulators ->
+//    a second merge kernel. Short TADs get one wave64 each, long ones a 256-thread block.
+//  * 64-bit indexing throughout (288 GB HBM makes > 2^31 elements reachable).
+#include "common.h"
+
+#define MAXR 8
+
+struct Strides3 {
+  int rank;
+  int contiguous;                 // 1: x,y,z all dense with identical order -> linear index
+  int64_t shape[MAXR];
+  int64_t sx[MAXR], sy[MAXR], sz[MAXR];
+};
+
+struct TadDesc {
+  int irank, orank;               // inner (reduced) dims, outer (kept) dims
+  int64_t ishape[MAXR], istride[MAXR], iystride[MAXR];
+  int64_t oshape[MAXR], ostride[MAXR], oystride[MAXR];
+  int64_t tad_len, num_tads;
+};
+
+// ---- binary functors ------------------------------------------------------------------------------
+enum BinF {
+  B_ADD = 0, B_SUB, B_MUL, B_DIV, B_RSUB, B_RDIV, B_COPY, B_POW, B_MAX, B_MIN, B_AMAX, B_AMIN, B_AXPY, B_CAS, B_CAR,
+  B_REMAINDER, B_FMOD, B_ATAN2, B_TRUNCDIV, B_FLOORDIV, B_FLOORMOD, B_SQSUB, B_RMOD, B_SAFEDIV, B_MOD, B_RELERR,
+  B_BINRELERR, B_BINMINABSRELERR, B_LOR, B_LXOR, B_LNOT, B_LAND, B_POWDERIV, B_LOGPOISSON, B_LOGPOISSONFULL,
+  B_TRUNCMOD, B_REPLACENANS, B_DIVNONAN, B_IGAMMA, B_IGAMMAC,
+  // scalar-only
+  B_ELU, B_ELUDERIV, B_SXE_SMOOTH, B_LRELU, B_LRELUDERIV, B_LOGX, B_RELU, B_RELU6, B_STEP, B_LSTMCLIP, B_SQRSUB,
+  B_RPOW, B_RELUDERIV,
+  // boolean-result
+  B_EQ, B_GT, B_LT, B_EPS, B_GTE, B_MATCH, B_NEQ, B_AND, B_OR, B_XOR, B_NOT, B_LTE,
+  // integer
+  B_SHL, B_SHR, B_CSHL, B_CSHR, B_IAND, B_IOR, B_IXOR
+};
+
+// MatchCondition modes (nd4j Conditions): extra[0]=compare value, extra[1]=eps, extra[2]=mode
+template <typename A>
+__device__ __forceinline__ bool match_cond(A x, A cmp, A eps, int mode) {
+  switch (mode) {
+    case 0: return fabs((double)(x - cmp)) <= (double)eps;   // epsEquals
+    case 1: return fabs((double)(x - cmp)) > (double)eps;    // epsNotEquals
+    case 2: return x < cmp;
+    case 3: return x > cmp;
+    case 4: return x <= cmp;
+    case 5: return x >= cmp;
+    case 6: return fabs((double)x) < (double)cmp;            // absLessThan
+    case 7: return fabs((double)x) > (double)cmp;
+    case 8: return isinf((double)x);
+    case 9: return isnan((double)x);
+    case 10: return x == cmp;
+    case 11: return x != cmp;
+    case 12: return fabs((double)x) >= (double)cmp;
+    case 13: return fabs((double)x) <= (double)cmp;
+    case 14: return isfinite((double)x);
+    case 15: return !isfinite((double)x);
+  }
+  return false;
+}
+
+// regularized incomplete gamma P(a,x) (series for x<a+1, continued fraction otherwise)
+__device__ double igamma_p(double a, double x) {
+  if (x <= 0.0 || a <= 0.0) return 0.0;
+  double gln = lgamma(a);
+  if (x < a + 1.0) {
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int n = 0; n < 200; ++n) {
+      ap += 1.0;
+      del *= x / ap;
+      sum += del;
+      if (fabs(del) < fabs(sum) * 1e-15) break;
+    }
+    return sum * exp(-x + a * log(x) - gln);
+  }
+  double b = x + 1.0 - a, c = 1.0 / 1e-300, d = 1.0 / b, h = d;
+  for (int i = 1; i < 200; ++i) {
+    double an = -i * (i - a);
+    b += 2.0;
+    d = an * d + b;
+    if (fabs(d) < 1e-300) d = 1e-300;
+    c = b + an / c;
+    if (fabs(c) < 1e-300) c = 1e-300;
+    d = 1.0 / d;
+    double del = d * c;
+    h *= del;
+    if (fabs(del - 1.0) < 1e-15) break;
+  }
+  return 1.0 - exp(-x + a * log(x) - gln) * h;
+}
+
+template <typename A>
+__device__ __forceinline__ A rel_err(A a, A b) {
+  if (a == (A)0 && b == (A)0) return (A)0;
+  return (A)(fabs((double)(a - b)) / (fabs((double)a) + fabs((double)b)));
+}
+
+template <typename A>
+__device__ __forceinline__ A bin_op(int f, A x, A y, const double* e) {
+  switch (f) {
+    case B_ADD: return x + y;
+    case B_SUB: return x - y;
+    case B_MUL: return x * y;
+    case B_DIV: return x / y;
+    case B_RSUB: return y - x;
+    case B_RDIV: return y / x;
+    case B_COPY: return y;
+    case B_POW: return (A)pow((double)x, (double)y);
+    case B_RPOW: return (A)pow((double)y, (double)x);
+    case B_MAX: return x > y ? x : y;
+    case B_MIN: return x < y ? x : y;
+    case B_AMAX: return fabs((double)x) > fabs((double)y) ? x : y;
+    case B_AMIN: return fabs((double)x) < fabs((double)y) ? x : y;
+    case B_AXPY: return (A)(e[0] * (double)x) + y;
+    case B_CAS: {   // CompareAndSet: where cond(x, e0) holds take y (pairwise) / e[3] (set value)
+      return match_cond<A>(x, (A)e[0], (A)e[1], (int)e[2]) ? y : x;
+    }
+    case B_CAR: return match_cond<A>(y, (A)e[0], (A)e[1], (int)e[2]) ? y : x;   // CompareAndReplace
+    case B_REMAINDER: return (A)remainder((double)x, (double)y);
+    case B_FMOD: return (A)fmod((double)x, (double)y);
+    case B_ATAN2: return (A)atan2((double)x, (double)y);
+    case B_TRUNCDIV: return (A)trunc((double)x / (double)y);
+    case B_FLOORDIV: return (A)floor((double)x / (double)y);
+    case B_FLOORMOD: {
+      double m = fmod((double)x, (double)y);
+      return (A)((m != 0.0 && ((m < 0.0) != ((double)y < 0.0))) ? m + (double)y : m);
+    }
+    case B_SQSUB: return (x - y) * (x - y);
+    case B_SQRSUB: return (y - x) * (y - x);
+    case B_RMOD: return (A)((long long)y % ((long long)x == 0 ? 1 : (long long)x));
+    case B_SAFEDIV: return y == (A)0 ? (A)0 : x / y;
+    case B_MOD:
+    case B_TRUNCMOD: return (A)((long long)x % ((long long)y == 0 ? 1 : (long long)y));
+    case B_RELERR: return rel_err<A>(x, y);
+    case B_BINRELERR: return rel_err<A>(x, y) > (A)e[0] ? (A)1 : (A)0;
+    case B_BINMINABSRELERR: {
+      if (fabs((double)(x - y)) < e[1]) return (A)0;
+      return rel_err<A>(x, y) > (A)e[0] ? (A)1 : (A)0;
+    }
+    case B_LOR: return (x != (A)0 || y != (A)0) ? (A)1 : (A)0;
+    case B_LXOR: return ((x != (A)0) != (y != (A)0)) ? (A)1 : (A)0;
+    case B_LNOT: return (x != (A)0 && y == (A)0) ? (A)1 : ((x == (A)0) ? (A)1 : (A)0);
+    case B_LAND: return (x != (A)0 && y != (A)0) ? (A)1 : (A)0;
+    case B_POWDERIV: return (A)((double)y * pow((double)x, (double)y - 1.0));
+    case B_LOGPOISSON: return (A)(exp((double)y) - (double)x * (double)y);
+    case B_LOGPOISSONFULL: {
+      double z = (double)x, c = (double)y;
+      return (A)(exp(c) - z * c + (z * log(z) - z + 0.5 * log(6.283185307179586 * z)));
+    }
+    case B_REPLACENANS: return isnan((double)x) ? y : x;
+    case B_DIVNONAN: return y == (A)0 ? (A)0 : x / y;
+    case B_IGAMMA: return (A)igamma_p((double)x, (double)y);
+    case B_IGAMMAC: return (A)(1.0 - igamma_p((double)x, (double)y));
+    case B_ELU: return x >= (A)0 ? x : (A)((double)y * (exp((double)x) - 1.0));
+    case B_ELUDERIV: return x >= (A)0 ? (A)1 : (A)((double)y * exp((double)x));
+    case B_SXE_SMOOTH: return (A)((double)x * (1.0 - (double)y) + 0.5 * (double)y);
+    case B_LRELU: return x < (A)0 ? (A)((double)y * (double)x) : x;
+    case B_LRELUDERIV: return x >= (A)0 ? (A)1 : y;
+    case B_LOGX: return (A)(log((double)x) / log((double)y));
+    case B_RELU: return x > y ? x : y;
+    case B_RELU6: {
+      A r = x > y ? x : y;
+      return r < (A)6 ? r : (A)6;
+    }
+    case B_STEP: return x > y ? (A)1 : (A)0;
+    case B_LSTMCLIP: return x > y ? y : (x < -y ? -y : x);
+    case B_RELUDERIV: return x > y ? (A)1 : (A)0;
+    case B_EQ: return x == y ? (A)1 : (A)0;
+    case B_GT: return x > y ? (A)1 : (A)0;
+    case B_LT: return x < y ? (A)1 : (A)0;
+    case B_EPS: {
+      double d = fabs((double)x - (double)y);
+      double eps = e ? e[0] : 0.0;
+      return d <= (eps > 0.0 ? eps : 1e-5) ? (A)1 : (A)0;
+    }
+    case B_GTE: return x >= y ? (A)1 : (A)0;
+    case B_MATCH: return match_cond<A>(x, (A)e[0], (A)e[1], (int)e[2]) ? (A)1 : (A)0;
+    case B_NEQ: return x != y ? (A)1 : (A)0;
+    case B_AND: return (x != (A)0 && y != (A)0) ? (A)1 : (A)0;
+    case B_OR: return (x != (A)0 || y != (A)0) ? (A)1 : (A)0;
+    case B_XOR: return ((x != (A)0) != (y != (A)0)) ? (A)1 : (A)0;
+    case B_NOT: return x == (A)0 ? (A)1 : (A)0;
+    case B_LTE: return x <= y ? (A)1 : (A)0;
+    case B_SHL: return (A)((long long)x << ((long long)y & 63));
+    case B_SHR: return (A)((long long)x >> ((long long)y & 63));
+    case B_CSHL: {
+      uint32_t v = (uint32_t)(long long)x;
+      int s = (int)((long long)y & 31);
+      return (A)(int32_t)((v << s) | (v >> ((32 - s) & 31)));
+    }
+    case B_CSHR: {
+      uint32_t v = (uint32_t)(long long)x;
+      int s = (int)((long long)y & 31);
+      return (A)(int32_t)((v >> s) | (v << ((32 - s) & 31)));
+    }
+    case B_IAND: return (A)((long long)x & (long long)y);
+    case B_IOR: return (A)((long long)x | (long long)y);
+    case B_IXOR: return (A)((long long)x ^ (long long)y);
+  }
+  return x;
+}
+
+// ---- unary functors -----------------------------------------------------------------------------------
+enum UnF {
+  U_ABS = 0, U_SIGN, U_ONES, U_NEG, U_ROUND, U_TIMESONEMINUS, U_CUBE, U_ONEMINUS, U_RECIPROCAL, U_SQUARE, U_CAS,
+  U_IDENTITY, U_CEIL, U_FLOOR, U_CLIP, U_COPY, U_SQRT, U_RSQRT,
+  U_ISINF, U_ISNAN, U_ISFINITE, U_ISINFORNAN, U_MATCHBOOL, U_ISPOS, U_NOT, U_ISNEG,
+  U_SCALEDTANH, U_AFFINE, U_TANHD, U_HARDTANHD, U_SIGMOIDD, U_SOFTSIGND, U_TAND, U_SELUD, U_HARDSIGMOIDD, U_RATTANHD,
+  U_RECTTANHD, U_SWISHD, U_ACOSHD, U_ASINHD, U_SINHD, U_LOGSIGMOIDD, U_SPECIALD, U_STABILIZE, U_CUBED, U_COS, U_EXP,
+  U_LOG, U_SETRANGE, U_SIGMOID, U_SIN, U_SOFTPLUS, U_TANH, U_ACOS, U_ASIN, U_ATAN, U_HARDTANH, U_SOFTSIGN,
+  U_HARDSIGMOID, U_RATTANH, U_RECTTANH, U_SINH, U_COSH, U_TAN, U_SELU, U_SWISH, U_LOG1P, U_ERF, U_ACOSH, U_ASINH,
+  U_RINT, U_LOGSIGMOID, U_ERFC, U_EXPM1, U_ATANH, U_GELU, U_GELUD, U_PGELU, U_PGELUD, U_MISH, U_MISHD
+};
+
+__device__ __forceinline__ double sigm(double x) { return 1.0 / (1.0 + exp(-x)); }
+__device__ __forceinline__ double rat_tanh(double x) {
+  double d = x * (2.0 / 3.0);
+  double a = fabs(d), sg = d < 0 ? -1.0 : 1.0;
+  double t = sg * (1.0 - 1.0 / (1.0 + a + d * d + 1.41645 * d * d * d * d));
+  return 1.7159 * t;
+}
+
+__device__ __forceinline__ double un_op(int f, double x, const double* e) {
+  const double SELU_A = 1.6732632423543772, SELU_L = 1.0507009873554805;
+  switch (f) {
+    case U_ABS: return fabs(x);
+    case U_SIGN: return (x > 0.0) - (x < 0.0);
+    case U_ONES: return 1.0;
+    case U_NEG: return -x;
+    case U_ROUND: return round(x);
+    case U_TIMESONEMINUS: return x * (1.0 - x);
+    case U_CUBE: return x * x * x;
+    case U_ONEMINUS: return 1.0 - x;
+    case U_RECIPROCAL: return 1.0 / x;
+    case U_SQUARE: return x * x;
+    case U_CAS: return match_cond<double>(x, e[0], e[1], (int)e[2]) ? e[3] : x;
+    case U_IDENTITY:
+    case U_COPY: return x;
+    case U_CEIL: return ceil(x);
+    case U_FLOOR: return floor(x);
+    case U_CLIP: return x < e[0] ? e[0] : (x > e[1] ? e[1] : x);
+    case U_SQRT: return sqrt(x);
+    case U_RSQRT: return 1.0 / sqrt(x);
+    case U_ISINF: return isinf(x) ? 1.0 : 0.0;
+    case U_ISNAN: return isnan(x) ? 1.0 : 0.0;
+    case U_ISFINITE: return isfinite(x) ? 1.0 : 0.0;
+    case U_ISINFORNAN: return isfinite(x) ? 0.0 : 1.0;
+    case U_MATCHBOOL: return match_cond<double>(x, e[0], e[1], (int)e[2]) ? 1.0 : 0.0;
+    case U_ISPOS: return x > 0.0 ? 1.0 : 0.0;
+    case U_NOT: return x == 0.0 ? 1.0 : 0.0;
+    case U_ISNEG: return x < 0.0 ? 1.0 : 0.0;
+    case U_SCALEDTANH: return e[0] * tanh(e[1] * x);
+    case U_AFFINE: return e[0] * x + e[1];
+    case U_TANHD: { double t = tanh(x); return 1.0 - t * t; }
+    case U_HARDTANHD: return (x >= -1.0 && x <= 1.0) ? 1.0 : 0.0;
+    case U_SIGMOIDD: { double s = sigm(x); return s * (1.0 - s); }
+    case U_SOFTSIGND: { double d = 1.0 + fabs(x); return 1.0 / (d * d); }
+    case U_TAND: { double c = cos(x); return 1.0 / (c * c); }
+    case U_SELUD: return x > 0.0 ? SELU_L : SELU_L * SELU_A * exp(x);
+    case U_HARDSIGMOIDD: return (x < -2.5 || x > 2.5) ? 0.0 : 0.2;
+    case U_RATTANHD: {
+      double d = x * (2.0 / 3.0), a = fabs(d);
+      double den = 1.0 + a + d * d + 1.41645 * d * d * d * d;
+      double td = (1.0 + (d < 0 ? -1.0 : 1.0) * (2.0 * d + 4.0 * 1.41645 * d * d * d)) / (den * den);
+      return 1.7159 * (2.0 / 3.0) * td;
+    }
+    case U_RECTTANHD: { double t = tanh(x); return x > 0.0 ? 1.0 - t * t : 0.0; }
+    case U_SWISHD: { double s = sigm(x); return s + x * s * (1.0 - s); }
+    case U_ACOSHD: return 1.0 / (sqrt(x - 1.0) * sqrt(x + 1.0));
+    case U_ASINHD: return 1.0 / sqrt(x * x + 1.0);
+    case U_SINHD: return cosh(x);
+    case U_LOGSIGMOIDD: return 1.0 / (exp(x) + 1.0);
+    case U_SPECIALD: return x * (1.0 - x);
+    case U_STABILIZE: {
+      double k = e[0];
+      if (x * k > 88.0) return 88.0 / k;
+      if (x * k < -88.0) return -88.0 / k;
+      return x;
+    }
+    case U_CUBED: return 3.0 * x * x;
+    case U_COS: return cos(x);
+    case U_EXP: return exp(x);
+    case U_LOG: return log(x);
+    case U_SETRANGE: {
+      double mn = e[0], mx = e[1];
+      if (x >= mn && x <= mx) return x;
+      if (mn == 0.0 && mx == 1.0) return floor(sigm(x) * (mx - mn)) + mn;
+      return floor(x * (mx - mn)) + mn;
+    }
+    case U_SIGMOID: return sigm(x);
+    case U_SIN: return sin(x);
+    case U_SOFTPLUS: return x > 30.0 ? x : log1p(exp(x));
+    case U_TANH: return tanh(x);
+    case U_ACOS: return acos(x);
+    case U_ASIN: return asin(x);
+    case U_ATAN: return atan(x);
+    case U_HARDTANH: return x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x);
+    case U_SOFTSIGN: return x / (1.0 + fabs(x));
+    case U_HARDSIGMOID: return fmin(1.0, fmax(0.0, 0.2 * x + 0.5));
+    case U_RATTANH: return rat_tanh(x);
+    case U_RECTTANH: return fmax(0.0, tanh(x));
+    case U_SINH: return sinh(x);
+    case U_COSH: return cosh(x);
+    case U_TAN: return tan(x);
+    case U_SELU: return x > 0.0 ? SELU_L * x : SELU_L * SELU_A * (exp(x) - 1.0);
+    case U_SWISH: return x * sigm(x);
+    case U_LOG1P: return log1p(x);
+    case U_ERF: return erf(x);
+    case U_ACOSH: return acosh(x);
+    case U_ASINH: return asinh(x);
+    case U_RINT: return rint(x);
+    case U_LOGSIGMOID: return -(x < -30.0 ? -x : log1p(exp(-x)));
+    case U_ERFC: return erfc(x);
+    case U_EXPM1: return expm1(x);
+    case U_ATANH: return atanh(x);
+    case U_GELU: return x * sigm(1.702 * x);
+    case U_GELUD: { double s = sigm(1.702 * x); return s + 1.702 * x * s * (1.0 - s); }
+    case U_PGELU: { double u = 0.7978845608028654 * (x + 0.044715 * x * x * x); return 0.5 * x * (1.0 + tanh(u)); }
+    case U_PGELUD: {
+      double u = 0.7978845608028654 * (x + 0.044715 * x * x * x), t = tanh(u);
+      return 0.5 * (1.0 + t) + 0.5 * x * (1.0 - t * t) * 0.7978845608028654 * (1.0 + 3.0 * 0.044715 * x * x);
+    }
+    case U_MISH: { double sp = x > 30.0 ? x : log1p(exp(x)); return x * tanh(sp); }
+    case U_MISHD: {
+      double sp = x > 30.0 ? x : log1p(exp(x)), t = tanh(sp), s = sigm(x);
+      return t + x * (1.0 - t * t) * s;
+    }
+  }
+  return x;
+}
+
+// float fast path for the hot activations (avoids fp64 math on the common fp32/bf16 tensors)
+__device__ __forceinline__ bool un_op_f32(int f, float x, float& out) {
+  switch (f) {
+    case U_ABS: out = fabsf(x); return true;
+    case U_NEG: out = -x; return true;
+    case U_SQUARE: out = x * x; return true;
+    case U_SQRT: out = sqrtf(x); return true;
+    case U_RSQRT: out = rsqrtf(x); return true;
+    case U_EXP: out = __expf(x); return true;
+    case U_LOG: out = __logf(x); return true;
+    case U_TANH: out = tanhf(x); return true;
+    case U_SIGMOID: out = 1.f / (1.f + __expf(-x)); return true;
+    case U_IDENTITY:
+    case U_COPY: out = x; return true;
+    case U_RECIPROCAL: out = 1.f / x; return true;
+    case U_ONEMINUS: out = 1.f - x; return true;
+    case U_SIN: out = sinf(x); return true;
+    case U_COS: out = cosf(x); return true;
+  }
+  return false;
+}
+
+template <typename T> struct Acc { typedef float type; };
+template <> struct Acc<double> { typedef double type; };
+template <> struct Acc<int32_t> { typedef long long type; };
+template <> struct Acc<int64_t> { typedef long long type; };
+
+template <typename T> __device__ __forceinline__ typename Acc<T>::type ldv(const T* p, int64_t i) { return (typename Acc<T>::type)p[i]; }
+template <> __device__ __forceinline__ float ldv<bf16_t>(const bf16_t* p, int64_t i) { return bf2f(p[i]); }
+template <typename T, typename A> __device__ __forceinline__ void stv(T* p, int64_t i, A v) { p[i] = (T)v; }
+template <> __device__ __forceinline__ void stv<bf16_t, float>(bf16_t* p, int64_t i, float v) { p[i] = f2bf(v); }
+template <> __device__ __forceinline__ void stv<bf16_t, double>(bf16_t* p, int64_t i, double v) { p[i] = f2bf((float)v); }
+
+__device__ __forceinline__ void offsets3(const Strides3& s, int64_t idx, int64_t& ox, int64_t& oy, int64_t& oz) {
+  ox = oy = oz = 0;
+#pragma unroll
+  for (int d = MAXR - 1; d >= 0; --d) {
+    if (d < s.rank) {
+      int64_t c = idx % s.shape[d];
+      idx /= s.shape[d];
+      ox += c * s.sx[d];
+      oy += c * s.sy[d];
+      oz += c * s.sz[d];
+    }
+  }
+}
+
+struct Extra {
+  double e[4];
+};
+
+// Z = type of output (T, or uint8 for bool-result families)
+template <typename T, typename Z>
+__global__ void pairwise_kernel(const T* __restrict__ x, const T* __restrict__ y, Z* __restrict__ z, int64_t n, int f,
+                                Strides3 s, Extra ex, int use_scalar, double scalar) {
+  typedef typename Acc<T>::type A;
+  const A sc = (A)scalar;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t ox, oy, oz;
+    if (s.contiguous) ox = oy = oz = i;
+    else offsets3(s, i, ox, oy, oz);
+    A a = ldv<T>(x, ox);
+    A b = use_scalar ? sc : ldv<T>(y, oy);
+    A r = bin_op<A>(f, a, b, ex.e);
+    stv<Z, A>(z, oz, r);
+  }
+}
+
+template <typename T, typename Z>
+__global__ void transform_kernel(const T* __restrict__ x, Z* __restrict__ z, int64_t n, int f, Strides3 s, Extra ex) {
+  typedef typename Acc<T>::type A;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t ox, oy, oz;
+    if (s.contiguous) ox = oz = i;
+    else offsets3(s, i, ox, oy, oz);
+    A a = ldv<T>(x, ox);
+    float fo;
+    if (sizeof(A) == 4 && un_op_f32(f, (float)a, fo)) stv<Z, A>(z, oz, (A)fo);
+    else stv<Z, A>(z, oz, (A)un_op(f, (double)a, ex.e));
+  }
+}
+
+// ---- reductions -----------------------------------------------------------------------------------
+enum RedF {
+  R_MEAN = 0, R_AMEAN, R_NORM1, R_NORM2, R_NORMMAX, R_NORMFROB, R_NORMP, R_SQNORM, R_ENTROPY, R_LOGENTROPY, R_SHANNON,
+  R_SUM, R_MAX, R_MIN, R_PROD, R_ASUM, R_AMAX, R_AMIN,
+  R_ANY, R_ALL, R_ISFINITE, R_ISINFORNAN, R_ISNAN, R_ISINF, R_ISPOS, R_ISNEG,
+  R_COUNTNZ, R_COUNTZ, R_MATCH,
+  // reduce3 (two operands; up to 3 running sums)
+  R3_MANHATTAN, R3_EUCLID, R3_COSSIM, R3_DOT, R3_EQEPS, R3_COSDIST, R3_JACCARD, R3_HAMMING,
+  // summary stats
+  RS_VAR, RS_STD,
+  // index reduce
+  RI_MAX, RI_MIN, RI_AMAX, RI_AMIN, RI_FIRST, RI_LAST
+};
+
+enum { K_SUM = 0, K_MAX = 1, K_MIN = 2, K_PROD = 3 };
+
+__device__ __forceinline__ int red_kind(int f) {
+  switch (f) {
+    case R_NORMMAX: case R_MAX: case R_AMAX: case R_ANY: case R_ISINFORNAN: case R_ISNAN: case R_ISINF: return K_MAX;
+    case R_MIN: case R_AMIN: case R_ALL: case R_ISFINITE: case R_ISPOS: case R_ISNEG: return K_MIN;
+    case R_PROD: return K_PROD;
+  }
+  return K_SUM;
+}
+__device__ __forceinline__ double red_init(int kind) {
+  return kind == K_MAX ? -INFINITY : kind == K_MIN ? INFINITY : kind == K_PROD ? 1.0 : 0.0;
+}
+__device__ __forceinline__ double red_merge(int kind, double a, double b) {
+  return kind == K_SUM ? a + b : kind == K_MAX ? fmax(a, b) : kind == K_MIN ? fmin(a, b) : a * b;
+}
+__device__ __forceinline__ double red_pre(int f, double x, const double* e) {
+  switch (f) {
+    case R_MEAN: case R_SUM: case R_MAX: case R_MIN: case R_PROD: return x;
+    case R_AMEAN: case R_NORM1: case R_ASUM: case R_NORMMAX: case R_AMAX: case R_AMIN: return fabs(x);
+    case R_NORM2: case R_NORMFROB: case R_SQNORM: return x * x;
+    case R_NORMP: return pow(fabs(x), e[0]);
+    case R_ENTROPY: case R_LOGENTROPY: return x > 0.0 ? x * log(x) : 0.0;
+    case R_SHANNON: { double p = x * x; return p > 0.0 ? p * log2(p) : 0.0; }
+    case R_ANY: return x != 0.0 ? 1.0 : 0.0;
+    case R_ALL: return x != 0.0 ? 1.0 : 0.0;
+    case R_ISFINITE: return isfinite(x) ? 1.0 : 0.0;
+    case R_ISINFORNAN: return isfinite(x) ? 0.0 : 1.0;
+    case R_ISNAN: return isnan(x) ? 1.0 : 0.0;
+    case R_ISINF: return isinf(x) ? 1.0 : 0.0;
+    case R_ISPOS: return x > 0.0 ? 1.0 : 0.0;
+    case R_ISNEG: return x < 0.0 ? 1.0 : 0.0;
+    case R_COUNTNZ: return x != 0.0 ? 1.0 : 0.0;
+    case R_COUNTZ: return x == 0.0 ? 1.0 : 0.0;
+    case R_MATCH: return match_cond<double>(x, e[0], e[1], (int)e[2]) ? 1.0 : 0.0;
+  }
+  return x;
+}
+__device__ __forceinline__ double red_post(int f, double acc, double n, const double* e) {
+  switch (f) {
+    case R_MEAN: case R_AMEAN: return acc / n;
+    case R_NORM2: case R_NORMFROB: return sqrt(acc);
+    case R_NORMP: return pow(acc, 1.0 / e[0]);
+    case R_ENTROPY: case R_SHANNON: return -acc;
+    case R_LOGENTROPY: return log(-acc);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ double wave_merge(int kind, double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = red_merge(kind, v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ int64_t tad_base(const int64_t* oshape, const int64_t* ostride, int orank, int64_t t) {
+  int64_t off = 0;
+  for (int d = orank - 1; d >= 0; --d) {
+    off += (t % oshape[d]) * ostride[d];
+    t /= oshape[d];
+  }
+  return off;
+}
+__device__ __forceinline__ int64_t inner_off(const int64_t* ishape, const int64_t* istride, int irank, int64_t j) {
+  if (irank == 1) return j * istride[0];
+  int64_t off = 0;
+  for (int d = irank - 1; d >= 0; --d) {
+    off += (j % ishape[d]) * istride[d];
+    j /= ishape[d];
+  }
+  return off;
+}
+
+// group = 64 (one wave per TAD) or 256 (one block per TAD). segs = segments per TAD (two-stage when > 1).
+// out: [num_tads * segs] accumulators (double) when segs > 1, else final values into z.
+template <typename T, typename Z>
+__global__ __launch_bounds__(256) void reduce_kernel(const T* __restrict__ x, Z* __restrict__ z, double* __restrict__ partial,
+                                                     TadDesc d, int f, Extra ex, int group, int segs) {
+  __shared__ double red[4];
+  const int kind = red_kind(f);
+  const int groups_per_block = 256 / group;
+  const int g_in_block = threadIdx.x / group, lane = threadIdx.x % group;
+  const int64_t total_groups = d.num_tads * segs;
+  // group == 256 -> one group per block, so g (and the trip count) is block-uniform around the barriers
+  for (int64_t g = (int64_t)blockIdx.x * groups_per_block + g_in_block; g < total_groups;
+       g += (int64_t)gridDim.x * groups_per_block) {
+    const bool live = g < total_groups;
+    double acc = red_init(kind);
+    int64_t t = 0, sidx = 0;
+    if (live) {
+      t = g / segs;
+      sidx = g % segs;
+      const int64_t seg_len = (d.tad_len + segs - 1) / segs;
+      const int64_t j0 = sidx * seg_len, j1 = (j0 + seg_len < d.tad_len) ? j0 + seg_len : d.tad_len;
+      const int64_t base = tad_base(d.oshape, d.ostride, d.orank, t);
+      for (int64_t j = j0 + lane; j < j1; j += group) {
+        double v = (double)ldv<T>(x, base + inner_off(d.ishape, d.istride, d.irank, j));
+        acc = red_merge(kind, acc, red_pre(f, v, ex.e));
+      }
+    }
+    acc = wave_merge(kind, acc);
+    if (group == 256) {
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+      __syncthreads();
+      acc = red_merge(kind, red_merge(kind, red[0], red[1]), red_merge(kind, red[2], red[3]));
+    }
+    if (live && lane == 0) {
+      if (segs > 1) partial[g] = acc;
+      else stv<Z, double>(z, t, red_post(f, acc, (double)d.tad_len, ex.e));
+    }
+  }
+}
+
+template <typename Z>
+__global__ void reduce_finish_kernel(const double* __restrict__ partial, Z* __restrict__ z, int64_t num_tads, int segs,
+                                     int64_t tad_len, int f, Extra ex) {
+  const int kind = red_kind(f);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < num_tads; t += (int64_t)gridDim.x * blockDim.x) {
+    double acc = red_init(kind);
+    for (int s = 0; s < segs; ++s) acc = red_merge(kind, acc, partial[t * segs + s]);
+    stv<Z, double>(z, t, red_post(f, acc, (double)tad_len, ex.e));
+  }
+}
+
+// reduce3 / summarystats / indexreduce: one 256-thread block per TAD (three running values)
+struct Tri {
+  double a, b, c;
+};
+__device__ __forceinline__ Tri tri_merge(int f, Tri p, Tri q) {
+  if (f == RS_VAR || f == RS_STD) {           // Welford/Chan merge of (n, mean, M2)
+    if (q.a == 0.0) return p;
+    if (p.a == 0.0) return q;
+    double n = p.a + q.a, dl = q.b - p.b;
+    return Tri{n, p.b + dl * q.a / n, p.c + q.c + dl * dl * p.a * q.a / n};
+  }
+  if (f >= RI_MAX) {                          // (value, index): keep better value, ties -> lower index
+    bool take_q;
+    if (q.b < 0.0) take_q = false;
+    else if (p.b < 0.0) take_q = true;
+    else if (f == RI_FIRST) take_q = q.b < p.b;
+    else if (f == RI_LAST) take_q = q.b > p.b;
+    else if (f == RI_MAX || f == RI_AMAX) take_q = q.a > p.a || (q.a == p.a && q.b < p.b);
+    else take_q = q.a < p.a || (q.a == p.a && q.b < p.b);
+    return take_q ? q : p;
+  }
+  return Tri{p.a + q.a, p.b + q.b, p.c + q.c};
+}
+__device__ __forceinline__ Tri tri_shfl(Tri v, int o) {
+  return Tri{__shfl_xor(v.a, o, 64), __shfl_xor(v.b, o, 64), __shfl_xor(v.c, o, 64)};
+}
+
+template <typename T, typename Z>
+__global__ __launch_bounds__(256) void reduce_tri_kernel(const T* __restrict__ x, const T* __restrict__ y, Z* __restrict__ z,
+                                                         TadDesc d, int f, Extra ex) {
+  __shared__ Tri red[4];
+  for (int64_t t = blockIdx.x; t < d.num_tads; t += gridDim.x) {
+    const int64_t bx = tad_base(d.oshape, d.ostride, d.orank, t);
+    const int64_t by = y ? tad_base(d.oshape, d.oystride, d.orank, t) : 0;
+    Tri acc = (f >= RI_MAX) ? Tri{0.0, -1.0, 0.0} : Tri{0.0, 0.0, 0.0};
+    for (int64_t j = threadIdx.x; j < d.tad_len; j += 256) {
+      double a = (double)ldv<T>(x, bx + inner_off(d.ishape, d.istride, d.irank, j));
+      double b = y ? (double)ldv<T>(y, by + inner_off(d.ishape, d.iystride, d.irank, j)) : 0.0;
+      Tri v;
+      switch (f) {
+        case R3_MANHATTAN: v = Tri{fabs(a - b), 0, 0}; break;
+        case R3_EUCLID: v = Tri{(a - b) * (a - b), 0, 0}; break;
+        case R3_COSSIM: case R3_COSDIST: v = Tri{a * b, a * a, b * b}; break;
+        case R3_DOT: v = Tri{a * b, 0, 0}; break;
+        case R3_EQEPS: v = Tri{fabs(a - b) > (ex.e[0] > 0 ? ex.e[0] : 1e-5) ? 1.0 : 0.0, 0, 0}; break;
+        case R3_JACCARD: v = Tri{fmin(a, b), fmax(a, b), 0}; break;
+        case R3_HAMMING: v = Tri{a != b ? 1.0 : 0.0, 0, 0}; break;
+        case RS_VAR: case RS_STD: v = Tri{1.0, a, 0.0}; break;
+        case RI_MAX: case RI_MIN: v = Tri{a, (double)j, 0}; break;
+        case RI_AMAX: case RI_AMIN: v = Tri{fabs(a), (double)j, 0}; break;
+        default: v = Tri{a, match_cond<double>(a, ex.e[0], ex.e[1], (int)ex.e[2]) ? (double)j : -1.0, 0}; break;   // FIRST/LAST
+      }
+      acc = tri_merge(f, acc, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc = tri_merge(f, acc, tri_shfl(acc, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      acc = tri_merge(f, tri_merge(f, red[0], red[1]), tri_merge(f, red[2], red[3]));
+      double r;
+      switch (f) {
+        case R3_EUCLID: r = sqrt(acc.a); break;
+        case R3_COSSIM: r = acc.a / (sqrt(acc.b) * sqrt(acc.c)); break;
+        case R3_COSDIST: r = 1.0 - acc.a / (sqrt(acc.b) * sqrt(acc.c)); break;
+        case R3_JACCARD: r = acc.b != 0.0 ? 1.0 - acc.a / acc.b : 0.0; break;
+        case R3_HAMMING: r = acc.a / (double)d.tad_len; break;
+        case RS_VAR: case RS_STD: {
+          double den = ex.e[0] != 0.0 ? acc.a - 1.0 : acc.a;     // e[0] = biasCorrected
+          double var = den > 0.0 ? acc.c / den : 0.0;
+          r = f == RS_STD ? sqrt(var) : var;
+        } break;
+        case RI_MAX: case RI_MIN: case RI_AMAX: case RI_AMIN: case RI_FIRST: case RI_LAST: r = acc.b; break;
+        default: r = acc.a;
+      }
+      stv<Z, double>(z, t, r);
+    }
+  }
+}
+
+// ---- C API ------------------------------------------------------------------------------------------
+// dtype: 0 f32, 1 bf16, 2 f64, 3 i32, 4 i64.  zkind: 0 = same as input, 1 = uint8 (bool), 2 = int64, 3 = f32, 4 = f64
+#define DISPATCH_T(dtype, CALL)                      \
+  switch (dtype) {                                   \
+    case 0: { typedef float T; CALL; } break;        \
+    case 1: { typedef bf16_t T; CALL; } break;       \
+    case 2: { typedef double T; CALL; } break;       \
+    case 3: { typedef int32_t T; CALL; } break;      \
+    case 4: { typedef int64_t T; CALL; } break;      \
+    default: return 1;                               \
+  }
+
+DL4J_API int dl4j_legacy_pairwise(int f, const void* x, const void* y, void* z, int64_t n, const Strides3* s, const double* extra,
+                                  int use_scalar, double scalar, int dtype, int zbool, hipStream_t st) {
+  if (n <= 0) return 0;
+  Extra ex{{extra ? extra[0] : 0, extra ? extra[1] : 0, extra ? extra[2] : 0, extra ? extra[3] : 0}};
+  int g = grid_for(n, 256 * 4);
+  if (zbool) {
+    DISPATCH_T(dtype, (pairwise_kernel<T, uint8_t><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (uint8_t*)z, n, f, *s, ex, use_scalar, scalar)))
+  } else {
+    DISPATCH_T(dtype, (pairwise_kernel<T, T><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (T*)z, n, f, *s, ex, use_scalar, scalar)))
+  }
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_legacy_transform(int f, const void* x, void* z, int64_t n, const Strides3* s, const double* extra, int dtype,
+                                   int zbool, hipStream_t st) {
+  if (n <= 0) return 0;
+  Extra ex{{extra ? extra[0] : 0, extra ? extra[1] : 0, extra ? extra[2] : 0, extra ? extra[3] : 0}};
+  int g = grid_for(n, 256 * 4);
+  if (zbool) {
+    DISPATCH_T(dtype, (transform_kernel<T, uint8_t><<<g, 256, 0, st>>>((const T*)x, (uint8_t*)z, n, f, *s, ex)))
+  } else {
+    DISPATCH_T(dtype, (transform_kernel<T, T><<<g, 256, 0, st>>>((const T*)x, (T*)z, n, f, *s, ex)))
+  }
+  DL4J_RET_LAST();
+}
+
+DL4J_API int64_t dl4j_legacy_reduce_segs(int64_t num_tads, int64_t tad_len) {
+  if (num_tads >= 512 || tad_len < (1 << 16)) return 1;
+  int64_t want = 1024 / num_tads;
+  int64_t maxs = tad_len / (1 << 13);
+  int64_t s = want < maxs ? want : maxs;
+  return s < 1 ? 1 : s;
+}
+
+template <typename T, typename Z>
+static int run_reduce(const void* x, void* z, double* partial, const TadDesc& d, int f, const Extra& ex, hipStream_t st) {
+  int64_t segs = dl4j_legacy_reduce_segs(d.num_tads, d.tad_len);
+  if (segs > 1 && !partial) segs = 1;
+  int group = d.tad_len <= 512 ? 64 : 256;
+  int64_t groups = d.num_tads * segs;
+  int per_block = 256 / group;
+  int g = grid_for((groups + per_block - 1) / per_block, 1);
+  reduce_kernel<T, Z><<<g, 256, 0, st>>>((const T*)x, (Z*)z, partial, d, f, ex, group, (int)segs);
+  if (segs > 1)
+    reduce_finish_kernel<Z><<<grid_for(d.num_tads, 256), 256, 0, st>>>(partial, (Z*)z, d.num_tads, (int)segs, d.tad_len, f, ex);
+  return (int)hipGetLastError();
+}
+
+// zkind: 0 same dtype as x, 1 uint8, 2 int64, 3 f32, 4 f64.  partial: >= num_tads*segs doubles (or null)
+DL4J_API int dl4j_legacy_reduce(int f, const void* x, void* z, double* partial, const TadDesc* d, const double* extra, int dtype,
+                                int zkind, hipStream_t st) {
+  if (d->num_tads <= 0) return 0;
+  Extra ex{{extra ? extra[0] : 0, extra ? extra[1] : 0, extra ? extra[2] : 0, extra ? extra[3] : 0}};
+  switch (zkind) {
+    case 0: DISPATCH_T(dtype, return (run_reduce<T, T>(x, z, partial, *d, f, ex, st))) break;
+    case 1: DISPATCH_T(dtype, return (run_reduce<T, uint8_t>(x, z, partial, *d, f, ex, st))) break;
+    case 2: DISPATCH_T(dtype, return (run_reduce<T, int64_t>(x, z, partial, *d, f, ex, st))) break;
+    case 3: DISPATCH_T(dtype, return (run_reduce<T, float>(x, z, partial, *d, f, ex, st))) break;
+    case 4: DISPATCH_T(dtype, return (run_reduce<T, double>(x, z, partial, *d, f, ex, st))) break;
+  }
+  return 1;
+}
+
+DL4J_API int dl4j_legacy_reduce_tri(int f, const void* x, const void* y, void* z, const TadDesc* d, const double* extra, int dtype,
+                                    int zkind, hipStream_t st) {
+  if (d->num_tads <= 0) return 0;
+  Extra ex{{extra ? extra[0] : 0, extra ? extra[1] : 0, extra ? extra[2] : 0, extra ? extra[3] : 0}};
+  int g = grid_for(d->num_tads, 1);
+  switch (zkind) {
+    case 0: DISPATCH_T(dtype, (reduce_tri_kernel<T, T><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (T*)z, *d, f, ex))) break;
+    case 2: DISPATCH_T(dtype, (reduce_tri_kernel<T, int64_t><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (int64_t*)z, *d, f, ex))) break;
+    case 3: DISPATCH_T(dtype, (reduce_tri_kernel<T, float><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (float*)z, *d, f, ex))) break;
+    case 4: DISPATCH_T(dtype, (reduce_tri_kernel<T, double><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (double*)z, *d, f, ex))) break;
+    default: return 1;
+  }
+  DL4J_RET_LAST();
+}

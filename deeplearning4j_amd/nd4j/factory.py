@@ -1,0 +1,573 @@
+"""``Nd4j`` static factory (reference: nd4j-api linalg/factory/Nd4j.java, ~7k LoC).
+
+Backend boot: the reference resolves ~20 backend roles reflectively from a properties file
+(Nd4j.initWithBackend :5210-5345). Here there is exactly one backend — MI355X through
+PyTorch-ROCm + the in-tree HIP library — so the roles are plain module-level singletons:
+executioner (nd4j/ops/legacy.py + ops/custom.py), workspace manager (workspace.py), memory manager,
+affinity manager (one process per GPU: the affinity is LOCAL_RANK), RNG (rng.py), compressor
+(compression.py).
+"""
+from __future__ import annotations
+
+import ctypes
+import io
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ..native import lib as L
+from . import rng as _rng
+from . import serde
+from .ndarray import DataType, INDArray, NDArrayIndex, _unwrap
+from .ops import legacy as LG
+
+
+class _State:
+    dtype = torch.float32
+    device = None
+    order = "c"
+
+
+def _dev(device=None):
+    if device is not None:
+        return torch.device(device)
+    if _State.device is None:
+        _State.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    return _State.device
+
+
+def _shape(args):
+    if len(args) == 1 and isinstance(args[0], (list, tuple, torch.Size)):
+        return [int(s) for s in args[0]]
+    return [int(s) for s in args]
+
+
+class AffinityManager:
+    """One process per GPU: the device of the current process is fixed at launch (LOCAL_RANK).
+    (reference: nd4j-cuda CudaAffinityManager.java — round-robins JVM threads across devices)."""
+
+    def getDeviceForCurrentThread(self):
+        return torch.cuda.current_device() if torch.cuda.is_available() else 0
+
+    def getNumberOfDevices(self):
+        return torch.cuda.device_count() if torch.cuda.is_available() else 1
+
+    def unsafeSetDevice(self, d):
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(d))
+            _State.device = torch.device("cuda", int(d))
+
+    attachThreadToDevice = lambda self, thread, d: self.unsafeSetDevice(d)
+
+    def replicateToDevice(self, d, arr: INDArray):
+        return INDArray(arr.tensor().to(torch.device("cuda", int(d))) if torch.cuda.is_available() else arr.tensor().clone(),
+                        arr.ordering())
+
+    def ensureLocation(self, arr, location="DEVICE"):
+        return arr
+
+    def isCrossDeviceAccessSupported(self):
+        if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+            return False
+        return bool(torch.cuda.can_device_access_peer(0, 1))
+
+    def allowCrossDeviceAccess(self, b):
+        pass
+
+    def getDeviceForArray(self, arr):
+        d = arr.tensor().device
+        return d.index if d.type == "cuda" else -1
+
+
+class MemoryManager:
+    """(reference: CudaMemoryManager.java / BasicMemoryManager) — allocation is torch's caching allocator."""
+
+    def __init__(self):
+        self._periodicGc = False
+
+    def allocate(self, nbytes, kind="DEVICE", initialize=True):
+        dev = _dev() if kind == "DEVICE" else torch.device("cpu")
+        t = torch.zeros(nbytes, dtype=torch.uint8, device=dev) if initialize else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if kind == "HOST" and torch.cuda.is_available():
+            t = t.pin_memory()
+        return t
+
+    def collect(self, *arrays):
+        for a in arrays:
+            a.close()
+
+    def purgeCaches(self):
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+
+    invokeGc = purgeCaches
+
+    def memcpy(self, dst, src):
+        _unwrap(dst).copy_(_unwrap(src))
+
+    def togglePeriodicGc(self, b):
+        self._periodicGc = b
+
+    def getCurrentWorkspace(self):
+        from .workspace import getWorkspaceManager
+        return getWorkspaceManager().getCurrentWorkspace()
+
+    def allocatedMemory(self, device=0):
+        return torch.cuda.memory_allocated(device) if torch.cuda.is_available() else 0
+
+    def getBandwidthUse(self):
+        return {}
+
+
+_AFF, _MEM = AffinityManager(), MemoryManager()
+
+
+class Nd4j:
+    EPS_THRESHOLD = 1e-5
+
+    # ---- configuration
+    @staticmethod
+    def setDefaultDataTypes(dtype, floatDtype=None):
+        _State.dtype = DataType.to_torch(floatDtype or dtype)
+
+    @staticmethod
+    def dataType():
+        return DataType.from_torch(_State.dtype)
+
+    defaultFloatingPointType = dataType
+
+    @staticmethod
+    def setDevice(device):
+        _State.device = torch.device(device)
+
+    @staticmethod
+    def order():
+        return _State.order
+
+    # ---- role singletons
+    @staticmethod
+    def getExecutioner():
+        from .ops.custom import OpExecutioner
+        return OpExecutioner.getInstance()
+
+    @staticmethod
+    def getAffinityManager():
+        return _AFF
+
+    @staticmethod
+    def getMemoryManager():
+        return _MEM
+
+    @staticmethod
+    def getWorkspaceManager():
+        from .workspace import getWorkspaceManager
+        return getWorkspaceManager()
+
+    @staticmethod
+    def getRandom():
+        return _rng.getRandom()
+
+    @staticmethod
+    def getRandomFactory():
+        return _rng
+
+    @staticmethod
+    def getCompressor():
+        from .compression import BasicNDArrayCompressor
+        return BasicNDArrayCompressor.getInstance()
+
+    @staticmethod
+    def getEnvironment():
+        from .environment import Environment
+        return Environment.getInstance()
+
+    @staticmethod
+    def getBackend():
+        return "gfx950-hip" if torch.cuda.is_available() else "cpu-torch"
+
+    @staticmethod
+    def exec(op, *a, **k):
+        return Nd4j.getExecutioner().exec(op, *a, **k)
+
+    # ---- creation
+    @staticmethod
+    def create(*args, dtype=None, order=None, device=None):
+        """create(shape...), create(data), create(data, shape), create(dtype, shape...)"""
+        order = order or _State.order
+        if args and isinstance(args[0], str):
+            dtype, args = args[0], args[1:]
+        td = DataType.to_torch(dtype) if dtype is not None else None
+        first = args[0] if args else []
+        two_lists = len(args) == 2 and isinstance(args[1], (list, tuple)) and isinstance(first, (list, tuple))
+        is_data = isinstance(first, (np.ndarray, torch.Tensor, INDArray)) or two_lists or (
+            isinstance(first, (list, tuple)) and len(first) > 0 and any(isinstance(v, (list, tuple, float)) for v in first))
+        if is_data:
+            data = _unwrap(first)
+            from_py = not isinstance(data, (torch.Tensor, np.ndarray))
+            t = data if isinstance(data, torch.Tensor) else torch.as_tensor(np.asarray(data))
+            if td is None:
+                td = _State.dtype if (t.is_floating_point() and (from_py or t.dtype == torch.float64)) else t.dtype
+            t = t.to(device=_dev(device), dtype=td, copy=True)
+            arr = INDArray(t, "c")
+            if len(args) > 1:
+                arr = arr.ravel().reshape(order, _shape(args[1:]))
+            return arr
+        shape = _shape(args)
+        t = torch.zeros(shape, dtype=td or _State.dtype, device=_dev(device))
+        return INDArray(t, order)
+
+    @staticmethod
+    def createUninitialized(*shape, dtype=None, order=None, device=None):
+        return INDArray(torch.empty(_shape(shape), dtype=DataType.to_torch(dtype) if dtype else _State.dtype, device=_dev(device)),
+                        order or _State.order)
+
+    createUninitializedDetached = createUninitialized
+
+    @staticmethod
+    def createFromArray(data, dtype=None, device=None):
+        t = torch.as_tensor(np.asarray(data))
+        if dtype is not None:
+            t = t.to(DataType.to_torch(dtype))
+        elif t.dtype == torch.float64:
+            t = t.to(_State.dtype)
+        return INDArray(t.to(_dev(device)), "c")
+
+    @staticmethod
+    def fromTensor(t: torch.Tensor, order="c"):
+        return INDArray(t, order)
+
+    @staticmethod
+    def zeros(*shape, dtype=None, order=None, device=None):
+        return INDArray(torch.zeros(_shape(shape), dtype=DataType.to_torch(dtype) if dtype else _State.dtype, device=_dev(device)),
+                        order or _State.order)
+
+    @staticmethod
+    def ones(*shape, dtype=None, order=None, device=None):
+        return INDArray(torch.ones(_shape(shape), dtype=DataType.to_torch(dtype) if dtype else _State.dtype, device=_dev(device)),
+                        order or _State.order)
+
+    @staticmethod
+    def zerosLike(a):
+        return a.like()
+
+    @staticmethod
+    def onesLike(a):
+        return INDArray(torch.ones_like(a.tensor()), a.ordering())
+
+    @staticmethod
+    def valueArrayOf(shape, value, dtype=None, device=None):
+        if isinstance(shape, int):
+            shape = [shape]
+        return INDArray(torch.full(_shape([shape]), value, dtype=DataType.to_torch(dtype) if dtype else _State.dtype,
+                                   device=_dev(device)), _State.order)
+
+    @staticmethod
+    def scalar(value, dtype=None, device=None):
+        if dtype is None:
+            dtype = _State.dtype if isinstance(value, float) else (torch.bool if isinstance(value, bool) else torch.int64 if isinstance(value, int) else _State.dtype)
+        return INDArray(torch.tensor(value, dtype=DataType.to_torch(dtype), device=_dev(device)), "c")
+
+    @staticmethod
+    def empty(dtype=None, device=None):
+        return INDArray(torch.empty(0, dtype=DataType.to_torch(dtype) if dtype else _State.dtype, device=_dev(device)), "c")
+
+    @staticmethod
+    def eye(n, dtype=None, device=None):
+        return INDArray(torch.eye(int(n), dtype=DataType.to_torch(dtype) if dtype else _State.dtype, device=_dev(device)), "c")
+
+    @staticmethod
+    def linspace(lower, upper, num, dtype=None, device=None):
+        return INDArray(torch.linspace(lower, upper, int(num), dtype=DataType.to_torch(dtype) if dtype else _State.dtype,
+                                       device=_dev(device)), "c")
+
+    @staticmethod
+    def arange(begin, end=None, step=1, dtype=None, device=None):
+        if end is None:
+            begin, end = 0, begin
+        return INDArray(torch.arange(begin, end, step, dtype=DataType.to_torch(dtype) if dtype else _State.dtype,
+                                     device=_dev(device)), "c")
+
+    # ---- random
+    @staticmethod
+    def rand(*shape, seed=None, dtype=None, device=None, rng=None):
+        r = rng or (_rng.Random(seed) if seed is not None else _rng.getRandom())
+        return INDArray(r.nextFloatArray(_shape(shape), _dev(device), DataType.to_torch(dtype) if dtype else _State.dtype), _State.order)
+
+    @staticmethod
+    def randn(*shape, seed=None, dtype=None, device=None, rng=None):
+        r = rng or (_rng.Random(seed) if seed is not None else _rng.getRandom())
+        return INDArray(r.nextGaussianArray(_shape(shape), _dev(device), DataType.to_torch(dtype) if dtype else _State.dtype), _State.order)
+
+    @staticmethod
+    def randomBernoulli(p, *shape, device=None):
+        z = torch.empty(_shape(shape), dtype=_State.dtype, device=_dev(device))
+        return INDArray(_rng.exec_random("BernoulliDistribution", None, z, None, None, [p]), _State.order)
+
+    @staticmethod
+    def randomBinomial(trials, p, *shape, device=None):
+        z = torch.empty(_shape(shape), dtype=_State.dtype, device=_dev(device))
+        return INDArray(_rng.exec_random("BinomialDistribution", None, z, None, None, [trials, p]), _State.order)
+
+    @staticmethod
+    def randomExponential(lam, *shape, device=None):
+        z = torch.empty(_shape(shape), dtype=_State.dtype, device=_dev(device))
+        return INDArray(_rng.exec_random("ExponentialDistribution", None, z, None, None, [lam]), _State.order)
+
+    @staticmethod
+    def shuffle(arr: INDArray, *dims, seed=None):
+        t = arr.tensor()
+        g = torch.Generator().manual_seed(seed if seed is not None else _rng.getRandom().nextInt())
+        d = dims[0] if dims else 0
+        # DL4J shuffles the TADs along `dims`: permute the complementary axis (rows for dims=1)
+        axis = 0 if (not dims or d != 0) else 1
+        perm = torch.randperm(t.shape[axis], generator=g).to(t.device)
+        t.copy_(t.index_select(axis, perm))
+        return arr
+
+    # ---- combination
+    @staticmethod
+    def concat(dim, *arrs):
+        arrs = arrs[0] if len(arrs) == 1 and isinstance(arrs[0], (list, tuple)) else arrs
+        return INDArray(torch.cat([_unwrap(a) for a in arrs], dim=dim), "c")
+
+    @staticmethod
+    def hstack(*arrs):
+        arrs = arrs[0] if len(arrs) == 1 and isinstance(arrs[0], (list, tuple)) else arrs
+        ts = [_unwrap(a) for a in arrs]
+        return INDArray(torch.cat(ts, dim=0 if ts[0].dim() == 1 else 1), "c")
+
+    @staticmethod
+    def vstack(*arrs):
+        arrs = arrs[0] if len(arrs) == 1 and isinstance(arrs[0], (list, tuple)) else arrs
+        ts = [_unwrap(a) for a in arrs]
+        ts = [t.unsqueeze(0) if t.dim() == 1 else t for t in ts]
+        return INDArray(torch.cat(ts, dim=0), "c")
+
+    @staticmethod
+    def stack(dim, *arrs):
+        arrs = arrs[0] if len(arrs) == 1 and isinstance(arrs[0], (list, tuple)) else arrs
+        return INDArray(torch.stack([_unwrap(a) for a in arrs], dim=dim), "c")
+
+    @staticmethod
+    def pile(*arrs):
+        return Nd4j.stack(0, *arrs)
+
+    @staticmethod
+    def tear(arr, *dims):
+        n = arr.tensorsAlongDimension(*dims)
+        return [arr.tensorAlongDimension(i, *dims).dup() for i in range(n)]
+
+    @staticmethod
+    def toFlattened(*arrs, order="c"):
+        arrs = arrs[0] if len(arrs) == 1 and isinstance(arrs[0], (list, tuple)) else arrs
+        return INDArray(torch.cat([(a if isinstance(a, INDArray) else INDArray(a)).ravel(order).tensor() for a in arrs]), "c")
+
+    @staticmethod
+    def pullRows(source: INDArray, sourceDimension, indexes, order="c"):
+        """Rows (sourceDimension=1) or columns (0) gathered by index (NativeOps pullRows :826)."""
+        t = source.tensor()
+        idx = torch.as_tensor(list(indexes), dtype=torch.int64, device=t.device)
+        if int(idx.min()) < 0 or int(idx.max()) >= t.shape[0 if sourceDimension == 1 else 1]:
+            raise IndexError("pullRows index out of range")
+        if sourceDimension != 1:
+            return INDArray(t.index_select(1, idx), order)
+        if t.is_cuda and t.is_contiguous() and t.dim() == 2:
+            z = torch.empty((idx.numel(), t.shape[1]), dtype=t.dtype, device=t.device)
+            L.check(L.hip().dl4j_pull_rows(L.ptr(t), L.ptr(idx), L.ptr(z), L.c_int64(idx.numel()), L.c_int64(t.shape[1]),
+                                           L.c_int64(t.shape[0]), L.c_int(t.element_size()), L.stream()), "pull_rows")
+            return INDArray(z, order)
+        return INDArray(t.index_select(0, idx), order)
+
+    @staticmethod
+    def diag(a):
+        return INDArray(torch.diag(_unwrap(a).reshape(-1) if _unwrap(a).dim() <= 2 and 1 in list(_unwrap(a).shape) + [1] and _unwrap(a).dim() == 1
+                                   else _unwrap(a)), "c")
+
+    @staticmethod
+    def sort(arr, dim=-1, ascending=True):
+        return INDArray(torch.sort(_unwrap(arr), dim=dim, descending=not ascending).values, "c")
+
+    @staticmethod
+    def sortWithIndices(arr, dim=-1, ascending=True):
+        v, i = torch.sort(_unwrap(arr), dim=dim, descending=not ascending)
+        return INDArray(i, "c"), INDArray(v, "c")
+
+    @staticmethod
+    def argMax(arr, *dims):
+        return arr.argMax(*dims)
+
+    @staticmethod
+    def where(cond, x, y):
+        return INDArray(torch.where(_unwrap(cond).bool(), _unwrap(x), _unwrap(y)), "c")
+
+    @staticmethod
+    def expandDims(a, dim):
+        return INDArray(_unwrap(a).unsqueeze(dim), a.ordering())
+
+    @staticmethod
+    def squeeze(a, dim):
+        return INDArray(_unwrap(a).squeeze(dim), a.ordering())
+
+    @staticmethod
+    def tile(a, *reps):
+        return INDArray(_unwrap(a).repeat(*reps), "c")
+
+    @staticmethod
+    def reverse(a):
+        return INDArray(torch.flip(_unwrap(a), dims=list(range(_unwrap(a).dim()))), "c")
+
+    # ---- BLAS
+    @staticmethod
+    def gemm(a, b, c=None, transposeA=False, transposeB=False, alpha=1.0, beta=0.0):
+        A, B = _unwrap(a), _unwrap(b)
+        A = A.t() if transposeA else A
+        B = B.t() if transposeB else B
+        if c is None:
+            return INDArray(alpha * (A @ B), "f")
+        C = _unwrap(c)
+        if beta == 0.0:
+            torch.matmul(A, B, out=C) if C.is_contiguous() and alpha == 1.0 else C.copy_(alpha * (A @ B))
+        else:
+            C.copy_(torch.addmm(C, A, B, beta=beta, alpha=alpha))
+        return c
+
+    @staticmethod
+    def matmul(a, b, transposeA=False, transposeB=False):
+        return a.mmul(b, None, transposeA, transposeB)
+
+    @staticmethod
+    def tensorMmul(a, b, axes):
+        return INDArray(torch.tensordot(_unwrap(a), _unwrap(b), dims=(list(axes[0]), list(axes[1]))), "c")
+
+    @staticmethod
+    def dot(a, b):
+        return float(torch.dot(_unwrap(a).reshape(-1), _unwrap(b).reshape(-1)))
+
+    @staticmethod
+    def getBlasWrapper():
+        return Nd4j
+
+    # ---- multi-array DP primitives (NativeOps average / accumulate)
+    @staticmethod
+    def _multi_reduce(arrays, target, scale, propagate):
+        ts = [_unwrap(a) for a in arrays]
+        n = ts[0].numel()
+        if any(t.numel() != n for t in ts):
+            raise ValueError("arrays must have equal lengths")
+        tgt = _unwrap(target) if target is not None else None
+        gpu = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts) and (
+            tgt is None or (tgt.is_cuda and tgt.is_contiguous() and tgt.dtype == torch.float32 and tgt.data_ptr() % 16 == 0))
+        if gpu and len({t.device for t in ts}) == 1:
+            table = torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=ts[0].device)
+            L.check(L.hip().dl4j_multi_reduce(L.ptr(table), L.c_int(len(ts)), L.c_int64(n), L.ptr(tgt), L.c_float(scale),
+                                              L.c_int(int(propagate)), L.stream()), "multi_reduce")
+        else:
+            # cross-device / host: reduce on the first array's device (host-side averaging fallback of
+            # JCublasNDArrayFactory.java:712-768); cross-GPU production traffic uses RCCL instead (parallel/comm.py)
+            acc = sum(t.to(ts[0].device).reshape(-1).double() for t in ts) * scale
+            if tgt is not None:
+                tgt.reshape(-1).copy_(acc.to(tgt.dtype))
+            if propagate:
+                for t in ts:
+                    t.reshape(-1).copy_(acc.to(t.device, t.dtype))
+        return target
+
+    @staticmethod
+    def averageAndPropagate(arrays, target=None):
+        arrays = list(arrays)
+        Nd4j._multi_reduce(arrays, target, 1.0 / len(arrays), True)
+        return target if target is not None else arrays[0]
+
+    @staticmethod
+    def average(target, arrays):
+        return Nd4j._multi_reduce(list(arrays), target, 1.0 / len(arrays), False)
+
+    @staticmethod
+    def accumulate(target, *arrays):
+        arrays = arrays[0] if len(arrays) == 1 and isinstance(arrays[0], (list, tuple)) else arrays
+        return Nd4j._multi_reduce(list(arrays), target, 1.0, False)
+
+    # ---- serde
+    @staticmethod
+    def write(arr: INDArray, stream):
+        serde.write_array(arr.tensor(), stream, arr.ordering())
+
+    @staticmethod
+    def read(stream) -> INDArray:
+        return INDArray(serde.read_array(stream).to(_dev()), "c")
+
+    @staticmethod
+    def toByteArray(arr):
+        return serde.to_bytes(arr.tensor(), arr.ordering())
+
+    @staticmethod
+    def fromByteArray(b):
+        return INDArray(serde.from_bytes(b).to(_dev()), "c")
+
+    @staticmethod
+    def saveBinary(arr, path):
+        with open(path, "wb") as f:
+            Nd4j.write(arr, f)
+
+    @staticmethod
+    def readBinary(path):
+        with open(path, "rb") as f:
+            return Nd4j.read(io.BytesIO(f.read()))
+
+    _NPY = {torch.float32: (b"<f4", 4), torch.float64: (b"<f8", 8), torch.float16: (b"<f2", 2), torch.int32: (b"<i4", 4),
+            torch.int64: (b"<i8", 8), torch.int16: (b"<i2", 2), torch.int8: (b"|i1", 1), torch.uint8: (b"|u1", 1),
+            torch.bool: (b"|b1", 1)}
+
+    @staticmethod
+    def writeAsNumpy(arr: INDArray, path):
+        """.npy through the native writer (rt_buffer.cpp; reference cnpy, NativeOps.h:127 saveNpy)."""
+        t = arr.tensor().detach().cpu().contiguous()
+        if t.dtype == torch.bfloat16:
+            t = t.float()
+        descr, es = Nd4j._NPY[t.dtype]
+        shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+        L.rt_check(L.rt().nd4j_npy_save(str(path).encode(), t.data_ptr(), shape, t.dim(), descr, es, 0), "npy save")
+
+    @staticmethod
+    def createFromNpyFile(path, device=None) -> INDArray:
+        rt = L.rt()
+        shape = (ctypes.c_int64 * 32)()
+        rank, fortran = ctypes.c_int(0), ctypes.c_int(0)
+        descr = ctypes.create_string_buffer(8)
+        off = rt.nd4j_npy_header(str(path).encode(), shape, ctypes.byref(rank), descr, ctypes.byref(fortran))
+        if off < 0:
+            L.rt_check(int(-off), "npy header")
+        d = descr.value.decode()
+        rev = {v[0].decode(): k for k, v in Nd4j._NPY.items()}
+        if d.startswith(">"):
+            raise ValueError("big-endian npy not supported")
+        key = d if d in rev else ("|" + d[1:] if ("|" + d[1:]) in rev else "<" + d[1:])
+        dt = rev[key]
+        shp = [int(shape[i]) for i in range(rank.value)]
+        t = torch.empty(shp[::-1] if fortran.value else shp, dtype=dt)
+        L.rt_check(rt.nd4j_npy_read_data(str(path).encode(), off, t.data_ptr(), t.numel() * t.element_size()), "npy read")
+        if fortran.value:
+            t = t.permute(*reversed(range(t.dim())))
+        return INDArray(t.to(_dev(device)), "f" if fortran.value else "c")
+
+    readNpy = createFromNpyFile
+
+    # ---- misc
+    @staticmethod
+    def getStrides(shape, order="c"):
+        rt = L.rt()
+        r = len(shape)
+        out = (ctypes.c_int64 * (2 * r + 4))()
+        L.rt_check(rt.nd4j_shape_buffer(r, (ctypes.c_int64 * max(r, 1))(*shape), order.encode(), 0, out), "getStrides")
+        return list(out)[1 + r:1 + 2 * r]
+
+    @staticmethod
+    def sizeOfDataType(dtype=None):
+        return torch.empty(0, dtype=DataType.to_torch(dtype) if dtype else _State.dtype).element_size()
+
+    @staticmethod
+    def clearNans(arr):
+        arr.tensor().nan_to_num_(nan=0.0)
+        return arr

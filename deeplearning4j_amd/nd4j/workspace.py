@@ -1,0 +1,351 @@
+"""Scoped arena workspaces (reference: nd4j-api linalg/api/memory/** — MemoryWorkspace,
+WorkspaceConfiguration, Nd4jWorkspace.alloc :348-459 / initializeWorkspace :466-525,
+MemoryWorkspaceManager; CUDA impl nd4j-cuda CudaWorkspace.java; ADR 0024).
+
+MI355X design: the arena bookkeeping (bump pointer, learning policy, spill accounting, cycles,
+generations) is native (rt_workspace.cpp); the arena *memory* is a single uint8 slab taken from the
+torch caching allocator (device) or pinned host memory, so workspaces and ordinary tensors share one
+allocator and 288 GB of HBM is never fragmented between two pools. ``alloc`` returns a typed view
+of the slab; spilled requests become ordinary allocations that die at scope exit.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Dict, List, Optional
+
+import torch
+
+from ..native import lib as L
+
+
+class AllocationPolicy:
+    STRICT, OVERALLOCATE = "STRICT", "OVERALLOCATE"
+
+
+class LearningPolicy:
+    NONE, FIRST_LOOP, OVER_TIME = "NONE", "FIRST_LOOP", "OVER_TIME"
+
+
+class SpillPolicy:
+    EXTERNAL, REALLOCATE, FAIL = "EXTERNAL", "REALLOCATE", "FAIL"
+
+
+class ResetPolicy:
+    BLOCK_LEFT, ENDOFBUFFER_REACHED = "BLOCK_LEFT", "ENDOFBUFFER_REACHED"
+
+
+class MirroringPolicy:
+    FULL, HOST_ONLY = "FULL", "HOST_ONLY"
+
+
+class LocationPolicy:
+    RAM, MMAP = "RAM", "MMAP"
+
+
+class MemoryKind:
+    HOST, DEVICE = 0, 1
+
+
+class WorkspaceConfiguration:
+    def __init__(self, initialSize=0, maxSize=0, minSize=0, overallocationLimit=0.0, cyclesBeforeInitialization=0,
+                 policyAllocation=AllocationPolicy.OVERALLOCATE, policyLearning=LearningPolicy.FIRST_LOOP,
+                 policySpill=SpillPolicy.EXTERNAL, policyReset=ResetPolicy.BLOCK_LEFT, policyMirroring=MirroringPolicy.FULL,
+                 policyLocation=LocationPolicy.RAM, tempFilePath=None):
+        self.initialSize, self.maxSize, self.minSize = int(initialSize), int(maxSize), int(minSize)
+        self.overallocationLimit = float(overallocationLimit)
+        self.cyclesBeforeInitialization = int(cyclesBeforeInitialization)
+        self.policyAllocation, self.policyLearning, self.policySpill = policyAllocation, policyLearning, policySpill
+        self.policyReset, self.policyMirroring, self.policyLocation = policyReset, policyMirroring, policyLocation
+        self.tempFilePath = tempFilePath
+
+    class Builder:
+        def __init__(self):
+            self._kw = {}
+
+        def __getattr__(self, name):
+            def setter(v):
+                self._kw[name] = v
+                return self
+            return setter
+
+        def build(self):
+            return WorkspaceConfiguration(**self._kw)
+
+    @staticmethod
+    def builder():
+        return WorkspaceConfiguration.Builder()
+
+
+_LEARN = {LearningPolicy.NONE: 0, LearningPolicy.FIRST_LOOP: 1, LearningPolicy.OVER_TIME: 2}
+_TLS = threading.local()
+
+
+def _stack() -> List["MemoryWorkspace"]:
+    if not hasattr(_TLS, "stack"):
+        _TLS.stack = []
+    return _TLS.stack
+
+
+class MemoryWorkspace:
+    def __init__(self, conf: WorkspaceConfiguration, wsId: str, device=None):
+        self.conf, self.id = conf, wsId
+        self.device = torch.device(device) if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+        self._rt = L.rt()
+        over = conf.overallocationLimit if conf.policyAllocation == AllocationPolicy.OVERALLOCATE else 0.0
+        self._h = self._rt.ws_create(_LEARN[conf.policyLearning], over, conf.cyclesBeforeInitialization)
+        self._slab: Dict[int, Optional[torch.Tensor]] = {0: None, 1: None}
+        self._spilled: List[torch.Tensor] = []
+        self._open = 0
+        self._borrowed = False
+        if conf.initialSize > 0:
+            self._bind(MemoryKind.DEVICE if self.device.type == "cuda" else MemoryKind.HOST, conf.initialSize)
+
+    def __del__(self):
+        try:
+            self._rt.ws_destroy(self._h)
+        except Exception:
+            pass
+
+    # -- arena management
+    def _bind(self, kind, nbytes):
+        if self.conf.maxSize > 0:
+            nbytes = min(nbytes, self.conf.maxSize)
+        nbytes = max(nbytes, self.conf.minSize)
+        nbytes = (nbytes + 255) // 256 * 256
+        if kind == MemoryKind.DEVICE:
+            raw = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        else:
+            raw = torch.empty(nbytes + 256, dtype=torch.uint8)
+            if torch.cuda.is_available():
+                raw = raw.pin_memory()
+        skew = (-raw.data_ptr()) % 256              # 256-byte aligned arena base (host malloc gives 64)
+        slab = raw[skew:skew + nbytes]
+        self._slab[kind] = slab
+        L.rt_check(self._rt.ws_bind(self._h, kind, ctypes.c_uint64(slab.data_ptr()), nbytes), "ws_bind")
+
+    def _stats(self, kind):
+        out = (ctypes.c_int64 * 9)()
+        self._rt.ws_stats(self._h, kind, out)
+        keys = ("capacity", "offset", "peakCycle", "peakAll", "spilledCycle", "spilledTotal", "cycles", "generation", "depth")
+        return dict(zip(keys, out))
+
+    def _kind(self, device=None):
+        d = self.device if device is None else torch.device(device)
+        return MemoryKind.DEVICE if d.type == "cuda" else MemoryKind.HOST
+
+    # -- scope protocol
+    def notifyScopeEntered(self):
+        self._rt.ws_scope_in(self._h)
+        self._open += 1
+        _stack().append(self)
+        return self
+
+    def notifyScopeLeft(self):
+        wh, wd = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._rt.ws_scope_out(self._h, ctypes.byref(wh), ctypes.byref(wd))
+        self._open -= 1
+        st = _stack()
+        if st and st[-1] is self:
+            st.pop()
+        if self._open == 0:
+            self._spilled.clear()       # spilled allocations are purged at BLOCK_LEFT
+            if wh.value > 0:
+                self._bind(MemoryKind.HOST, wh.value)
+            if wd.value > 0:
+                self._bind(MemoryKind.DEVICE, wd.value)
+        return self
+
+    def notifyScopeBorrowed(self):
+        self._borrowed = True
+        _stack().append(self)
+        return self
+
+    __enter__ = notifyScopeEntered
+
+    def __exit__(self, *exc):
+        self.notifyScopeLeft()
+        return False
+
+    close = notifyScopeLeft
+
+    def isScopeActive(self):
+        return self._open > 0
+
+    def tagOutOfScopeUse(self):
+        return _ScopeOut()
+
+    # -- allocation
+    def alloc(self, shape, dtype=torch.float32, initialize=False, device=None) -> torch.Tensor:
+        kind = self._kind(device)
+        n = 1
+        for s in shape:
+            n *= int(s)
+        es = torch.empty(0, dtype=dtype).element_size()
+        nbytes = max(n * es, 1)
+        if self.conf.policyReset == ResetPolicy.ENDOFBUFFER_REACHED and self._slab[kind] is not None:
+            # cyclic workspace: wrap around to the start of the arena (AsyncDataSetIterator's buffer mode)
+            st = self._stats(kind)
+            need = (nbytes + 255) // 256 * 256
+            if st["offset"] + need > st["capacity"] and need <= st["capacity"]:
+                self._rt.ws_rewind(self._h, kind)
+        addr = self._rt.ws_alloc(self._h, kind, nbytes)
+        if addr == 0:
+            if self.conf.policySpill == SpillPolicy.FAIL:
+                raise MemoryError("workspace '%s': %d bytes do not fit (capacity %d) and spill policy is FAIL" % (
+                    self.id, nbytes, self._stats(kind)["capacity"]))
+            dev = self.device if kind == MemoryKind.DEVICE else torch.device("cpu")
+            t = torch.zeros(shape, dtype=dtype, device=dev) if initialize else torch.empty(shape, dtype=dtype, device=dev)
+            self._spilled.append(t)
+            return t
+        slab = self._slab[kind]
+        off = addr - slab.data_ptr()
+        t = slab[off:off + n * es].view(dtype).reshape(list(shape))
+        if initialize:
+            t.zero_()
+        return t
+
+    def create(self, *shape, dtype=torch.float32, order="c"):
+        from .ndarray import INDArray
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (list, tuple)) else shape
+        a = INDArray(self.alloc(shape, dtype, True), order)
+        a._ws = self.id
+        return a
+
+    # -- introspection (MemoryWorkspace getters)
+    def getId(self):
+        return self.id
+
+    def getCurrentSize(self, kind=None):
+        return self._stats(self._kind() if kind is None else kind)["capacity"]
+
+    def getCurrentOffset(self, kind=None):
+        return self._stats(self._kind() if kind is None else kind)["offset"]
+
+    def getSpilledSize(self, kind=None):
+        return self._stats(self._kind() if kind is None else kind)["spilledTotal"]
+
+    def getMaxCycleAllocations(self, kind=None):
+        return self._stats(self._kind() if kind is None else kind)["peakAll"]
+
+    def getThisCycleAllocations(self, kind=None):
+        return self._stats(self._kind() if kind is None else kind)["peakCycle"]
+
+    def getGenerationId(self):
+        return self._stats(0)["generation"]
+
+    def getCyclesCount(self):
+        return self._stats(0)["cycles"]
+
+    def destroyWorkspace(self, extended=True):
+        self._slab = {0: None, 1: None}
+        self._spilled.clear()
+        self._rt.ws_bind(self._h, 0, ctypes.c_uint64(0), 0)
+        self._rt.ws_bind(self._h, 1, ctypes.c_uint64(0), 0)
+
+    def getWorkspaceConfiguration(self):
+        return self.conf
+
+
+class _ScopeOut:
+    """scopeOutOfWorkspaces(): temporarily detach the thread from every workspace."""
+
+    def __enter__(self):
+        self._saved = list(_stack())
+        _stack().clear()
+        return self
+
+    def __exit__(self, *exc):
+        _stack().extend(self._saved)
+        return False
+
+
+class DummyWorkspace(MemoryWorkspace):
+    def __init__(self):
+        super().__init__(WorkspaceConfiguration(policyLearning=LearningPolicy.NONE), "DUMMY")
+
+    def alloc(self, shape, dtype=torch.float32, initialize=False, device=None):
+        dev = self.device if device is None else device
+        return torch.zeros(shape, dtype=dtype, device=dev) if initialize else torch.empty(shape, dtype=dtype, device=dev)
+
+
+class MemoryWorkspaceManager:
+    """Thread-local named workspaces (reference: BasicWorkspaceManager / CudaWorkspaceManager)."""
+
+    def __init__(self):
+        self._default = WorkspaceConfiguration(initialSize=0, overallocationLimit=0.3, policyLearning=LearningPolicy.FIRST_LOOP)
+
+    def _map(self) -> Dict[str, MemoryWorkspace]:
+        if not hasattr(_TLS, "ws"):
+            _TLS.ws = {}
+        return _TLS.ws
+
+    def setDefaultWorkspaceConfiguration(self, conf):
+        self._default = conf
+
+    def createNewWorkspace(self, conf=None, wsId=None, device=None):
+        ws = MemoryWorkspace(conf or self._default, wsId or "WS_%d" % len(self._map()), device)
+        self._map()[ws.id] = ws
+        return ws
+
+    def getWorkspaceForCurrentThread(self, conf=None, wsId="DEFAULT", device=None):
+        m = self._map()
+        if wsId not in m:
+            m[wsId] = MemoryWorkspace(conf or self._default, wsId, device)
+        return m[wsId]
+
+    def getAndActivateWorkspace(self, conf=None, wsId="DEFAULT", device=None):
+        return self.getWorkspaceForCurrentThread(conf, wsId, device).notifyScopeEntered()
+
+    def checkIfWorkspaceExists(self, wsId):
+        return wsId in self._map()
+
+    def checkIfWorkspaceExistsAndActive(self, wsId):
+        return wsId in self._map() and self._map()[wsId].isScopeActive()
+
+    def getCurrentWorkspace(self):
+        st = _stack()
+        return st[-1] if st else None
+
+    def anyWorkspaceActiveForCurrentThread(self):
+        return bool(_stack())
+
+    def getAllWorkspacesIdsForCurrentThread(self):
+        return list(self._map().keys())
+
+    def getAllWorkspacesForCurrentThread(self):
+        return list(self._map().values())
+
+    def destroyWorkspace(self, ws=None):
+        ws = ws or self.getCurrentWorkspace()
+        if ws is not None:
+            ws.destroyWorkspace()
+            self._map().pop(ws.id, None)
+
+    def destroyAllWorkspacesForCurrentThread(self):
+        for ws in list(self._map().values()):
+            ws.destroyWorkspace()
+        self._map().clear()
+        _stack().clear()
+
+    def scopeOutOfWorkspaces(self):
+        return _ScopeOut()
+
+    def printAllocationStatisticsForCurrentThread(self):
+        lines = []
+        for ws in self._map().values():
+            for kind, nm in ((0, "host"), (1, "device")):
+                s = ws._stats(kind)
+                lines.append("%-28s %-6s size=%d peak=%d spilled=%d cycles=%d" % (ws.id, nm, s["capacity"], s["peakAll"],
+                                                                                   s["spilledTotal"], s["cycles"]))
+        out = "\n".join(lines)
+        print(out)
+        return out
+
+
+_MGR = MemoryWorkspaceManager()
+
+
+def getWorkspaceManager() -> MemoryWorkspaceManager:
+    return _MGR
