@@ -307,12 +307,22 @@ class OpExecutioner:
 
     def _run(self, name, ins, i, t, b, d, allow_helpers=True):
         _load_impls()
-        if allow_helpers and self.env.helpersAllowed():
+        if allow_helpers and self.env.helpersAllowed() and not any(
+                isinstance(x, torch.Tensor) and x.requires_grad for x in ins):
             for usable, fn in _PLATFORM.get(name, ()):
                 if usable(ins, i, t, b, d):
                     return fn(ins, i, t, b, d)
         if name not in _IMPL:
-            raise NotImplementedError("custom op '%s' has no implementation in this build" % name)
+            canon = name_by_hash(op_hash(name))         # DECLARE_SYN aliases resolve to the canonical op (mmul -> matmul)
+            if canon is None or canon not in _IMPL:
+                raise NotImplementedError("custom op '%s' has no implementation in this build" % name)
+            _IMPL[name] = _IMPL[canon]
+            if canon in _PLATFORM:
+                _PLATFORM.setdefault(name, _PLATFORM[canon])
+                for usable, fn in _PLATFORM[name]:
+                    if allow_helpers and self.env.helpersAllowed() and not any(
+                            isinstance(x, torch.Tensor) and x.requires_grad for x in ins) and usable(ins, i, t, b, d):
+                        return fn(ins, i, t, b, d)
         return _IMPL[name](ins, i, t, b, d)
 
     def exec(self, op_or_name, *args, **kw):

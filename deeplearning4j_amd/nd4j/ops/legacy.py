@@ -131,6 +131,19 @@ _RED_ORDER = ["Mean", "AMean", "Norm1", "Norm2", "NormMax", "NormFrobenius", "No
 RED = {n: i for i, n in enumerate(_RED_ORDER)}
 
 MAXR = 8
+_FORCE_TORCH = [False]
+
+
+class force_torch:
+    """Context manager: run legacy ops through their ATen formulation even on GPU tensors."""
+
+    def __enter__(self):
+        self._prev = _FORCE_TORCH[0]
+        _FORCE_TORCH[0] = True
+
+    def __exit__(self, *exc):
+        _FORCE_TORCH[0] = self._prev
+        return False
 
 
 class _Strides3(ctypes.Structure):
@@ -406,6 +419,8 @@ class LegacyOpExecutioner:
     # -- helpers
     @staticmethod
     def _gpu_ok(*ts):
+        if _FORCE_TORCH[0] or any(t is not None and t.requires_grad for t in ts):
+            return False        # autograd sessions (SameDiff training) need the differentiable ATen formulation
         return L.use_hip(*ts) and all(t is None or L.dtype_code_all(t) >= 0 for t in ts)
 
     def _pairwise(self, name, x, y, z, extra, scalar=None, zbool=False):
