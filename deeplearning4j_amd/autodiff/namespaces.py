@@ -129,6 +129,7 @@ for _fam, _tbl in (("transform_same", LG.TRANSFORM_SAME), ("transform_strict", L
         if not hasattr(SDMath, _py):
             setattr(SDMath, _py, _unary(_fam, _n, _py))
 SDMath.cos = SDMath.cosine
+SDMath.rsqrt = SDMath.rSqrt
 
 
 def _math_extra():

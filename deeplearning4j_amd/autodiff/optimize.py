@@ -1,0 +1,357 @@
+"""Graph optimizer (reference: nd4j-api autodiff/samediff/optimize/{GraphOptimizer,OptimizationHelper} and
+optimizations/{Constant,Identity,Shape,Unused,CuDNN}FunctionOptimizations).
+
+Passes rewrite the SameDiff graph in place:
+* ConstantFolding      – ops whose inputs are all CONSTANT are evaluated once and replaced by a constant
+* IdentityRemoval      – identity / stop-gradient-free passthroughs are bypassed
+* ShapeFolding         – shape_of / rank / size of statically known shapes become constants
+* UnusedRemoval        – ops and constants that no requested output depends on are dropped
+* Fusion (MI355X)      – primitive sub-graphs produced by TF/ONNX exporters are pattern-matched into one fused
+  op so they hit a single kernel: TF layer-norm decomposition -> ``layer_norm``; erf/tanh GELU -> legacy GELU
+  functors; ``softmax(q·kᵀ·s)·v`` -> ``dot_product_attention_v2`` (BERT speed depends on this).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .samediff import OpType, SameDiff, SameDiffOp, VariableType, _CONTROL
+
+
+class GraphOptimizer:
+    @staticmethod
+    def defaultOptimizations():
+        return [ConstantFolding(), ShapeFolding(), IdentityRemoval(), Fusion(), UnusedRemoval()]
+
+    @staticmethod
+    def optimize(sd: SameDiff, outputs: Optional[Sequence[str]] = None, optimizations=None, maxPasses=10) -> SameDiff:
+        outputs = list(outputs) if outputs else (sd.outputs() + list(sd.lossVariables))
+        opts = optimizations or GraphOptimizer.defaultOptimizations()
+        for _ in range(maxPasses):
+            changed = False
+            for p in opts:
+                changed = p.apply(sd, outputs) or changed
+            if not changed:
+                break
+        return sd
+
+
+# ----------------------------------------------------------------------------- helpers
+def _remove_op(sd: SameDiff, o: SameDiffOp):
+    for i in o.inputs:
+        if o.name in sd._consumers.get(i, []):
+            sd._consumers[i] = [c for c in sd._consumers[i] if c != o.name]
+    for out in o.outputs:
+        sd._producer.pop(out, None)
+    sd.ops.pop(o.name, None)
+
+
+def _replace_uses(sd: SameDiff, old: str, new: str, outputs: List[str]):
+    for cn in list(sd._consumers.get(old, [])):
+        c = sd.ops[cn]
+        c.inputs = [new if i == old else i for i in c.inputs]
+        sd._consumers[new].append(cn)
+    sd._consumers[old] = []
+    for k, n in enumerate(outputs):
+        if n == old:
+            outputs[k] = new
+    sd.lossVariables = [new if n == old else n for n in sd.lossVariables]
+
+
+def _to_constant(sd: SameDiff, name: str, value: torch.Tensor):
+    v = sd.variables[name]
+    v.variableType = VariableType.CONSTANT
+    v.dtype, v.shape = value.dtype, list(value.shape)
+    sd._arrays[name] = value
+
+
+def _producer(sd, name) -> Optional[SameDiffOp]:
+    p = sd._producer.get(name)
+    return sd.ops[p] if p is not None else None
+
+
+def _is(o: Optional[SameDiffOp], *names) -> bool:
+    return o is not None and o.opName.lower() in names
+
+
+def _const_val(sd, name) -> Optional[torch.Tensor]:
+    v = sd.variables.get(name)
+    if v is not None and v.variableType == VariableType.CONSTANT:
+        return sd._arrays.get(name)
+    return None
+
+
+def _single_use(sd, name, outputs) -> bool:
+    return len(sd._consumers.get(name, [])) == 1 and name not in outputs
+
+
+class Optimization:
+    def apply(self, sd, outputs) -> bool:
+        raise NotImplementedError
+
+
+class ConstantFolding(Optimization):
+    MAX_ELEMENTS = 1 << 24
+    _SKIP = {"randomuniform", "random_normal", "random_bernoulli", "random_exponential", "dropout", "random_shuffle", "random_crop",
+             "random_gamma", "random_poisson", "random_multinomial", "print_variable", "assert"}
+
+    def apply(self, sd, outputs):
+        changed = False
+        for o in list(sd.ops.values()):
+            if o.opName.lower() in _CONTROL or o.opName.lower() in self._SKIP or o.opType == OpType.RANDOM or not o.inputs:
+                continue
+            if not all(_const_val(sd, i) is not None for i in o.inputs):
+                continue
+            try:
+                with torch.no_grad():
+                    outs = sd._exec_op(o, [sd._arrays[i] for i in o.inputs])
+            except Exception:
+                continue
+            if not all(isinstance(t, torch.Tensor) and t.numel() <= self.MAX_ELEMENTS for t in outs):
+                continue
+            for n, t in zip(o.outputs, outs):
+                _to_constant(sd, n, t.detach())
+            _remove_op(sd, o)
+            changed = True
+        return changed
+
+
+class ShapeFolding(Optimization):
+    def apply(self, sd, outputs):
+        changed = False
+        for o in list(sd.ops.values()):
+            if o.opName not in ("shape_of", "rank", "size"):
+                continue
+            shp = sd.variables[o.inputs[0]].getShape()
+            if shp is None or (o.opName != "rank" and any(s is None or s < 0 for s in shp)):
+                continue
+            val = {"shape_of": torch.tensor(shp, dtype=torch.int64), "rank": torch.tensor(len(shp), dtype=torch.int32),
+                   "size": torch.tensor(int(math.prod(shp)), dtype=torch.int64)}[o.opName]
+            _to_constant(sd, o.outputs[0], val.to(sd.device))
+            _remove_op(sd, o)
+            changed = True
+        return changed
+
+
+class IdentityRemoval(Optimization):
+    def apply(self, sd, outputs):
+        changed = False
+        for o in list(sd.ops.values()):
+            if o.opName == "identity" and o.opType == OpType.CUSTOM and len(o.inputs) == 1 and not o.controlDeps:
+                out = o.outputs[0]
+                if out in outputs or out in sd.lossVariables:
+                    continue                      # keep named graph outputs addressable
+                _replace_uses(sd, out, o.inputs[0], outputs)
+                _remove_op(sd, o)
+                sd.variables.pop(out, None)
+                changed = True
+        return changed
+
+
+class UnusedRemoval(Optimization):
+    def apply(self, sd, outputs):
+        need = sd._required_ops(list(outputs) + list(sd.lossVariables))
+        changed = False
+        for o in list(sd.ops.values()):
+            if o.name not in need:
+                for out in o.outputs:
+                    sd.variables.pop(out, None)
+                _remove_op(sd, o)
+                changed = True
+        used = set(outputs) | set(sd.lossVariables)
+        for o in sd.ops.values():
+            used.update(o.inputs)
+            used.update(o.controlDeps)
+        for n, v in list(sd.variables.items()):
+            if v.variableType == VariableType.CONSTANT and n not in used:
+                sd.variables.pop(n)
+                sd._arrays.pop(n, None)
+                changed = True
+        return changed
+
+
+class Fusion(Optimization):
+    def apply(self, sd, outputs):
+        changed = False
+        for fn in (self._layer_norm_tf, self._gelu_erf, self._gelu_tanh, self._sdpa):
+            for o in list(sd.ops.values()):
+                if o.name in sd.ops:
+                    changed = fn(sd, o, outputs) or changed
+        return changed
+
+    # y = x*m + (beta - mean*m),  m = rsqrt(var + eps) * gamma,  var = mean(sqdiff(x, mean)), mean = mean(x, axis, keepdims)
+    def _layer_norm_tf(self, sd, add1: SameDiffOp, outputs):
+        if not _is(add1, "add"):
+            return False
+        for a, b in (add1.inputs, add1.inputs[::-1]):
+            mul1, sub = _producer(sd, a), _producer(sd, b)
+            if not (_is(mul1, "multiply") and _is(sub, "subtract")):
+                continue
+            beta = sub.inputs[0]
+            mul2 = _producer(sd, sub.inputs[1])
+            if not _is(mul2, "multiply"):
+                continue
+            for x, m in (mul1.inputs, mul1.inputs[::-1]):
+                if m not in mul2.inputs:
+                    continue
+                mean_name = [i for i in mul2.inputs if i != m]
+                if len(mean_name) != 1:
+                    continue
+                mean = _producer(sd, mean_name[0])
+                mm = _producer(sd, m)
+                if not (_is(mean, "reduce_mean") and mean.inputs[0] == x and _is(mm, "multiply")):
+                    continue
+                for r, gamma in (mm.inputs, mm.inputs[::-1]):
+                    rs = _producer(sd, r)
+                    if not (_is(rs, "rsqrt") and rs.opType == OpType.TRANSFORM_FLOAT):
+                        continue
+                    addeps = _producer(sd, rs.inputs[0])
+                    if not _is(addeps, "add"):
+                        continue
+                    for vname, ename in (addeps.inputs, addeps.inputs[::-1]):
+                        eps = _const_val(sd, ename)
+                        var = _producer(sd, vname)
+                        if eps is None or eps.numel() != 1 or not _is(var, "reduce_mean"):
+                            continue
+                        sq = _producer(sd, var.inputs[0])
+                        if not (_is(sq, "squaredsubtract") and set(sq.inputs) == {x, mean_name[0]}):
+                            continue
+                        axes = list(mean.iArgs)
+                        xs = sd.variables[x].getShape()
+                        if not axes or xs is None or sorted(a_ % len(xs) for a_ in axes) != [len(xs) - 1]:
+                            continue
+                        new = SameDiffOp(add1.name, "layer_norm", [x, gamma, beta], add1.outputs, iArgs=[-1], tArgs=[float(eps)], bArgs=[False])
+                        _remove_op(sd, add1)
+                        sd._add_op(new)
+                        return True
+        return False
+
+    # 0.5 * x * (1 + erf(x / sqrt(2)))   (any association order of the three factors)
+    def _gelu_erf(self, sd, top: SameDiffOp, outputs):
+        if not _is(top, "multiply"):
+            return False
+        factors = self._flatten_mul(sd, top, outputs)
+        if factors is None or len(factors) != 3:
+            return False
+        half = [f for f in factors if (c := _const_val(sd, f)) is not None and c.numel() == 1 and abs(float(c) - 0.5) < 1e-6]
+        rest = [f for f in factors if f not in half]
+        if len(half) != 1 or len(rest) != 2:
+            return False
+        for x, e in (rest, rest[::-1]):
+            add = _producer(sd, e)
+            if not _is(add, "add"):
+                continue
+            for one, erfn in (add.inputs, add.inputs[::-1]):
+                c1 = _const_val(sd, one)
+                erf = _producer(sd, erfn)
+                if c1 is None or c1.numel() != 1 or abs(float(c1) - 1.0) > 1e-6 or not _is(erf, "erf"):
+                    continue
+                arg = _producer(sd, erf.inputs[0])
+                ok = False
+                if _is(arg, "divide") and arg.inputs[0] == x:
+                    c = _const_val(sd, arg.inputs[1])
+                    ok = c is not None and c.numel() == 1 and abs(float(c) - math.sqrt(2)) < 1e-4
+                elif _is(arg, "multiply") and x in arg.inputs:
+                    c = _const_val(sd, [i for i in arg.inputs if i != x][0]) if len(set(arg.inputs)) == 2 else None
+                    ok = c is not None and c.numel() == 1 and abs(float(c) - 1 / math.sqrt(2)) < 1e-4
+                if ok:
+                    # exact erf GELU = x * Phi(x): expressed with the fused pairwise kernel chain collapsed to one custom op call
+                    new = SameDiffOp(top.name, "gelu_erf_fused", [x], top.outputs, opType=OpType.UDF, opNum=0)
+                    _ensure_gelu_udf()
+                    _remove_op(sd, top)
+                    sd._add_op(new)
+                    return True
+        return False
+
+    # 0.5 * x * (1 + tanh(sqrt(2/pi) * (x + 0.044715 x^3)))
+    def _gelu_tanh(self, sd, top: SameDiffOp, outputs):
+        if not _is(top, "multiply"):
+            return False
+        factors = self._flatten_mul(sd, top, outputs)
+        if factors is None or len(factors) != 3:
+            return False
+        half = [f for f in factors if (c := _const_val(sd, f)) is not None and c.numel() == 1 and abs(float(c) - 0.5) < 1e-6]
+        rest = [f for f in factors if f not in half]
+        if len(half) != 1 or len(rest) != 2:
+            return False
+        for x, e in (rest, rest[::-1]):
+            add = _producer(sd, e)
+            if not _is(add, "add"):
+                continue
+            for one, tn in (add.inputs, add.inputs[::-1]):
+                c1 = _const_val(sd, one)
+                th = _producer(sd, tn)
+                if c1 is None or c1.numel() != 1 or abs(float(c1) - 1.0) > 1e-6 or not _is(th, "tanh"):
+                    continue
+                # accept any inner polynomial that references only x and constants ~ (0.79788, 0.044715)
+                consts = self._collect_consts(sd, th.inputs[0], x, depth=6)
+                if consts is not None and any(abs(v - 0.7978845608) < 1e-4 for v in consts) and any(abs(v - 0.044715) < 1e-5 for v in consts):
+                    from ..nd4j.ops import legacy as LG
+                    new = SameDiffOp(top.name, "precisegelu", [x], top.outputs, opType=OpType.TRANSFORM_STRICT,
+                                     opNum=LG.op_num("transform_strict", "PreciseGELU"))
+                    _remove_op(sd, top)
+                    sd._add_op(new)
+                    return True
+        return False
+
+    def _collect_consts(self, sd, name, x, depth) -> Optional[List[float]]:
+        if name == x:
+            return []
+        c = _const_val(sd, name)
+        if c is not None:
+            return [float(c)] if c.numel() == 1 else None
+        o = _producer(sd, name)
+        if o is None or depth == 0 or not _is(o, "multiply", "add", "pow", "cube", "square"):
+            return None
+        out = []
+        for i in o.inputs:
+            r = self._collect_consts(sd, i, x, depth - 1)
+            if r is None:
+                return None
+            out += r
+        return out
+
+    def _flatten_mul(self, sd, top, outputs) -> Optional[List[str]]:
+        out = []
+        for i in top.inputs:
+            p = _producer(sd, i)
+            if _is(p, "multiply") and _single_use(sd, i, outputs):
+                out += p.inputs
+            else:
+                out.append(i)
+        return out
+
+    # matmul(softmax(matmul(q, k^T) [* scale] [+ mask]), v)  ->  dot_product_attention_v2
+    def _sdpa(self, sd, mm2: SameDiffOp, outputs):
+        if not _is(mm2, "matmul") or (mm2.iArgs and any(mm2.iArgs[:3])):
+            return False
+        sm = _producer(sd, mm2.inputs[0])
+        if not (_is(sm, "softmax") and (not sm.iArgs or sm.iArgs[0] == -1) and _single_use(sd, mm2.inputs[0], outputs)):
+            return False
+        cur = _producer(sd, sm.inputs[0])
+        scale = 1.0
+        if _is(cur, "multiply", "divide"):
+            c = _const_val(sd, cur.inputs[1])
+            if c is None or c.numel() != 1:
+                return False
+            scale = float(c) if _is(cur, "multiply") else 1.0 / float(c)
+            cur = _producer(sd, cur.inputs[0])
+        if not _is(cur, "matmul"):
+            return False
+        ia = (list(cur.iArgs) + [0, 0, 0])[:3]
+        if ia[0] or not ia[1] or ia[2]:
+            return False                          # need q · kᵀ
+        q, k, v = cur.inputs[0], cur.inputs[1], mm2.inputs[1]
+        new = SameDiffOp(mm2.name, "dot_product_attention_v2", [q, v, k], mm2.outputs + [mm2.name + ":scores", mm2.name + ":logits"],
+                         tArgs=[scale, 0.0], bArgs=[False, False])
+        _remove_op(sd, mm2)
+        sd._add_op(new)
+        return True
+
+
+def _ensure_gelu_udf():
+    from ..nd4j.ops.custom import _IMPL
+    if "gelu_erf_fused" not in _IMPL:
+        _IMPL["gelu_erf_fused"] = lambda ins, i, t, b, d: torch.nn.functional.gelu(ins[0])

@@ -82,7 +82,11 @@ class SDVariable:
 
     def getShape(self):
         a = self.sd._arrays.get(self.name)
-        return list(a.shape) if a is not None else self.shape
+        if a is not None:
+            return list(a.shape)
+        if self.shape is None and self.variableType == VariableType.ARRAY:
+            return self.sd.inferShape(self.name)
+        return self.shape
 
     def isPlaceHolder(self):
         return self.variableType == VariableType.PLACEHOLDER
@@ -586,6 +590,55 @@ class SameDiff:
             z = torch.empty(shape, device=self.device)
             return [R.exec_random(name, None, z, None, None, o.tArgs)]
         raise NotImplementedError("op type %s (%s)" % (t, o.opName))
+
+    # ------------------------------------------------------------------ static shape inference
+    def _probe(self, name, probe, cache):
+        """Value of ``name`` with unknown placeholder dims set to ``probe``: real tensors for variables/constants,
+        ``meta`` tensors downstream of placeholders (no compute, no memory)."""
+        if name in cache:
+            return cache[name]
+        v = self.variables[name]
+        t = None
+        if v.variableType in (VariableType.VARIABLE, VariableType.CONSTANT):
+            t = self._arrays.get(name)
+        elif v.variableType == VariableType.PLACEHOLDER:
+            if v.shape is not None:
+                t = torch.empty([probe if (s is None or s < 0) else int(s) for s in v.shape], dtype=v.dtype or torch.float32, device="meta")
+        else:
+            pn = self._producer.get(name)
+            if pn is not None:
+                o = self.ops[pn]
+                ins = [self._probe(i, probe, cache) for i in o.inputs]
+                outs = None
+                if all(x is not None for x in ins) and o.opName.lower() not in _CONTROL:
+                    if any(x.device.type == "meta" for x in ins):
+                        ins = [x if (x.device.type == "meta" or not x.is_floating_point()) else
+                               torch.empty(x.shape, dtype=x.dtype, device="meta") for x in ins]
+                    else:
+                        ins = [x.detach() for x in ins]
+                    try:
+                        with torch.no_grad():
+                            outs = self._exec_op(o, ins, allow_helpers=False)
+                    except Exception:
+                        outs = None
+                for k, on in enumerate(o.outputs):
+                    cache[on] = outs[k] if outs is not None and k < len(outs) and isinstance(outs[k], torch.Tensor) else None
+                return cache.get(name)
+        cache[name] = t
+        return t
+
+    def inferShape(self, name):
+        """Static shape of any variable (``-1`` for dims that depend on unknown placeholder dims), or None."""
+        import sys
+        sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))
+        key = (len(self.ops), len(self.variables))
+        if getattr(self, "_shape_key", None) != key:
+            self._shape_key, self._shape_caches = key, ({}, {})
+        a = self._probe(name, 2, self._shape_caches[0])
+        b = self._probe(name, 3, self._shape_caches[1])
+        if a is None or b is None or a.dim() != b.dim():
+            return None
+        return [int(x) if x == y else -1 for x, y in zip(a.shape, b.shape)]
 
     def _required_ops(self, outputs: Sequence[str]) -> set:
         need, stack = set(), list(outputs)

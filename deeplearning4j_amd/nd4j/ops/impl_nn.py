@@ -165,7 +165,7 @@ def _layer_norm(ins, i, t, b, d):
     nchw = bool(b[0]) if b else False
     m = x.mean(axes, keepdim=True)
     v = x.var(axes, unbiased=False, keepdim=True)
-    y = (x - m) * torch.rsqrt(v + 1e-5)
+    y = (x - m) * torch.rsqrt(v + (float(t[0]) if t else 1e-5))
     sh = [1, -1] + [1] * (x.dim() - 2) if (nchw and x.dim() > 2) else [1] * (x.dim() - gain.dim()) + list(gain.shape)
     y = y * gain.reshape(sh)
     if bias is not None:

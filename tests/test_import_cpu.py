@@ -1,0 +1,326 @@
+"""TF GraphDef / ONNX import, static shape inference and the graph optimizer.
+
+Reference strategy: nd4j/samediff-import tests (TestTensorflowIr / TestOnnxIr) import a frozen model and compare
+op outputs. TensorFlow / onnx are not installed here, so graphs are hand-encoded on the protobuf wire
+(``protowire.enc_*``) and checked against a plain PyTorch recomputation; the reference's own ``lenet_frozen.pb`` and
+``add.onnx`` resources are imported when present ("parity unpinned" for LeNet: no stored outputs ship with it).
+"""
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from deeplearning4j_amd.autodiff.import_onnx import OnnxImporter
+from deeplearning4j_amd.autodiff.import_tf import TFGraphMapper
+from deeplearning4j_amd.autodiff.optimize import GraphOptimizer
+from deeplearning4j_amd.autodiff.protowire import enc_msg, Msg
+from deeplearning4j_amd.autodiff.samediff import SameDiff
+
+REF = "/root/reference"
+
+
+# ----------------------------------------------------------------------------- TF wire helpers
+def tf_shape(dims):
+    return enc_msg(*[(2, enc_msg((1, int(d)))) for d in dims])
+
+
+def tf_tensor(t: torch.Tensor):
+    dt = {torch.float32: 1, torch.int32: 3, torch.int64: 9}[t.dtype]
+    return enc_msg((1, dt), (2, tf_shape(t.shape)), (4, t.contiguous().numpy().tobytes()))
+
+
+def tf_attr(**kw):
+    out = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            av = enc_msg((8, tf_tensor(v)))
+        elif isinstance(v, bool):
+            av = enc_msg((5, v))
+        elif isinstance(v, int):
+            av = enc_msg((3, v))
+        elif isinstance(v, float):
+            av = enc_msg((4, v))
+        elif isinstance(v, str):
+            av = enc_msg((2, v))
+        elif isinstance(v, tuple) and v[0] == "type":
+            av = enc_msg((6, v[1]))
+        elif isinstance(v, tuple) and v[0] == "shape":
+            av = enc_msg((7, tf_shape(v[1])))
+        elif isinstance(v, list):
+            av = enc_msg((1, enc_msg(*[(3, int(i)) for i in v])))
+        else:
+            raise TypeError(k)
+        out.append((5, enc_msg((1, k), (2, av))))
+    return out
+
+
+def tf_node(name, op, inputs=(), **attrs):
+    return enc_msg((1, name), (2, op), *[(3, i) for i in inputs], *tf_attr(**attrs))
+
+
+def tf_graph(*nodes):
+    return enc_msg(*[(1, n) for n in nodes])
+
+
+def tf_const(name, t):
+    return tf_node(name, "Const", value=t, dtype=("type", 1 if t.dtype == torch.float32 else 3))
+
+
+# ----------------------------------------------------------------------------- ONNX wire helpers
+def ox_tensor(name, t: torch.Tensor):
+    dt = {torch.float32: 1, torch.int64: 7, torch.int32: 6}[t.dtype]
+    return enc_msg(*[(1, int(d)) for d in t.shape], (2, dt), (8, name), (9, t.contiguous().numpy().tobytes()))
+
+
+def ox_attr(name, v):
+    if isinstance(v, float):
+        return enc_msg((1, name), (2, v), (20, 1))
+    if isinstance(v, int):
+        return enc_msg((1, name), (3, v), (20, 2))
+    if isinstance(v, str):
+        return enc_msg((1, name), (4, v), (20, 3))
+    if isinstance(v, list):
+        return enc_msg((1, name), *[(8, int(i)) for i in v], (20, 7))
+    raise TypeError(name)
+
+
+def ox_node(op, inputs, outputs, name="", **attrs):
+    return enc_msg(*[(1, i) for i in inputs], *[(2, o) for o in outputs], (3, name or outputs[0]), (4, op),
+                   *[(5, ox_attr(k, v)) for k, v in attrs.items()])
+
+
+def ox_value_info(name, dims, elem=1):
+    dim_msgs = [(1, enc_msg((1, int(d))) if isinstance(d, int) else enc_msg((2, d))) for d in dims]
+    ttype = enc_msg((1, elem), (2, enc_msg(*dim_msgs)))
+    return enc_msg((1, name), (2, enc_msg((1, ttype))))
+
+
+def ox_model(nodes, inits, inputs, outputs):
+    g = enc_msg(*[(1, n) for n in nodes], (2, "g"), *[(5, i) for i in inits], *[(11, i) for i in inputs], *[(12, o) for o in outputs])
+    return enc_msg((1, 7), (7, g), (8, enc_msg((2, 13))))
+
+
+# ----------------------------------------------------------------------------- tests
+def test_protowire_roundtrip():
+    b = enc_msg((1, "abc"), (2, 300), (3, -5), (4, 1.5), (5, [1, 2, 3]), (6, enc_msg((1, "n"))))
+    m = Msg(b)
+    assert m.str(1) == "abc" and m.int(2) == 300 and m.int(3) == -5 and m.float(4) == 1.5
+    assert m.ints(5) == [1, 2, 3] and m.msg(6).str(1) == "n"
+
+
+def test_tf_mlp_import_matches_torch():
+    torch.manual_seed(0)
+    W, b = torch.randn(4, 3), torch.randn(3)
+    g = tf_graph(
+        tf_node("x", "Placeholder", dtype=("type", 1), shape=("shape", [-1, 4])),
+        tf_const("W", W), tf_const("b", b),
+        tf_node("mm", "MatMul", ["x", "W"], transpose_a=False, transpose_b=False),
+        tf_node("ba", "BiasAdd", ["mm", "b"]),
+        tf_node("r", "Relu", ["ba"]),
+        tf_node("out", "Softmax", ["r"]))
+    sd = TFGraphMapper.importGraph(g)
+    x = torch.randn(5, 4)
+    y = sd.output({"x": x}, ["out"])["out"]
+    ref = torch.softmax(torch.relu(x @ W + b), -1)
+    assert torch.allclose(_t(y), ref, atol=1e-6)
+    assert sd.getVariable("out").getShape() == [-1, 3]
+
+
+def test_tf_conv_pool_bn_import():
+    torch.manual_seed(1)
+    k = torch.randn(3, 3, 2, 4)                   # HWIO
+    gamma, beta, mean, var = torch.rand(4) + 0.5, torch.randn(4), torch.randn(4), torch.rand(4) + 0.5
+    g = tf_graph(
+        tf_node("x", "Placeholder", dtype=("type", 1), shape=("shape", [-1, 8, 8, 2])),
+        tf_const("k", k), tf_const("gamma", gamma), tf_const("beta", beta), tf_const("mean", mean), tf_const("var", var),
+        tf_node("conv", "Conv2D", ["x", "k"], strides=[1, 1, 1, 1], padding="SAME", data_format="NHWC"),
+        tf_node("bn", "FusedBatchNorm", ["conv", "gamma", "beta", "mean", "var"], epsilon=1e-3, is_training=False, data_format="NHWC"),
+        tf_node("relu", "Relu", ["bn"]),
+        tf_node("pool", "MaxPool", ["relu"], ksize=[1, 2, 2, 1], strides=[1, 2, 2, 1], padding="VALID", data_format="NHWC"),
+        tf_const("shape", torch.tensor([-1, 64], dtype=torch.int32)),
+        tf_node("flat", "Reshape", ["pool", "shape"]))
+    sd = TFGraphMapper.importGraph(g)
+    x = torch.randn(2, 8, 8, 2)
+    y = _t(sd.output({"x": x}, ["flat"])["flat"])
+    xc = x.permute(0, 3, 1, 2)
+    r = F.conv2d(xc, k.permute(3, 2, 0, 1), padding=1)
+    r = F.batch_norm(r, mean, var, gamma, beta, False, 0.0, 1e-3)
+    r = F.max_pool2d(torch.relu(r), 2).permute(0, 2, 3, 1).reshape(-1, 64)
+    assert torch.allclose(y, r, atol=1e-4)
+
+
+def _t(v):
+    return v if isinstance(v, torch.Tensor) else (v._t if hasattr(v, "_t") else torch.as_tensor(v))
+
+
+def test_tf_while_loop_import():
+    """i=0; while i < 5: i += 1; acc *= 2  — TF1 frame ops (Enter/Merge/Switch/NextIteration/Exit/LoopCond)."""
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32)
+    g = tf_graph(
+        tf_const("zero", i32(0)), tf_const("five", i32(5)), tf_const("one", i32(1)),
+        tf_const("a0", torch.tensor(1.0)), tf_const("two", torch.tensor(2.0)),
+        tf_node("enter_i", "Enter", ["zero"], frame_name="w", is_constant=False),
+        tf_node("enter_a", "Enter", ["a0"], frame_name="w", is_constant=False),
+        tf_node("enter_five", "Enter", ["five"], frame_name="w", is_constant=True),
+        tf_node("enter_one", "Enter", ["one"], frame_name="w", is_constant=True),
+        tf_node("enter_two", "Enter", ["two"], frame_name="w", is_constant=True),
+        tf_node("merge_i", "Merge", ["enter_i", "next_i"]),
+        tf_node("merge_a", "Merge", ["enter_a", "next_a"]),
+        tf_node("less", "Less", ["merge_i", "enter_five"]),
+        tf_node("cond", "LoopCond", ["less"]),
+        tf_node("sw_i", "Switch", ["merge_i", "cond"]),
+        tf_node("sw_a", "Switch", ["merge_a", "cond"]),
+        tf_node("add", "Add", ["sw_i:1", "enter_one"]),
+        tf_node("mul", "Mul", ["sw_a:1", "enter_two"]),
+        tf_node("next_i", "NextIteration", ["add"]),
+        tf_node("next_a", "NextIteration", ["mul"]),
+        tf_node("exit_i", "Exit", ["sw_i"]),
+        tf_node("exit_a", "Exit", ["sw_a"]))
+    sd = TFGraphMapper.importGraph(g)
+    out = sd.output({}, ["exit_i", "exit_a"])
+    assert int(_t(out["exit_i"])) == 5
+    assert float(_t(out["exit_a"])) == 32.0
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_tf_reference_lenet_frozen():
+    import glob
+    hits = glob.glob(REF + "/**/lenet_frozen.pb", recursive=True)
+    if not hits:
+        pytest.skip("lenet_frozen.pb not shipped")
+    sd = TFGraphMapper.importGraph(hits[0])
+    ph = sd.inputs()
+    assert ph, "frozen graph must expose a placeholder"
+    shp = sd.getVariable(ph[0]).shape
+    x = torch.rand([2 if (s is None or s < 0) else s for s in shp] if shp else [2, 784])
+    outs = sd.outputs()
+    res = sd.output({ph[0]: x}, outs[:1])
+    y = _t(res[outs[0]])
+    assert y.shape[0] == 2 and torch.isfinite(y.float()).all()
+
+
+def test_onnx_cnn_import_matches_torch():
+    torch.manual_seed(2)
+    w, b = torch.randn(4, 2, 3, 3), torch.randn(4)
+    fw, fb = torch.randn(10, 4 * 4 * 4), torch.randn(10)
+    m = ox_model(
+        [ox_node("Conv", ["x", "w", "b"], ["c"], kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[1, 1]),
+         ox_node("Relu", ["c"], ["r"]),
+         ox_node("MaxPool", ["r"], ["p"], kernel_shape=[2, 2], strides=[2, 2]),
+         ox_node("Flatten", ["p"], ["f"], axis=1),
+         ox_node("Gemm", ["f", "fw", "fb"], ["logits"], transB=1, alpha=1.0, beta=1.0),
+         ox_node("Softmax", ["logits"], ["prob"], axis=-1)],
+        [ox_tensor("w", w), ox_tensor("b", b), ox_tensor("fw", fw), ox_tensor("fb", fb)],
+        [ox_value_info("x", ["N", 2, 8, 8])], [ox_value_info("prob", ["N", 10])])
+    sd = OnnxImporter.importGraph(m)
+    x = torch.randn(3, 2, 8, 8)
+    y = _t(sd.output({"x": x}, ["prob"])["prob"])
+    ref = torch.softmax(F.max_pool2d(torch.relu(F.conv2d(x, w, b, padding=1)), 2).flatten(1) @ fw.t() + fb, -1)
+    assert torch.allclose(y, ref, atol=1e-5)
+    assert sd.getVariable("prob").getShape() == [-1, 10]
+    assert sd.getVariable("p").getShape() == [-1, 4, 4, 4]
+
+
+def test_onnx_trainable_finetune():
+    torch.manual_seed(3)
+    w, b = torch.randn(3, 4) * 0.1, torch.zeros(3)
+    m = ox_model([ox_node("Gemm", ["x", "w", "b"], ["y"], transB=1)], [ox_tensor("w", w), ox_tensor("b", b)],
+                 [ox_value_info("x", ["N", 4])], [ox_value_info("y", ["N", 3])])
+    sd = OnnxImporter.importGraph(m, trainable=True)
+    assert set(sd.trainableVariables()) == {"w", "b"}
+    x, t = torch.randn(16, 4), torch.randn(16, 3)
+    lab = sd.placeHolder("t", "FLOAT", -1, 3)
+    diff = sd.getVariable("y").sub(lab)
+    loss = diff.mul(diff).mean()
+    sd.setLossVariables(loss)
+    g = sd.calculateGradients({"x": x, "t": t}, ["w"])
+    gw = _t(g["w"])
+    ref = (2.0 / t.numel()) * (x @ w.t() + b - t).t() @ x
+    assert torch.allclose(gw, ref, atol=1e-5)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present")
+def test_onnx_reference_add():
+    import glob
+    hits = [h for h in glob.glob(REF + "/**/add.onnx", recursive=True) if os.path.getsize(h) > 0]
+    if not hits:
+        pytest.skip("add.onnx not shipped")
+    sd = OnnxImporter.importGraph(hits[0])
+    ph = sd.inputs()
+    feeds = {n: torch.full([2, 2] if not sd.getVariable(n).shape else [s if s and s > 0 else 2 for s in sd.getVariable(n).shape], float(k + 1))
+             for k, n in enumerate(ph)}
+    out = sd.outputs()[0]
+    y = _t(sd.output(feeds, [out])[out])
+    assert torch.allclose(y, sum(feeds.values()))
+
+
+# ----------------------------------------------------------------------------- shape inference + optimizer
+def test_infer_shape_dynamic_batch():
+    sd = SameDiff.create()
+    x = sd.placeHolder("x", "FLOAT", -1, 6)
+    w = sd.var("w", torch.randn(6, 4))
+    h = sd.nn.relu(x.mmul(w))
+    r = sd.base.reshape(h, -1, 2, 2)
+    s = r.sum(1)
+    assert h.getShape() == [-1, 4]
+    assert r.getShape() == [-1, 2, 2]
+    assert s.getShape() == [-1, 2]
+
+
+def test_optimizer_constant_folding_and_unused():
+    sd = SameDiff.create()
+    x = sd.placeHolder("x", "FLOAT", -1, 3)
+    a = sd.constant("a", torch.tensor([1.0, 2.0, 3.0]))
+    b = sd.constant("b", torch.tensor(2.0))
+    c = a.mul(b).add(1.0)                       # constant sub-graph
+    dead = sd.math.exp(x)                       # not needed for the output
+    y = sd.base.identity(x.add(c))
+    out = sd.math.neg(y, name="out")
+    n_before = len(sd.ops)
+    GraphOptimizer.optimize(sd, ["out"])
+    assert len(sd.ops) < n_before
+    assert dead.name not in sd.variables
+    assert all(o.opName != "identity" for o in sd.ops.values())
+    assert len(sd.ops) == 2                     # add + neg
+    xv = torch.randn(2, 3)
+    assert torch.allclose(_t(sd.output({"x": xv}, ["out"])["out"]), -(xv + torch.tensor([3.0, 5.0, 7.0])))
+
+
+def _tf_layernorm_gelu_attention():
+    sd = SameDiff.create()
+    x = sd.placeHolder("x", "FLOAT", -1, 5, 8)
+    gamma, beta = sd.var("gamma", torch.rand(8) + 0.5), sd.var("beta", torch.randn(8))
+    mean = x.mean(-1, keepDims=True)
+    sq = sd._op("squaredsubtract", [x, mean])[0]
+    var = sq.mean(-1, keepDims=True)
+    rs = sd.math.rsqrt(var.add(1e-6))
+    m = rs.mul(gamma)
+    ln = x.mul(m).add(beta.sub(mean.mul(m)))
+    # erf GELU
+    ge = ln.mul(0.5).mul(sd.math.erf(ln.div(math.sqrt(2.0))).add(1.0))
+    # attention
+    q, k, v = ge, ge, ln
+    att = sd.nn.softmax(q.mmul(k, transposeB=True).mul(1.0 / math.sqrt(8.0)), -1).mmul(v)
+    out = sd.base.identity(att, name="out")
+    return sd
+
+
+def test_optimizer_fusions_preserve_numerics():
+    torch.manual_seed(4)
+    sd = _tf_layernorm_gelu_attention()
+    x = torch.randn(3, 5, 8)
+    before = _t(sd.output({"x": x}, ["out"])["out"]).clone()
+    GraphOptimizer.optimize(sd, ["out"])
+    names = [o.opName for o in sd.ops.values()]
+    assert "layer_norm" in names and "dot_product_attention_v2" in names and "gelu_erf_fused" in names, names
+    assert "rsqrt" not in names and "erf" not in names and "softmax" not in names
+    after = _t(sd.output({"x": x}, ["out"])["out"])
+    assert torch.allclose(before, after, atol=1e-5)
+    # gradients still flow through the fused ops
+    sd.setLossVariables(sd.getVariable("out").mean())
+    g = sd.calculateGradients({"x": x}, ["gamma"])
+    assert torch.isfinite(_t(g["gamma"])).all() and _t(g["gamma"]).abs().sum() > 0
