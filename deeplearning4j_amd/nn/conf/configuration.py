@@ -271,6 +271,16 @@ class ListBuilder:
                                        validateOutputLayerConfig=self._validateOutput, inputType=self._inputType)
         if self._inputType is not None:
             conf._apply_input_type(self._inputType, self._overrideNinUponBuild)
+        elif n and 0 not in self._pre:
+            # no InputType given: infer it from the first layer's nIn where that is unambiguous
+            # (MultiLayerConfiguration.Builder.build, reference MultiLayerConfiguration.java:700-735)
+            from .layers import BaseRecurrentLayer, FeedForwardLayer, ConvolutionLayer, RnnOutputLayer, EmbeddingSequenceLayer
+            l0 = self._layers[0]
+            nin = getattr(l0, "nIn", 0) or 0
+            if nin > 0 and isinstance(l0, FeedForwardLayer) and not isinstance(l0, ConvolutionLayer):
+                rnn = isinstance(l0, (BaseRecurrentLayer, RnnOutputLayer)) and not isinstance(l0, EmbeddingSequenceLayer)
+                it = InputType.recurrent(nin) if rnn else InputType.feedForward(nin)
+                conf._apply_input_type(it, False)
         return conf
 
 

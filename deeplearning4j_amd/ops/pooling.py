@@ -86,8 +86,12 @@ def pool2d_backward(dy, ctx):
         with torch.enable_grad():
             y = F.avg_pool2d(x0, k, s, p, count_include_pad=not excl)
         return torch.autograd.grad(y, x0, dy)[0]
-    x = ctx.x.detach().requires_grad_(True)
+    # pnorm: y = (sum |x|^p)^(1/p)  =>  dx = sign(x)|x|^(p-1) * scatter(dy * y^(1-p)); all-zero windows contribute 0
+    # (autograd through pow(1/p) gives 0 * inf = NaN there, e.g. after a ReLU)
+    x, y = ctx.x.detach(), ctx.y.detach()
+    gy = torch.where(y > 0, dy * y.clamp_min(1e-30).pow(1.0 - pnorm), torch.zeros_like(dy))
+    leaf = torch.zeros_like(x, requires_grad=True)
     with torch.enable_grad():
-        xp = x.abs().pow(pnorm)
-        y = (F.avg_pool2d(xp, k, s, p, count_include_pad=True) * (k[0] * k[1])).pow(1.0 / pnorm)
-    return torch.autograd.grad(y, x, dy)[0]
+        lin = F.avg_pool2d(leaf, k, s, p, count_include_pad=True) * (k[0] * k[1])
+    spread = torch.autograd.grad(lin, leaf, gy)[0]
+    return spread * x.sign() * x.abs().pow(pnorm - 1)
