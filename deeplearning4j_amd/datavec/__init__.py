@@ -1,0 +1,13 @@
+"""DataVec: ETL (reference: datavec/datavec-api, datavec-data-image, datavec-local)."""
+from .writable import (Writable, IntWritable, LongWritable, FloatWritable, DoubleWritable, BooleanWritable, Text, NullWritable,  # noqa: F401
+                       BytesWritable, NDArrayWritable)
+from .records import (InputSplit, FileSplit, CollectionInputSplit, NumberedFileInputSplit, StringSplit, ListStringSplit, RecordReader,  # noqa: F401
+                      SequenceRecordReader, LineRecordReader, CSVRecordReader, CSVSequenceRecordReader, CSVRegexRecordReader,
+                      RegexLineRecordReader, SVMLightRecordReader, LibSvmRecordReader, JacksonLineRecordReader, CollectionRecordReader,
+                      CollectionSequenceRecordReader, InMemoryRecordReader, InMemorySequenceRecordReader, FileRecordReader,
+                      TransformProcessRecordReader, ConcatenatingRecordReader, Record, RecordMetaData)
+from .transform import (ColumnType, Schema, TransformProcess, LocalTransformExecutor, AnalyzeLocal, DataAnalysis, ConditionOp,  # noqa: F401
+                        ColumnCondition, DoubleColumnCondition, IntegerColumnCondition, LongColumnCondition, StringColumnCondition,
+                        CategoricalColumnCondition, NullWritableColumnCondition, NaNColumnCondition, InvalidValueColumnCondition,
+                        BooleanCondition, ConditionFilter, FilterInvalidValues, MathOp, MathFunction, ReduceOp, Reducer, Join, Normalize,
+                        NumericalColumnComparator, StringComparator)
