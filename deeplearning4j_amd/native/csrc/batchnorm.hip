@@ -51,16 +51,39 @@ __device__ __forceinline__ void store_vec<bf16_t, 1>(bf16_t* p, const float (&o)
 template <>
 __device__ __forceinline__ void store_vec<float, 1>(float* p, const float (&o)[1]) { *p = o[0]; }
 
+// Per-channel fp32 coefficients for V consecutive channels: 16-byte loads (V=8: two, V=4: one). With one scalar load per
+// channel a single-iteration thread issued 4-5x more (poorly coalesced) coefficient loads than data loads, which is what
+// bounded the small late-stage layers.
+template <int V>
+__device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, float (&o)[V]) {
+  if constexpr (V == 8) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + c0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + c0 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
+  } else if constexpr (V == 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + c0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = a[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = p[c0 + j];
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Pass A: per-channel column reductions of up to two quantities.
 //   MODE 0: q0 = x, q1 = x*x                      (forward statistics)
 //   MODE 1: q0 = dz, q1 = dz * (x-mean)*invstd    (backward dbeta / dgamma), dz = dy*[out>0]
+//           the ReLU mask comes from ``out`` or, when out == nullptr and mscale != nullptr (no residual was added),
+//           is recomputed as [x*mscale + mshift > 0] so that the activation tensor is not re-read.
 // block = 256 threads: cpb channel-vectors x rpi rows per iteration.
 // ---------------------------------------------------------------------------------------
 template <typename T, int V, int MODE>
 __global__ void __launch_bounds__(256) bn_colreduce_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ out,
     const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ mscale, const float* __restrict__ mshift,
     float* __restrict__ partial, int64_t M, int C, int cpb, int rpi) {
   __shared__ float red[2 * V * 256];
   const int cv = C / V;
@@ -73,10 +96,12 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
   for (int j = 0; j < V; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
   if (active) {
     const int c0 = cvec * V;
-    float mu[V], is[V];
+    float mu[V], is[V], ms[V], mt[V];
+    const bool xmask = (MODE == 1) && (out == nullptr) && (mscale != nullptr);
     if (MODE == 1) {
-#pragma unroll
-      for (int j = 0; j < V; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; }
+      load_coef<V>(mean, c0, mu);
+      load_coef<V>(invstd, c0, is);
+      if (xmask) { load_coef<V>(mscale, c0, ms); load_coef<V>(mshift, c0, mt); }
     }
 #pragma unroll 2
     for (int64_t r = (int64_t)blockIdx.y * rpi + r_in; r < M; r += (int64_t)gridDim.y * rpi) {
@@ -94,6 +119,9 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
           load_vec<T, V>(out + off, ov);
 #pragma unroll
           for (int j = 0; j < V; ++j) dv[j] = ov[j] > 0.f ? dv[j] : 0.f;
+        } else if (xmask) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) dv[j] = (xv[j] * ms[j] + mt[j]) > 0.f ? dv[j] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) { a0[j] += dv[j]; a1[j] += dv[j] * (xv[j] - mu[j]) * is[j]; }
@@ -153,8 +181,8 @@ static inline int64_t colreduce_ws_floats(int C) { return (int64_t)BN_MAX_ROWBLO
 
 template <typename T, int MODE>
 static int launch_colreduce(const void* x, const void* dy, const void* out, const float* mean,
-                            const float* invstd, float* partial, float* sums, float* out0, float* out1, int64_t M,
-                            int C, hipStream_t st) {
+                            const float* invstd, const float* mscale, const float* mshift, float* partial, float* sums,
+                            float* out0, float* out1, int64_t M, int C, hipStream_t st) {
   constexpr int VFULL = VecOf<T>::N;
   const bool vec_ok = (C % VFULL) == 0;
   const int V = vec_ok ? VFULL : 1;
@@ -169,10 +197,10 @@ static int launch_colreduce(const void* x, const void* dy, const void* out, cons
   dim3 grid(gx, (unsigned)gy);
   if (vec_ok)
     hipLaunchKernelGGL((bn_colreduce_kernel<T, VFULL, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
-                       (const T*)out, mean, invstd, partial, M, C, cpb, rpi);
+                       (const T*)out, mean, invstd, mscale, mshift, partial, M, C, cpb, rpi);
   else
     hipLaunchKernelGGL((bn_colreduce_kernel<T, 1, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
-                       (const T*)out, mean, invstd, partial, M, C, cpb, rpi);
+                       (const T*)out, mean, invstd, mscale, mshift, partial, M, C, cpb, rpi);
   hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)gy, C, sums, out0,
                      out1);
   DL4J_RET_LAST();
@@ -260,23 +288,18 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float sc[V], sh[V], rs[V], rt[V];
   const bool has_rs = (res != nullptr) && (rscale != nullptr);
-  if (HOIST) {
-    const int c0 = (int)(tid0 % cv) * V;
+  auto coeffs = [&](int c0) {
+    load_coef<V>(scale, c0, sc);
+    load_coef<V>(shift, c0, sh);
+    if (has_rs) { load_coef<V>(rscale, c0, rs); load_coef<V>(rshift, c0, rt); }
+    else {
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
-      rs[j] = has_rs ? rscale[c0 + j] : 1.f; rt[j] = has_rs ? rshift[c0 + j] : 0.f;
+      for (int j = 0; j < V; ++j) { rs[j] = 1.f; rt[j] = 0.f; }
     }
-  }
+  };
+  if (HOIST) coeffs((int)(tid0 % cv) * V);
   for (int64_t i = tid0; i < nvec; i += stride) {
-    if (!HOIST) {
-      const int c0 = (int)(i % cv) * V;
-#pragma unroll
-      for (int j = 0; j < V; ++j) {
-        sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
-        rs[j] = has_rs ? rscale[c0 + j] : 1.f; rt[j] = has_rs ? rshift[c0 + j] : 0.f;
-      }
-    }
+    if (!HOIST) coeffs((int)(i % cv) * V);
     float xv[V];
     load_vec<T, V>(x + i * V, xv);
 #pragma unroll
@@ -327,20 +350,28 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
                                                         const T* __restrict__ out, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma,
-                                                        const float* __restrict__ sums, T* __restrict__ dx,
+                                                        const float* __restrict__ sums,
+                                                        const float* __restrict__ mscale,
+                                                        const float* __restrict__ mshift, T* __restrict__ dx,
                                                         T* __restrict__ dz_out, int64_t nvec, int cv, int C,
                                                         float invM) {
   const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  float A[V], B[V], K[V];
+  float A[V], B[V], K[V], ms[V], mt[V];
+  const bool xmask = (out == nullptr) && (mscale != nullptr);
   auto coeffs = [&](int c0) {
+    float is[V], g[V], s0[V], s1[V], mu[V];
+    load_coef<V>(invstd, c0, is);
+    load_coef<V>(sums, c0, s0);
+    load_coef<V>(sums + C, c0, s1);
+    load_coef<V>(mean, c0, mu);
+    if (gamma) load_coef<V>(gamma, c0, g);
+    if (xmask) { load_coef<V>(mscale, c0, ms); load_coef<V>(mshift, c0, mt); }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const int c = c0 + j;
-      const float is = invstd[c];
-      const float a = (gamma ? gamma[c] : 1.f) * is;
-      const float bq = -a * is * sums[C + c] * invM;
-      A[j] = a; B[j] = bq; K[j] = -a * sums[c] * invM - bq * mean[c];
+      const float a = (gamma ? g[j] : 1.f) * is[j];
+      const float bq = -a * is[j] * s1[j] * invM;
+      A[j] = a; B[j] = bq; K[j] = -a * s0[j] * invM - bq * mu[j];
     }
   };
   if (HOIST) coeffs((int)(tid0 % cv) * V);
@@ -354,6 +385,9 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
       load_vec<T, V>(out + i * V, ov);
 #pragma unroll
       for (int j = 0; j < V; ++j) dv[j] = ov[j] > 0.f ? dv[j] : 0.f;
+    } else if (xmask) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) dv[j] = (xv[j] * ms[j] + mt[j]) > 0.f ? dv[j] : 0.f;
     }
     if (dz_out != nullptr) store_vec<T, V>(dz_out + i * V, dv);
     float r[V];
@@ -365,8 +399,8 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
 
 template <typename T>
 static int launch_bwd_dx(const void* x, const void* dy, const void* out, const float* mean, const float* invstd,
-                         const float* gamma, const float* sums, void* dx, void* dz, int64_t M, int C,
-                         hipStream_t st) {
+                         const float* gamma, const float* sums, const float* mscale, const float* mshift, void* dx,
+                         void* dz, int64_t M, int C, hipStream_t st) {
   constexpr int VFULL = VecOf<T>::N;
   const float invM = 1.f / (float)M;
   if (C % VFULL == 0) {
@@ -375,14 +409,14 @@ static int launch_bwd_dx(const void* x, const void* dy, const void* out, const f
     const int g = hoist_grid(nvec, C / VFULL, &hoist);
     if (hoist)
       hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VFULL, true>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)dy,
-                         (const T*)out, mean, invstd, gamma, sums, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM);
+                         (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM);
     else
       hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VFULL, false>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)dy,
-                         (const T*)out, mean, invstd, gamma, sums, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM);
+                         (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM);
   } else {
     const int64_t nvec = M * C;
     hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1, false>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x,
-                       (const T*)dy, (const T*)out, mean, invstd, gamma, sums, (T*)dx, (T*)dz, nvec, C, C, invM);
+                       (const T*)dy, (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C, C, invM);
   }
   DL4J_RET_LAST();
 }
@@ -401,8 +435,10 @@ DL4J_API int dl4j_bn_sum_partials(const float* partial, int gy, int C, float* su
 DL4J_API int dl4j_bn_stats(const void* x, float* partial_ws, float* sums, int64_t M, int C, int dtype,
                            hipStream_t st) {
   if (dtype == 1)
-    return launch_colreduce<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, partial_ws, sums, nullptr, nullptr, M, C, st);
-  return launch_colreduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, partial_ws, sums, nullptr, nullptr, M, C, st);
+    return launch_colreduce<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, partial_ws, sums, nullptr,
+                                       nullptr, M, C, st);
+  return launch_colreduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, partial_ws, sums, nullptr, nullptr,
+                                    M, C, st);
 }
 
 DL4J_API int dl4j_bn_finalize(const float* sums, const float* gamma, const float* beta, const float* conv_bias,
@@ -429,17 +465,21 @@ DL4J_API int dl4j_bn_apply(const void* x, const float* scale, const float* shift
   return launch_apply<float>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st);
 }
 
+// mscale/mshift (optional, used when out == nullptr): recompute the fused-ReLU mask from x instead of reading the output.
 DL4J_API int dl4j_bn_bwd_reduce(const void* x, const void* dy, const void* out, const float* mean,
-                                const float* invstd, float* partial_ws, float* sums, float* dbeta_out,
-                                float* dgamma_out, int64_t M, int C, int dtype, hipStream_t st) {
+                                const float* invstd, const float* mscale, const float* mshift, float* partial_ws,
+                                float* sums, float* dbeta_out, float* dgamma_out, int64_t M, int C, int dtype,
+                                hipStream_t st) {
   if (dtype == 1)
-    return launch_colreduce<bf16_t, 1>(x, dy, out, mean, invstd, partial_ws, sums, dbeta_out, dgamma_out, M, C, st);
-  return launch_colreduce<float, 1>(x, dy, out, mean, invstd, partial_ws, sums, dbeta_out, dgamma_out, M, C, st);
+    return launch_colreduce<bf16_t, 1>(x, dy, out, mean, invstd, mscale, mshift, partial_ws, sums, dbeta_out, dgamma_out,
+                                       M, C, st);
+  return launch_colreduce<float, 1>(x, dy, out, mean, invstd, mscale, mshift, partial_ws, sums, dbeta_out, dgamma_out, M, C,
+                                    st);
 }
 
 DL4J_API int dl4j_bn_bwd_dx(const void* x, const void* dy, const void* out, const float* mean, const float* invstd,
-                            const float* gamma, const float* sums, void* dx, void* dz, int64_t M, int C, int dtype,
-                            hipStream_t st) {
-  if (dtype == 1) return launch_bwd_dx<bf16_t>(x, dy, out, mean, invstd, gamma, sums, dx, dz, M, C, st);
-  return launch_bwd_dx<float>(x, dy, out, mean, invstd, gamma, sums, dx, dz, M, C, st);
+                            const float* gamma, const float* sums, const float* mscale, const float* mshift, void* dx,
+                            void* dz, int64_t M, int C, int dtype, hipStream_t st) {
+  if (dtype == 1) return launch_bwd_dx<bf16_t>(x, dy, out, mean, invstd, gamma, sums, mscale, mshift, dx, dz, M, C, st);
+  return launch_bwd_dx<float>(x, dy, out, mean, invstd, gamma, sums, mscale, mshift, dx, dz, M, C, st);
 }

@@ -35,6 +35,7 @@ struct IGemmP {
   int OHs, OWs, oys, oxs;  // physical output tensor spatial dims and pixel strides (scatter for strided dgrad)
   int M;              // N*OH*OW
   int mtiles, ntiles;
+  int accum;          // 1: y += result (in-place gradient accumulation at graph fan-out points, saves a separate add pass)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -192,7 +193,13 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
       const int n = m / OHW, rem = m - n * OHW;
       const int oh = rem / p.OW, ow = rem - oh * p.OW;
       const int64_t o = (((int64_t)n * p.OHs + oh * p.oys) * p.OWs + ow * p.oxs) * p.K + n0 + ch * 8;
-      *reinterpret_cast<s16x8*>(p.y + o) = *reinterpret_cast<const s16x8*>(sC + row * PITCH_C + ch * 16);
+      s16x8 v = *reinterpret_cast<const s16x8*>(sC + row * PITCH_C + ch * 16);
+      if (p.accum) {
+        const s16x8 prev = *reinterpret_cast<const s16x8*>(p.y + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)v[j]) + bf2f((bf16_t)prev[j]));
+      }
+      *reinterpret_cast<s16x8*>(p.y + o) = v;
     }
   }
 }
@@ -215,9 +222,9 @@ static int launch_fwd(IGemmP& p, hipStream_t st) {
 // geom = [N,H,W,C, OH,OW,K, R,S, sh,sw, ph,pw, dh,dw, OHs,OWs,oys,oxs]
 // returns the number of M tiles used (needed to reduce the BN-stat partials) via *mtiles_out.
 DL4J_API int dl4j_igemm_conv(const void* x, const void* w, void* y, const float* bias, float* stats,
-                             const int* g, int tile, int* mtiles_out, hipStream_t st) {
+                             const int* g, int tile, int accum, int* mtiles_out, hipStream_t st) {
   IGemmP p;
-  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.bias = bias; p.stats = stats;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.bias = bias; p.stats = stats; p.accum = accum;
   p.N = g[0]; p.H = g[1]; p.W = g[2]; p.C = g[3]; p.OH = g[4]; p.OW = g[5]; p.K = g[6]; p.R = g[7]; p.S = g[8];
   p.sh = g[9]; p.sw = g[10]; p.ph = g[11]; p.pw = g[12]; p.dh = g[13]; p.dw = g[14];
   p.OHs = g[15]; p.OWs = g[16]; p.oys = g[17]; p.oxs = g[18];

@@ -105,6 +105,7 @@ def _stats_only(self, x, train):
     scale, shift = self.coefficients(x2, train)
     if train:
         self._x2, self._shp, self._out2, self._z2, self._want_dz = x2, shp, None, None, False
+        self._mask_coeffs = None
     return scale, shift
 
 
@@ -447,6 +448,24 @@ class ComputationGraph(BaseNetwork):
             else:
                 e = eps.pop(nd.out, None)
                 if e is None:
+                    continue
+                # fan-out accumulation fused into the conv dgrad epilogue: the gradient already collected for this node's
+                # input is updated in place instead of materialising dx and running a separate add
+                acc_in = None
+                if (type(nd) is _Node and nd.is_layer and nd.pre is None and len(nd.inputs) == 1
+                        and isinstance(nd.impl, ConvolutionLayerImpl) and type(nd.impl) is ConvolutionLayerImpl
+                        and nd.impl.supports_accum()):
+                    acc_in = eps.get(nd.inputs[0])
+                    if acc_in is not None:
+                        # the target must be exclusively owned: vertices such as Add hand the *same* tensor to several inputs
+                        sp = acc_in.untyped_storage().data_ptr()
+                        if sp == e.untyped_storage().data_ptr() or any(
+                                t is not acc_in and t.untyped_storage().data_ptr() == sp for t in eps.values()):
+                            acc_in = None
+                if acc_in is not None:
+                    dx = nd.impl.backward(e, accum=acc_in)
+                    if dx is not None:
+                        eps[nd.inputs[0]] = dx
                     continue
                 dxs = nd.backward(e, mb)
             for inp, dx in zip(nd.inputs, dxs):

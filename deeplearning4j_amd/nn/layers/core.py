@@ -322,7 +322,10 @@ class BatchNormalizationImpl(LayerImpl):
         y2 = BN.apply(x2, scale, shift, r2, rs, rt, fuse_relu)
         if train:
             self._x2, self._shp = x2, shp
-            self._out2 = y2 if fuse_relu else None
+            # without a residual the ReLU mask is recomputable from x (x*scale+shift > 0): the backward kernels then skip
+            # re-reading the output tensor; with a residual the mask needs the stored output
+            self._out2 = y2 if (fuse_relu and residual is not None) else None
+            self._mask_coeffs = (scale, shift) if (fuse_relu and residual is None) else None
             self._want_dz = residual is not None
         if not fuse_relu and act is not None and not isinstance(act, ActivationIdentity):
             self._z2 = y2
@@ -343,7 +346,7 @@ class BatchNormalizationImpl(LayerImpl):
         dg = self.grads["gamma"].reshape(-1) if "gamma" in self.grads else None
         db = self.grads["beta"].reshape(-1) if "beta" in self.grads else None
         dx2, dz2 = BN.backward(self._x2, d2, self._out2, self._mean, self._invstd, gamma, dg, db,
-                               want_dz=return_dz or self._want_dz)
+                               want_dz=return_dz or self._want_dz, mask_coeffs=getattr(self, "_mask_coeffs", None))
         dx = self._from2d(dx2, self._shp)
         if return_dz or self._want_dz:
             return dx, self._from2d(dz2, self._shp)
@@ -351,7 +354,7 @@ class BatchNormalizationImpl(LayerImpl):
 
     def clear(self):
         super().clear()
-        self._x2 = self._out2 = self._z2 = None
+        self._x2 = self._out2 = self._z2 = self._mask_coeffs = None
 
 
 # ------------------------------------------------------------------ convolution
@@ -400,7 +403,11 @@ class ConvolutionLayerImpl(LayerImpl):
         self.z = z
         return act.forward(z, train)
 
-    def backward(self, eps):
+    def supports_accum(self):
+        """True when backward(eps, accum=g) can add the input gradient into ``g`` (graph fan-out accumulation)."""
+        return self._extra is None and self.conf.idropout is None
+
+    def backward(self, eps, accum=None):
         c = self.conf
         dz = eps if self.z is None else c.activationFn.backprop(self.z, eps)
         if dz.dtype != self.input.dtype:
@@ -409,7 +416,7 @@ class ConvolutionLayerImpl(LayerImpl):
         need_dx = getattr(self, "needs_input_grad", True)
         dx, dW, db = CONV.conv2d_backward(dz, self.input, self.w("W"), c.stride, self._pad, c.dilation,
                                           need_dx, True, has_b, w_dgrad=self.cparams.get("W_dgrad"),
-                                          dw_out=self.grads["W"])
+                                          dw_out=self.grads["W"], dx_accum=accum if need_dx else None)
         if dW is not None:
             self.grads["W"].copy_(dW)
         if "b" in self.grads:

@@ -134,8 +134,10 @@ def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std
     return mean, invstd, scale, shift
 
 
-def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_dz=False):
-    """BatchNorm backward. ``out2d`` (optional) is the fused ReLU output used as mask.
+def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_dz=False, mask_coeffs=None):
+    """BatchNorm backward. ``out2d`` (optional) is the fused ReLU output used as mask; alternatively ``mask_coeffs`` =
+    (scale, shift) lets the kernels recompute the mask as [x*scale + shift > 0] (valid when no residual was added), which
+    saves re-reading the activation tensor in both backward passes.
 
     Returns (dx, dz) where dz = dy*[out>0] (only materialised when want_dz).
     dgamma/dbeta are written into the given fp32 gradient views (may be None for lockGammaBeta).
@@ -148,14 +150,16 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
         ws = _workspace(C, x2d.device)
         direct = (dbeta_out is None or (dbeta_out.is_contiguous() and dbeta_out.dtype == torch.float32)) and \
                  (dgamma_out is None or (dgamma_out.is_contiguous() and dgamma_out.dtype == torch.float32))
-        L.check(h.dl4j_bn_bwd_reduce(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(ws),
-                                     L.ptr(sums), L.ptr(dbeta_out if direct else None),
+        ms, mt = mask_coeffs if (mask_coeffs is not None and out2d is None) else (None, None)
+        L.check(h.dl4j_bn_bwd_reduce(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(ms), L.ptr(mt),
+                                     L.ptr(ws), L.ptr(sums), L.ptr(dbeta_out if direct else None),
                                      L.ptr(dgamma_out if direct else None), L.c_int64(M), L.c_int(C), dt, L.stream()),
                 "bn_bwd_reduce")
         dx = torch.empty_like(x2d)
         dz = torch.empty_like(x2d) if want_dz else None
         L.check(h.dl4j_bn_bwd_dx(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-                                 L.ptr(sums), L.ptr(dx), L.ptr(dz), L.c_int64(M), L.c_int(C), dt, L.stream()),
+                                 L.ptr(sums), L.ptr(ms), L.ptr(mt), L.ptr(dx), L.ptr(dz), L.c_int64(M), L.c_int(C), dt,
+                                 L.stream()),
                 "bn_bwd_dx")
         if not direct:
             if dbeta_out is not None:
@@ -167,6 +171,8 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
     xf, dz = x2d.to(cd), dy2d.to(cd)
     if out2d is not None:
         dz = dz * (out2d > 0).to(cd)
+    elif mask_coeffs is not None:
+        dz = dz * ((xf * mask_coeffs[0].to(cd) + mask_coeffs[1].to(cd)) > 0).to(cd)
     xhat = (xf - mean.to(cd)) * invstd.to(cd)
     dbeta = dz.sum(0)
     dgamma = (dz * xhat).sum(0)

@@ -46,7 +46,7 @@ def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False):
 
 
 def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=True, need_db=False, w_dgrad=None,
-                    dw_out=None):
+                    dw_out=None, dx_accum=None):
     """Returns (dx, dW, db); dW has logical shape [nOut, nIn, kH, kW] — or None when it was written
     straight into ``dw_out`` (fp32 gradient view) by the HIP wgrad kernel."""
     if _hip_eligible(x, w, stride, padding, dilation) and dz.dtype == torch.bfloat16:
@@ -58,15 +58,22 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
             dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out)
         if need_dx:
             if w_dgrad is not None and IG.dgrad_supported(w, stride, padding):
-                dx = IG.dgrad(dz, x.shape, w_dgrad, stride, padding, dilation)
+                acc = dx_accum if IG.accum_ok(dx_accum, x.shape) else None
+                dx = IG.dgrad(dz, x.shape, w_dgrad, stride, padding, dilation, accum_into=acc)
+                if dx_accum is not None and acc is None:
+                    dx = dx_accum + dx
             else:
                 dx = torch.ops.aten.convolution_backward(
                     dz.contiguous(memory_format=torch.channels_last), x, w, None, list(stride), list(padding),
                     list(dilation), False, [0, 0], 1, [True, False, False])[0]
+                if dx_accum is not None:
+                    dx = dx_accum + dx
         return dx, dW, db
     if x.is_cuda and not dz.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last):
         dz = dz.contiguous(memory_format=torch.channels_last)
     dx, dw, db = torch.ops.aten.convolution_backward(
         dz, x, w, [w.shape[0]] if need_db else None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
         [bool(need_dx), bool(need_dw), bool(need_db)])
+    if dx_accum is not None and dx is not None:
+        dx = dx_accum + dx
     return dx, dw, db

@@ -62,7 +62,7 @@ def _out_hw(H, W, R, S, stride, padding, dilation):
     return OH, OW
 
 
-def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M):
+def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False):
     tile = pick_tile(M, Kout)
     stats = None
     mt = int(L.hip().dl4j_igemm_mtiles(L.c_int64(M), L.c_int(tile)))
@@ -70,7 +70,7 @@ def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M):
         stats = _ws(mt * 2 * Kout, x_t.device, "igemm_stats")
     g = (ctypes.c_int * 19)(*geom)
     L.check(L.hip().dl4j_igemm_conv(L.ptr(x_t), L.ptr(w_t), L.ptr(y_t), L.ptr(bias), L.ptr(stats), g, L.c_int(tile),
-                                    None, L.stream()), "igemm_conv")
+                                    L.c_int(1 if accum else 0), None, L.stream()), "igemm_conv")
     if not want_stats:
         return None
     sums = torch.empty(2 * Kout, device=x_t.device, dtype=torch.float32)
@@ -100,24 +100,34 @@ def dgrad_supported(w, stride, padding):
     return R == 1 and S == 1 and tuple(padding) == (0, 0)
 
 
-def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation):
-    """dx for y = conv(x, w). ``w_dgrad``: [C][R][S][K] spatially flipped filters (bf16, contiguous)."""
+def accum_ok(t, x_shape):
+    """Can ``t`` (an already produced gradient for the same tensor) be accumulated into in place by the dgrad epilogue?"""
+    return (t is not None and t.dtype == torch.bfloat16 and tuple(t.shape) == tuple(x_shape) and t.dim() == 4
+            and t.is_contiguous(memory_format=torch.channels_last) and t.data_ptr() % 16 == 0)
+
+
+def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation, accum_into=None):
+    """dx for y = conv(x, w). ``w_dgrad``: [C][R][S][K] spatially flipped filters (bf16, contiguous).
+    ``accum_into``: existing gradient tensor for x (see accum_ok); the epilogue adds into it in place and it is returned."""
     N, C, H, W = x_shape
     _, K, OH, OW = dz.shape
     R, S = w_dgrad.shape[1], w_dgrad.shape[2]
     if not dz.is_contiguous(memory_format=torch.channels_last):
         dz = dz.contiguous(memory_format=torch.channels_last)
+    acc = accum_into is not None
     if tuple(stride) == (1, 1):
-        dx = torch.empty((N, C, H, W), device=dz.device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+        dx = accum_into if acc else torch.empty((N, C, H, W), device=dz.device, dtype=torch.bfloat16,
+                                                memory_format=torch.channels_last)
         ph = (R - 1) * dilation[0] - padding[0]
         pw = (S - 1) * dilation[1] - padding[1]
         geom = (N, OH, OW, K, H, W, C, R, S, 1, 1, ph, pw, dilation[0], dilation[1], H, W, 1, 1)
-        _launch(dz, w_dgrad, dx, None, geom, False, C, N * H * W)
+        _launch(dz, w_dgrad, dx, None, geom, False, C, N * H * W, accum=acc)
         return dx
-    # 1x1 strided: rows scatter into a zeroed dx
-    dx = torch.empty((N, C, H, W), device=dz.device, dtype=torch.bfloat16, memory_format=torch.channels_last).zero_()
+    # 1x1 strided: rows scatter into a zeroed dx (or add into the positions they hit of an existing gradient)
+    dx = accum_into if acc else torch.empty((N, C, H, W), device=dz.device, dtype=torch.bfloat16,
+                                            memory_format=torch.channels_last).zero_()
     geom = (N, OH, OW, K, OH, OW, C, 1, 1, 1, 1, 0, 0, 1, 1, H, W, stride[0], stride[1])
-    _launch(dz, w_dgrad, dx, None, geom, False, C, N * OH * OW)
+    _launch(dz, w_dgrad, dx, None, geom, False, C, N * OH * OW, accum=acc)
     return dx
 
 

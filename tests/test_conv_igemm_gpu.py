@@ -61,6 +61,13 @@ def test_dgrad(case):
     dx = IG.dgrad(dz, x.shape, w_dgrad, (s, s), (p, p), (d, d))
     err = (dx.float() - ref_dx).abs().max().item()
     assert err < 2e-2 * max(1.0, ref_dx.abs().max().item()), err
+    # accumulate epilogue: an existing gradient for the same tensor is updated in place (graph fan-out points)
+    prev = torch.randn(x.shape, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    assert IG.accum_ok(prev, x.shape)
+    want = (prev.float() + dx.float()).bfloat16()
+    got = IG.dgrad(dz, x.shape, w_dgrad, (s, s), (p, p), (d, d), accum_into=prev)
+    assert got.data_ptr() == prev.data_ptr()
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("case", CASES)

@@ -56,6 +56,13 @@ def test_batchnorm_forward_backward(dtype, M, C):
     assert torch.allclose(dg.cpu(), dgr, atol=t * (M ** 0.5), rtol=2e-2)
     assert torch.allclose(dz.float().cpu(), dzr, atol=1e-6, rtol=1e-6)
     assert torch.allclose(dx.float().cpu(), dxr, atol=t, rtol=5e-2)
+    # ReLU mask recomputed from x (no residual): must equal the result obtained with the stored output as mask
+    y1 = BN.apply(x, scale, shift, None, None, None, True)
+    dg1, db1, dg2, db2 = (torch.empty(C, device=dev()) for _ in range(4))
+    dxa, _ = BN.backward(x, dy, y1, mean, invstd, gamma, dg1, db1)
+    dxb, dzb = BN.backward(x, dy, None, mean, invstd, gamma, dg2, db2, want_dz=True, mask_coeffs=(scale, shift))
+    assert torch.equal(dxa, dxb) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    assert torch.equal(dzb, torch.where(y1 > 0, dy, torch.zeros_like(dy)))
 
 
 @pytest.mark.parametrize("kind", ["NoOp", "Sgd", "Nesterovs", "Adam", "RmsProp", "AdaGrad", "AdaDelta", "AdaMax", "Nadam",
