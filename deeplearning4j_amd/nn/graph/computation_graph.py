@@ -217,8 +217,8 @@ class ComputationGraph(BaseNetwork):
                     if len(other) != 1:
                         continue
                     o = other[0]
-                    if o in fused_away:
-                        continue
+                    if o in fused_away and fused_away[o] != o:
+                        continue            # o is interior to another fused node (not materialised); a fused node's *output* is fine
                     bn2 = None
                     in2 = o
                     if o in impls and is_plain_bn(o) and single(o):
