@@ -35,6 +35,8 @@ struct IGemmP {
   int OHs, OWs, oys, oxs;  // physical output tensor spatial dims and pixel strides (scatter for strided dgrad)
   int M;              // N*OH*OW
   int mtiles, ntiles;
+  int nbuf;           // LDS stages: 2 (double buffered) or 1 when the reduction is a single 64-wide tile (1x1 conv, C = 64):
+                      // halves the LDS footprint so twice as many workgroups are resident to hide the load latency
   int accum;          // 1: y += result (in-place gradient accumulation at graph fan-out points, saves a separate add pass)
 };
 
@@ -50,7 +52,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   constexpr int PITCH_C = BN * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
-  char* sB = smem + 2 * BM * 128;
+  char* sB = smem + p.nbuf * BM * 128;
 
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = lid / p.ntiles, nt = lid - mt * p.ntiles;
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   __syncthreads();
   const int l31 = lane & 31, lh = lane >> 5;
   for (int t = 0; t < KT; ++t) {
-    const int cur = t & 1;
+    const int cur = t & (p.nbuf - 1);
     if (t + 1 < KT) gload(t + 1);
     const char* cA = sA + cur * (BM * 128);
     const char* cB = sB + cur * (BN * 128);
@@ -208,11 +210,16 @@ template <int BM, int BN>
 static int launch_fwd(IGemmP& p, hipStream_t st) {
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = p.K / BN;
-  const int smem = 2 * (BM + BN) * 128;
+  const int KT = p.R * p.S * (p.C >> 6);
+  p.nbuf = KT == 1 ? 1 : 2;
+  constexpr int PITCH_C = BN * 2 + 16;
+  constexpr int epi = ((BM * PITCH_C + 255) & ~255) + 4 * BN * (int)sizeof(float);   // epilogue staging (C tile + stat partials)
+  int smem = p.nbuf * (BM + BN) * 128;
+  if (smem < epi) smem = epi;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * 128 > epi ? 2 * (BM + BN) * 128 : epi);
     attr_set = true;
   }
   hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
