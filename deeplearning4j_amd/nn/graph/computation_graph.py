@@ -189,8 +189,7 @@ class ComputationGraph(BaseNetwork):
 
         def is_plain_bn(n):
             l = impls.get(n)
-            return (isinstance(l, BatchNormalizationImpl) and isinstance(l.conf.activationFn, (ActivationIdentity, type(None)))
-                    and l.conf.idropout is None and conf.vertices[n].preProcessor is None)
+            return isinstance(l, BatchNormalizationImpl) and l.conf.idropout is None and conf.vertices[n].preProcessor is None
 
         for impl in impls.values():
             if isinstance(impl, ConvolutionLayerImpl):

@@ -316,8 +316,9 @@ class BatchNormalizationImpl(LayerImpl):
             r2, _ = self._to2d(residual)
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
-        act = self.conf.activationFn
-        fuse_relu = relu or isinstance(act, ActivationReLU)
+        # the reference layer never applies its configured activation (BatchNormalization.java:379 activate() == preOutput);
+        # ReLU only comes from the graph fusion planner
+        fuse_relu = relu
         rs, rt = res_coeffs if res_coeffs is not None else (None, None)
         y2 = BN.apply(x2, scale, shift, r2, rs, rt, fuse_relu)
         if train:
@@ -327,11 +328,7 @@ class BatchNormalizationImpl(LayerImpl):
             self._out2 = y2 if (fuse_relu and residual is not None) else None
             self._mask_coeffs = (scale, shift) if (fuse_relu and residual is None) else None
             self._want_dz = residual is not None
-        if not fuse_relu and act is not None and not isinstance(act, ActivationIdentity):
-            self._z2 = y2
-            y2 = act.forward(y2, train)
-        else:
-            self._z2 = None
+        self._z2 = None
         return self._from2d(y2, shp)
 
     def backward(self, eps, return_dz=False):
@@ -340,8 +337,6 @@ class BatchNormalizationImpl(LayerImpl):
             d2 = d2.contiguous()
         if d2.dtype != self._x2.dtype:
             d2 = d2.to(self._x2.dtype)
-        if self._z2 is not None:
-            d2 = self.conf.activationFn.backprop(self._z2, d2)
         gamma = self.params["gamma"].reshape(-1) if "gamma" in self.params else None
         dg = self.grads["gamma"].reshape(-1) if "gamma" in self.grads else None
         db = self.grads["beta"].reshape(-1) if "beta" in self.grads else None

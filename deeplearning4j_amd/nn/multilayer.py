@@ -73,8 +73,7 @@ class MultiLayerNetwork(BaseNetwork):
             l = self.layers[i]
             if (isinstance(l, BatchNormalizationImpl) and i + 1 < n and isinstance(self.layers[i + 1], ActivationLayerImpl)
                     and isinstance(self.layers[i + 1].conf.activationFn, ActivationReLU) and (i + 1) not in pre
-                    and self.layers[i + 1].conf.idropout is None
-                    and isinstance(l.conf.activationFn, (ActivationIdentity, type(None)))):
+                    and self.layers[i + 1].conf.idropout is None):
                 plan.append(("bn_relu", i))
                 i += 2
                 continue
