@@ -6,8 +6,12 @@ captured once into hipGraphs and replayed: launch overhead disappears and the GP
 back-to-back kernels. Everything the iteration reads that changes between steps lives in device
 memory (input/label staging buffers, updater iteration counter, learning-rate segment table).
 
-Data-parallel mode splits the capture in two (A = forward+backward, B = fused update) with the
-RCCL gradient all-reduce issued eagerly between the replays on the same stream.
+Data-parallel mode splits the capture: A = forward+backward, B = fused update, with the RCCL
+gradient all-reduce issued eagerly between the replays. When the wrapper provides gradient buckets
+(``net._dp_buckets``) A itself is cut into segments at the points of backward where a bucket of the
+flat gradient vector becomes final: after replaying segment k the bucket's all-reduce is launched on
+the communication stream and runs over xGMI while segment k+1 computes — the same overlap the eager
+path gets from the backward-progress hook, without giving up graph replay.
 """
 from __future__ import annotations
 
@@ -19,6 +23,7 @@ class CapturedTrainStep:
         self.net = net
         self.warmup = warmup
         self.graph_a = self.graph_b = None
+        self.segments = None
         self._x = self._y = None
         self._seen = 0
         self._sig = None
@@ -51,17 +56,70 @@ class CapturedTrainStep:
                 net._on_backward_progress = hook
                 net._apply_update(net._last_batch)
                 return
-            net._on_backward_progress = None   # overlap hooks cannot run inside a captured region
             # thread_local: the RCCL watchdog thread's event queries must not invalidate the capture
             torch.cuda.synchronize()
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                self._compute(self._x, self._y)
+            buckets = getattr(net, "_dp_buckets", None)
+            if buckets is not None and net._grad_sync is not None:
+                self.segments = self._capture_segmented(buckets)
+                ga = self.segments[0][0]
+            else:
+                net._on_backward_progress = None   # eager overlap hooks cannot run inside a captured region
+                self.segments = None
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                    self._compute(self._x, self._y)
             gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
                 net._apply_update(net._last_batch, sync=False)
             self.graph_a, self.graph_b = ga, gb
-        self.graph_a.replay()
-        if net._grad_sync is not None:
-            net._grad_sync()
+        if self.segments is not None:
+            buckets = net._dp_buckets
+            buckets.begin()
+            for g, nb in self.segments:
+                g.replay()
+                if nb:
+                    buckets.launch_next(nb)
+            buckets.finish()
+        else:
+            self.graph_a.replay()
+            if net._grad_sync is not None:
+                net._grad_sync()
         self.graph_b.replay()
+
+    def _capture_segmented(self, buckets):
+        """Capture forward+backward as a chain of graphs cut where gradient buckets become final.
+
+        Returns [(graph, n_buckets_ready_after_it), ...]; all graphs share one memory pool and are replayed in capture order."""
+        net = self.net
+        segs = []
+        state = {"g": None, "pool": torch.cuda.graph_pool_handle(), "launched": 0}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=state["pool"], capture_error_mode="thread_local")
+            state["g"] = g
+
+        def progress(min_done_offset):
+            nb = buckets.count_ready(min_done_offset) - state["launched"]
+            if nb > 0:
+                state["g"].capture_end()
+                segs.append((state["g"], nb))
+                state["launched"] += nb
+                begin()
+
+        hook, begin_hook = net._on_backward_progress, net._on_backward_begin
+        net._on_backward_progress, net._on_backward_begin = progress, None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(side):
+                begin()
+                try:
+                    self._compute(self._x, self._y)
+                finally:
+                    state["g"].capture_end()
+                segs.append((state["g"], 0))
+        finally:
+            net._on_backward_progress, net._on_backward_begin = hook, begin_hook
+        torch.cuda.current_stream().wait_stream(side)
+        return segs

@@ -63,6 +63,7 @@ class BaseNetwork:
         self._grad_sync = None              # DP hook: called between backward and update
         self._on_backward_progress = None   # DP overlap hook: lowest finished gradient offset
         self._on_backward_begin = None
+        self._dp_buckets = None             # DP: GradientBuckets for the segmented HIP-graph capture
 
     # ------------------------------------------------------------------ to be provided by subclasses
     def _ordered_layers(self) -> List[LayerImpl]:

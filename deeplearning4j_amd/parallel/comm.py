@@ -131,6 +131,22 @@ class GradientBuckets:
             self._launch(self._next)
             self._next -= 1
 
+    def count_ready(self, min_done_offset: int) -> int:
+        """Number of buckets (counted from the tail) whose range lies entirely at or above ``min_done_offset``."""
+        n = 0
+        for s, _ in reversed(self.ranges):
+            if s < min_done_offset:
+                break
+            n += 1
+        return n
+
+    def launch_next(self, n: int = 1):
+        """Launch the next ``n`` buckets in tail-to-head order (captured-graph path: readiness was decided at capture time)."""
+        while n > 0 and self._next >= 0:
+            self._launch(self._next)
+            self._next -= 1
+            n -= 1
+
     def _launch(self, k):
         s, e = self.ranges[k]
         seg = self.flat[s:e]

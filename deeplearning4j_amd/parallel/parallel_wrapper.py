@@ -94,6 +94,7 @@ class ParallelWrapper:
             if overlap and self.world > 1:
                 model._on_backward_progress = self.buckets.ready
                 model._on_backward_begin = self.buckets.begin
+                model._dp_buckets = self.buckets      # lets the HIP-graph step cut its capture at bucket boundaries
 
     # gradient sharing
     def _sync_gradients(self):
@@ -143,6 +144,7 @@ class ParallelWrapper:
     def shutdown(self):
         self.model._grad_sync = None
         self.model._on_backward_progress = None
+        self.model._dp_buckets = None
 
     close = shutdown
 
