@@ -24,6 +24,7 @@ class CapturedTrainStep:
         self.warmup = warmup
         self.graph_a = self.graph_b = None
         self.segments = None
+        self._cap_stream = None
         self._x = self._y = None
         self._seen = 0
         self._sig = None
@@ -66,10 +67,10 @@ class CapturedTrainStep:
                 net._on_backward_progress = None   # eager overlap hooks cannot run inside a captured region
                 self.segments = None
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                with torch.cuda.graph(ga, stream=self._capture_stream(), capture_error_mode="thread_local"):
                     self._compute(self._x, self._y)
             gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(gb, pool=ga.pool(), stream=self._capture_stream(), capture_error_mode="thread_local"):
                 net._apply_update(net._last_batch, sync=False)
             self.graph_a, self.graph_b = ga, gb
         if self.segments is not None:
@@ -86,6 +87,11 @@ class CapturedTrainStep:
                 net._grad_sync()
         self.graph_b.replay()
 
+    def _capture_stream(self):
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream()
+        return self._cap_stream
+
     def _capture_segmented(self, buckets):
         """Capture forward+backward as a chain of graphs cut where gradient buckets become final.
 
@@ -100,7 +106,8 @@ class CapturedTrainStep:
             state["g"] = g
 
         def progress(min_done_offset):
-            nb = buckets.count_ready(min_done_offset) - state["launched"]
+            # the head bucket is never worth a cut: nothing is left to overlap it with (finish() launches it)
+            nb = min(buckets.count_ready(min_done_offset), len(buckets.ranges) - 1) - state["launched"]
             if nb > 0:
                 state["g"].capture_end()
                 segs.append((state["g"], nb))
@@ -109,7 +116,7 @@ class CapturedTrainStep:
 
         hook, begin_hook = net._on_backward_progress, net._on_backward_begin
         net._on_backward_progress, net._on_backward_begin = progress, None
-        side = torch.cuda.Stream()
+        side = self._capture_stream()
         side.wait_stream(torch.cuda.current_stream())
         try:
             with torch.cuda.stream(side):

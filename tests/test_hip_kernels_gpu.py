@@ -190,18 +190,17 @@ def test_lenet_bf16_graph_capture_trains():
     assert net.getIterationCount() == 61
 
 
-def test_segmented_graph_capture_matches_single_graph():
+def test_segmented_graph_capture_matches_eager():
     """DP overlap path: forward+backward captured as a chain of graphs cut at gradient-bucket boundaries
-    (world size 1, so the bucket launches are no-ops) must train exactly like the single-graph capture."""
+    (world size 1, so the bucket launches are no-ops) must produce the gradients of the eager step, replay after replay."""
     from tests.test_networks_cpu import _onehot
     from deeplearning4j_amd.models.resnet50 import ResNet50
     from deeplearning4j_amd.parallel.comm import GradientBuckets
     from deeplearning4j_amd.nd4j.learning import Sgd
-    # plain SGD: RmsProp's g/sqrt(v) turns wgrad atomics round-off into sign flips, which would hide a real mismatch
-    m = ResNet50(numClasses=5, inputShape=(3, 160, 160), computeDataType="BFLOAT16", updater=Sgd(1e-2))
-    a = m.init(device=dev())
+    # lr 0: weights stay put, so every iteration must reproduce the same gradient (BN running-stat slots aside)
+    m = ResNet50(numClasses=5, inputShape=(3, 160, 160), computeDataType="BFLOAT16", updater=Sgd(0.0))
+    a = m.init(device=dev())            # eager reference
     b = m.init(device=dev())
-    a.enableGraphCapture(True)
     b.enableGraphCapture(True)
     buckets = GradientBuckets(b._grads, 8 << 20)
     launched = []
@@ -211,17 +210,21 @@ def test_segmented_graph_capture_matches_single_graph():
     b._grad_sync = buckets.reduce_all
     x = torch.rand(8, 3, 160, 160, device=dev())
     y = _onehot(8, 5).float().to(dev())
-    for _ in range(6):
-        a.fit(x, y)
+    a.computeGradientAndScore([x], [y])
+    g_ref, s_ref = a._grads.clone(), float(a._score)
+    wmask = torch.zeros_like(g_ref, dtype=torch.bool)       # weight / bias / gamma / beta slots (running stats drift with decay)
+    for e in a._entries:
+        if e.spec.role != "stat":
+            wmask[e.off:e.off + e.spec.numel] = True
+    for it in range(7):
         b.fit(x, y)
+        if it >= 3:
+            assert b._graph_step.segments is not None
+            rel = ((b._grads - g_ref)[wmask]).norm() / g_ref[wmask].norm()
+            assert rel < 2e-2, (it, float(rel))
+            assert abs(float(b._score) - s_ref) < 1e-2 * abs(s_ref)
     segs = b._graph_step.segments
-    assert segs is not None and len(segs) >= 3, "capture was not segmented"
-    assert sum(nb for _, nb in segs) <= len(buckets.ranges)
+    assert len(segs) >= 3, "capture was not segmented"
     # every bucket launched exactly once per replayed iteration, tail first
     per_iter = launched[-len(buckets.ranges):]
     assert per_iter == list(range(len(buckets.ranges) - 1, -1, -1))
-    p0 = m.init(device=dev()).params()
-    da, db = a.params() - p0, b.params() - p0
-    rel = (da - db).norm() / da.norm()
-    assert da.norm() > 0 and rel < 5e-2, float(rel)
-    assert abs(a.score() - b.score()) < 2e-2 * max(1.0, abs(a.score()))
