@@ -38,7 +38,8 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU", file=sys.stderr)
         sys.exit(2)
-    if world > 1:
+    force_dp = os.environ.get("DL4J_AMD_FORCE_COLLECTIVES") == "1"      # 1-GPU rehearsal of the DP code path (debug only)
+    if world > 1 or force_dp:
         comm.init_process_group("nccl")
     rank = comm.rank()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -50,7 +51,7 @@ def main():
     net = model.init(device=dev)
     if not args.no_graph:
         net.enableGraphCapture(True)
-    pw = ParallelWrapper.Builder(net).build() if world > 1 else None
+    pw = ParallelWrapper.Builder(net).build() if (world > 1 or force_dp) else None
 
     it = BenchmarkDataSetIterator([args.batch, 3, args.image, args.image], args.classes, 1, device=dev, seed=1234 + rank)
     ds = it.next()
@@ -83,7 +84,7 @@ def main():
                        "per_gpu_batch": args.batch, "image": "3x%dx%d" % (args.image, args.image), "classes": args.classes,
                        "updater": "RmsProp(0.1,0.96,0.001)+l1 1e-7+l2 5e-5", "parallelism": "dp%d" % world,
                        "hip_graph": not args.no_graph, "final_score": round(float(score), 4)}}))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

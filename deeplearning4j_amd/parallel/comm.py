@@ -58,9 +58,14 @@ def broadcast_(t: torch.Tensor, src=0):
     return t
 
 
+def _forced():
+    """DL4J_AMD_FORCE_COLLECTIVES=1: issue the collectives even at world size 1 (single-GPU rehearsal of the RCCL call pattern)."""
+    return os.environ.get("DL4J_AMD_FORCE_COLLECTIVES") == "1" and dist.is_initialized()
+
+
 def all_reduce_avg_(t: torch.Tensor, async_op=False):
     """In-place average across ranks."""
-    if world_size() == 1:
+    if world_size() == 1 and not _forced():
         return None
     if dist.get_backend() == "nccl":
         return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)

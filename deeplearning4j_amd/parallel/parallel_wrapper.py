@@ -91,14 +91,14 @@ class ParallelWrapper:
         self._local_iters = 0
         if trainingMode == TrainingMode.SHARED_GRADIENTS:
             model._grad_sync = self._sync_gradients
-            if overlap and self.world > 1:
+            if overlap and (self.world > 1 or comm._forced()):
                 model._on_backward_progress = self.buckets.ready
                 model._on_backward_begin = self.buckets.begin
                 model._dp_buckets = self.buckets      # lets the HIP-graph step cut its capture at bucket boundaries
 
     # gradient sharing
     def _sync_gradients(self):
-        if self.world == 1:
+        if self.world == 1 and not comm._forced():
             return
         if (self.overlap and getattr(self.model, "_on_backward_progress", None) is not None
                 and self.model._graph_step is None):
