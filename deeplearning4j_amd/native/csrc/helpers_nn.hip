@@ -1,0 +1,293 @@
+// Declarable-op helper kernels, nn family (gfx950): softmax / log-softmax backward, layer norm fwd+bwd,
+// channel bias add, Philox dropout, LRN, PReLU, clip-by-norm.
+//
+// Reference counterparts (libnd4j/include/ops/declarable/helpers/cuda): activations.cu (softMaxCuda + derivative,
+// prelu), addBias.cu, dropout.cu, lrn.cu, clip.cu, and the layer_norm composition (generic/nn/layer_norm.cpp:
+// standardize + mul + add as three passes). Own design: rows are reduced with 64-lane shuffles (one wave per
+// row for short rows, 4 waves for long ones) instead of shared-memory trees; layer norm is one pass forward and
+// a dx pass + a partial column reduction backward; dropout draws 4 uniforms per Philox block so a wave fills
+// 256 elements per round without any RNG state in memory.
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+// ------------------------------------------------------------------ softmax / log-softmax backward
+// dx = y * (g - sum(g*y))            (softmax, y = softmax(x) recomputed from x)
+// dx = g - softmax(x) * sum(g)       (log-softmax)
+template <typename T>
+__global__ void softmax_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ dx, int64_t rows, int cols,
+                                   int is_log) {
+  __shared__ float red[16];
+  const int64_t r = blockIdx.x;
+  if (r >= rows) return;
+  const T* xr = x + r * cols;
+  const T* gr = g + r * cols;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) mx = fmaxf(mx, Cvt<T>::ld(xr, c));
+  mx = block_max(mx, red);
+  float se = 0.f, sg = 0.f, sgy = 0.f;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const float e = __expf(Cvt<T>::ld(xr, c) - mx), gv = Cvt<T>::ld(gr, c);
+    se += e; sg += gv; sgy += gv * e;
+  }
+  se = block_sum(se, red);
+  sg = block_sum(sg, red);
+  sgy = block_sum(sgy, red);
+  const float inv = 1.f / se;
+  sgy *= inv;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const float y = __expf(Cvt<T>::ld(xr, c) - mx) * inv, gv = Cvt<T>::ld(gr, c);
+    Cvt<T>::st(dx + r * cols, c, is_log ? gv - y * sg : y * (gv - sgy));
+  }
+}
+
+// ------------------------------------------------------------------ layer norm
+template <typename T>
+__global__ void layer_norm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int cols,
+                                      float eps) {
+  __shared__ float red[16];
+  const int64_t r = blockIdx.x;
+  if (r >= rows) return;
+  const T* xr = x + r * cols;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) s += Cvt<T>::ld(xr, c);
+  const float mu = block_sum(s, red) / cols;
+  float v = 0.f;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) { const float d = Cvt<T>::ld(xr, c) - mu; v += d * d; }
+  const float rs = rsqrtf(block_sum(v, red) / cols + eps);
+  if (threadIdx.x == 0) { if (mean) mean[r] = mu; if (rstd) rstd[r] = rs; }
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    float o = (Cvt<T>::ld(xr, c) - mu) * rs;
+    if (gamma) o *= gamma[c];
+    if (beta) o += beta[c];
+    Cvt<T>::st(y + r * cols, c, o);
+  }
+}
+
+template <typename T>
+__global__ void layer_norm_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ gamma,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
+                                         int64_t rows, int cols) {
+  __shared__ float red[16];
+  const int64_t r = blockIdx.x;
+  if (r >= rows) return;
+  const T* xr = x + r * cols;
+  const T* gr = g + r * cols;
+  const float mu = mean[r], rs = rstd[r];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const float gg = Cvt<T>::ld(gr, c) * (gamma ? gamma[c] : 1.f), xh = (Cvt<T>::ld(xr, c) - mu) * rs;
+    s1 += gg; s2 += gg * xh;
+  }
+  s1 = block_sum(s1, red) / cols;
+  s2 = block_sum(s2, red) / cols;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const float gg = Cvt<T>::ld(gr, c) * (gamma ? gamma[c] : 1.f), xh = (Cvt<T>::ld(xr, c) - mu) * rs;
+    Cvt<T>::st(dx + r * cols, c, rs * (gg - s1 - xh * s2));
+  }
+}
+
+// partial[gy][2][cols]: row 0 = sum g*xhat (dgamma), row 1 = sum g (dbeta); finished by dl4j_bn_sum_partials
+template <typename T>
+__global__ void layer_norm_bwd_param_kernel(const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd, float* __restrict__ partial, int64_t rows, int cols,
+                                            int64_t rows_per_block) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float dg = 0.f, db = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float gv = Cvt<T>::ld(g, r * cols + c);
+    dg += gv * (Cvt<T>::ld(x, r * cols + c) - mean[r]) * rstd[r];
+    db += gv;
+  }
+  partial[((int64_t)blockIdx.y * 2) * cols + c] = dg;
+  partial[((int64_t)blockIdx.y * 2 + 1) * cols + c] = db;
+}
+
+// ------------------------------------------------------------------ bias add: channel = (i / inner) % C
+template <typename T>
+__global__ void bias_add_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y, int64_t n, int C,
+                                int64_t inner) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = inner == 1 ? (int)(i % C) : (int)((i / inner) % C);
+    Cvt<T>::st(y, i, Cvt<T>::ld(x, i) + bias[c]);
+  }
+}
+
+// ------------------------------------------------------------------ dropout (inverted): keep with prob p, scale 1/p
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ mask, int64_t n, float p,
+                               float scale, uint64_t seed, uint64_t stream) {
+  const int64_t nblk = (n + 3) >> 2;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (int64_t)gridDim.x * blockDim.x) {
+    const philox::u4 r = philox::block((uint64_t)b, stream, seed);
+    const uint32_t bits[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = b * 4 + k;
+      if (i < n) {
+        const bool keep = philox::u01(bits[k]) < p;
+        Cvt<T>::st(y, i, keep ? Cvt<T>::ld(x, i) * scale : 0.f);
+        if (mask) mask[i] = keep ? 1 : 0;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void dropout_bwd_kernel(const T* __restrict__ g, const uint8_t* __restrict__ mask, T* __restrict__ dx, int64_t n,
+                                   float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Cvt<T>::st(dx, i, mask[i] ? Cvt<T>::ld(g, i) * scale : 0.f);
+}
+
+// ------------------------------------------------------------------ LRN across the innermost (channel) dim of [M, C] rows
+// y = x / (bias + alpha * sum_{c-d..c+d} x^2)^beta ; also emits the denominators' base for the backward
+template <typename T>
+__global__ void lrn_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ scale_out, int64_t M, int C, int depth,
+                               float bias, float alpha, float beta) {
+  const int64_t n = M * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t base = i - c;
+    const int lo = c - depth < 0 ? 0 : c - depth, hi = c + depth >= C ? C - 1 : c + depth;
+    float s = 0.f;
+    for (int k = lo; k <= hi; ++k) { const float v = Cvt<T>::ld(x, base + k); s += v * v; }
+    const float sc = bias + alpha * s;
+    if (scale_out) scale_out[i] = sc;
+    Cvt<T>::st(y, i, Cvt<T>::ld(x, i) * __powf(sc, -beta));
+  }
+}
+
+// ------------------------------------------------------------------ PReLU with per-channel alpha (channel = (i / inner) % C)
+template <typename T>
+__global__ void prelu_kernel(const T* __restrict__ x, const float* __restrict__ alpha, T* __restrict__ y, int64_t n, int C,
+                             int64_t inner) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = Cvt<T>::ld(x, i);
+    const int c = (int)((i / inner) % C);
+    Cvt<T>::st(y, i, v >= 0.f ? v : v * alpha[c]);
+  }
+}
+
+// ------------------------------------------------------------------ clip by (global) L2 norm: two kernels, no host round trip
+template <typename T>
+__global__ void sumsq_partial_kernel(const T* __restrict__ x, float* __restrict__ partial, int64_t n) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = Cvt<T>::ld(x, i);
+    s += v * v;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+template <typename T>
+__global__ void clip_scale_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ partial, int nparts, int64_t n,
+                                  float clip, float* __restrict__ norm_out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < nparts; k += blockDim.x) s += partial[k];     // kernel boundary made the partials visible
+  const float nrm = sqrtf(block_sum(s, red));
+  if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = nrm;
+  const float f = nrm > clip ? clip / nrm : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Cvt<T>::st(y, i, Cvt<T>::ld(x, i) * f);
+}
+
+inline int row_threads(int cols) { return cols <= 1024 ? 64 : 256; }
+
+}  // namespace
+
+#define DISPATCH_T(...)                          \
+  if (dtype == 1) { typedef bf16_t T; __VA_ARGS__ } \
+  else { typedef float T; __VA_ARGS__ }
+
+DL4J_API int dl4j_softmax_bwd_x(const void* x, const void* g, void* dx, int64_t rows, int cols, int is_log, int dtype, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return 0;
+  DISPATCH_T(hipLaunchKernelGGL(softmax_bwd_kernel<T>, dim3((unsigned)rows), dim3(row_threads(cols)), 0, st, (const T*)x, (const T*)g,
+                                (T*)dx, rows, cols, is_log);)
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_layer_norm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
+                                 int cols, float eps, int dtype, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return 0;
+  DISPATCH_T(hipLaunchKernelGGL(layer_norm_fwd_kernel<T>, dim3((unsigned)rows), dim3(row_threads(cols)), 0, st, (const T*)x, gamma, beta,
+                                (T*)y, mean, rstd, rows, cols, eps);)
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_layer_norm_bwd_rows(int64_t rows) {
+  int64_t gy = rows < 256 ? rows : 256;
+  return (int)(gy < 1 ? 1 : gy);
+}
+
+// partial must hold dl4j_layer_norm_bwd_rows(rows) * 2 * cols floats ([gy][2][cols]; finished by dl4j_bn_sum_partials)
+DL4J_API int dl4j_layer_norm_bwd(const void* x, const void* g, const float* gamma, const float* mean, const float* rstd, void* dx,
+                                 float* partial, int64_t rows, int cols, int dtype, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return 0;
+  const int gy = dl4j_layer_norm_bwd_rows(rows);
+  const int64_t rpb = (rows + gy - 1) / gy;
+  const dim3 pg((cols + 255) / 256, gy);
+  DISPATCH_T(
+      hipLaunchKernelGGL(layer_norm_bwd_dx_kernel<T>, dim3((unsigned)rows), dim3(row_threads(cols)), 0, st, (const T*)x, (const T*)g,
+                         gamma, mean, rstd, (T*)dx, rows, cols);
+      if (partial) hipLaunchKernelGGL(layer_norm_bwd_param_kernel<T>, pg, dim3(256), 0, st, (const T*)x, (const T*)g, mean, rstd, partial,
+                                      rows, cols, rpb);)
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_bias_add(const void* x, const float* bias, void* y, int64_t n, int C, int64_t inner, int dtype, hipStream_t st) {
+  if (n <= 0) return 0;
+  DISPATCH_T(hipLaunchKernelGGL(bias_add_kernel<T>, dim3(grid_for(n, 1024)), dim3(256), 0, st, (const T*)x, bias, (T*)y, n, C, inner);)
+  DL4J_RET_LAST();
+}
+
+// keep-probability p (DL4J convention); mask (optional, 1 byte/element) is what the backward needs
+DL4J_API int dl4j_dropout(const void* x, void* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t stream_id, int dtype,
+                          hipStream_t st) {
+  if (n <= 0) return 0;
+  const float scale = p > 0.f ? 1.f / p : 0.f;
+  DISPATCH_T(hipLaunchKernelGGL(dropout_kernel<T>, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, st, (const T*)x, (T*)y, mask, n, p,
+                                scale, seed, stream_id);)
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_dropout_bwd(const void* g, const uint8_t* mask, void* dx, int64_t n, float p, int dtype, hipStream_t st) {
+  if (n <= 0) return 0;
+  const float scale = p > 0.f ? 1.f / p : 0.f;
+  DISPATCH_T(hipLaunchKernelGGL(dropout_bwd_kernel<T>, dim3(grid_for(n, 1024)), dim3(256), 0, st, (const T*)g, mask, (T*)dx, n, scale);)
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_lrn_fwd(const void* x, void* y, float* scale_out, int64_t M, int C, int depth, float bias, float alpha, float beta,
+                          int dtype, hipStream_t st) {
+  if (M <= 0 || C <= 0) return 0;
+  DISPATCH_T(hipLaunchKernelGGL(lrn_fwd_kernel<T>, dim3(grid_for(M * C, 512)), dim3(256), 0, st, (const T*)x, (T*)y, scale_out, M, C,
+                                depth, bias, alpha, beta);)
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_prelu(const void* x, const float* alpha, void* y, int64_t n, int C, int64_t inner, int dtype, hipStream_t st) {
+  if (n <= 0) return 0;
+  DISPATCH_T(hipLaunchKernelGGL(prelu_kernel<T>, dim3(grid_for(n, 1024)), dim3(256), 0, st, (const T*)x, alpha, (T*)y, n, C, inner);)
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_clip_ws_floats() { return DL4J_MAX_GRID; }
+
+// y = x * min(1, clip / ||x||_2); partial_ws: dl4j_clip_ws_floats() floats; norm_out optional (device float)
+DL4J_API int dl4j_clip_by_norm(const void* x, void* y, float* partial_ws, int64_t n, float clip, float* norm_out, int dtype,
+                               hipStream_t st) {
+  if (n <= 0) return 0;
+  const int g = grid_for(n, 2048);
+  DISPATCH_T(hipLaunchKernelGGL(sumsq_partial_kernel<T>, dim3(g), dim3(256), 0, st, (const T*)x, partial_ws, n);
+             hipLaunchKernelGGL(clip_scale_kernel<T>, dim3(g), dim3(256), 0, st, (const T*)x, (T*)y, partial_ws, g, n, clip, norm_out);)
+  DL4J_RET_LAST();
+}

@@ -46,7 +46,7 @@ def _load_impls():
     global _LOADED
     if not _LOADED:
         _LOADED = True
-        from . import impl_core, impl_nn, impl_misc  # noqa: F401  (populate the registry)
+        from . import impl_core, impl_nn, impl_misc, impl_platform  # noqa: F401  (populate the registry)
 
 
 class OpDescriptor:

@@ -103,8 +103,10 @@ def _scatter(mat, idx, upd):
 
 def _train_batch(table: InMemoryLookupTable, l1, targets, alpha, hs, n_neg, gen, train_outputs=True):
     """l1: [B, D] input vectors; targets: [B] predicted word rows.  Returns neu1e [B, D]; updates syn1 / syn1neg in place."""
-    neu1e = torch.zeros_like(l1)
     D = l1.shape[1]
+    if l1.is_cuda and l1.dtype == torch.float32 and train_outputs:
+        return _train_batch_hip(table, l1.contiguous(), targets, alpha, hs, n_neg, gen)
+    neu1e = torch.zeros_like(l1)
     if hs is not None:
         codes, points, mask = hs
         pts, cds, msk = points[targets], codes[targets], mask[targets]               # [B, L]
@@ -129,6 +131,37 @@ def _train_batch(table: InMemoryLookupTable, l1, targets, alpha, hs, n_neg, gen,
         neu1e += torch.einsum("bk,bkd->bd", g, rows)
         if train_outputs:
             _scatter(table.syn1neg, tg.reshape(-1), (g.unsqueeze(2) * l1.unsqueeze(1)).reshape(-1, D))
+    return neu1e
+
+
+def _train_batch_hip(table, l1, targets, alpha, hs, n_neg, gen):
+    """GPU path: the fused skip-gram/CBOW kernel (native/csrc/helpers_data.hip sg_pairs_kernel; reference sg_cb.cu
+    hSoftmaxKernel / nSamplingKernel): one wave per (input, output row, label) triple does dot -> sigmoid -> both
+    gradients; output rows are updated with fp32 atomics as the triples retire (hogwild, like the reference), so no
+    duplicate damping is needed."""
+    from ..ops import helpers as H
+    B, D = l1.shape
+    neu1e = torch.zeros_like(l1)
+
+    def run(syn, tg, lab):
+        K = tg.shape[1]
+        hidden = l1.unsqueeze(1).expand(B, K, D).reshape(B * K, D).contiguous()
+        dh = H.sg_pairs_(table.syn0, syn, tg.reshape(-1), tg.reshape(-1).contiguous(), lab.reshape(-1).contiguous(), float(alpha),
+                         hidden=hidden)
+        return dh.view(B, K, D).sum(1)
+
+    if hs is not None:
+        codes, points, mask = hs
+        pts = torch.where(mask[targets] > 0, points[targets], torch.full_like(points[targets], -1))
+        neu1e += run(table.syn1, pts.long(), (1.0 - codes[targets]).float())
+    if n_neg > 0:
+        r = torch.rand(B, n_neg, device=l1.device, generator=gen)
+        negs = torch.searchsorted(table.neg_cdf(), r).clamp_(max=table.syn1neg.shape[0] - 1)
+        negs = torch.where(negs == targets.unsqueeze(1), torch.full_like(negs, -1), negs)   # word2vec skips a negative equal to the target
+        tg = torch.cat([targets.unsqueeze(1), negs], 1)
+        lab = torch.zeros(tg.shape, dtype=torch.float32, device=l1.device)
+        lab[:, 0] = 1
+        neu1e += run(table.syn1neg, tg.long(), lab)
     return neu1e
 
 

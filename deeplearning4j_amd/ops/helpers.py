@@ -1,0 +1,281 @@
+"""Python launchers for the declarable-helper HIP kernels (native/csrc/helpers_nn.hip, helpers_data.hip).
+
+Each function validates shapes / dtypes / contiguity on the host before the launch (a faulting kernel can take the
+whole GPU down) and returns new tensors. They are registered as ``@platform`` helpers of the matching custom ops in
+nd4j/ops/impl_platform.py — the same isUsable-then-invoke rule as the reference's PlatformHelper
+(ops/declarable/impl/DeclarableOp.cpp:692-739) — and are called directly by the layer implementations.
+Reference kernel families: libnd4j/include/ops/declarable/helpers/cuda/{activations,addBias,dropout,lrn,clip,gather,
+scatter,one_hot,prefix,im2col,col2im,convolutions_upsampling2d,merge,segment_sum,image_resize,sg_cb}.cu.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ..native import lib as L
+
+_F = (torch.float32, torch.bfloat16)
+
+
+def ok(t, dtypes=_F):
+    return L.use_hip(t) and t.dtype in dtypes and t.is_contiguous() and t.numel() > 0
+
+
+def _f32(t):
+    return None if t is None else t.reshape(-1).float().contiguous()
+
+
+def _idx_ok(i):
+    return i.is_cuda and i.dtype in (torch.int32, torch.int64) and i.is_contiguous()
+
+
+# ----------------------------------------------------------------------------- softmax family (any rank, last axis)
+def softmax_last(x, log=False):
+    from . import softmax as SM
+    return SM.softmax(x.reshape(-1, x.shape[-1]), log).reshape(x.shape)
+
+
+def softmax_bwd_last(x, g, log=False):
+    """dL/dx for y = (log_)softmax(x, -1) given dL/dy = g (y is recomputed from x inside the kernel)."""
+    cols = x.shape[-1]
+    dx = torch.empty_like(x)
+    L.check(L.hip().dl4j_softmax_bwd_x(L.ptr(x), L.ptr(g), L.ptr(dx), L.c_int64(x.numel() // cols), L.c_int(cols),
+                                       L.c_int(1 if log else 0), L.c_int(L.dtype_code(x)), L.stream()), "softmax_bwd_x")
+    return dx
+
+
+# ----------------------------------------------------------------------------- layer norm over the last axis
+def layer_norm(x, gamma=None, beta=None, eps=1e-5, want_stats=False):
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty_like(x)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    ga, be = _f32(gamma), _f32(beta)
+    assert ga is None or ga.numel() == cols
+    assert be is None or be.numel() == cols
+    L.check(L.hip().dl4j_layer_norm_fwd(L.ptr(x), L.ptr(ga), L.ptr(be), L.ptr(y), L.ptr(mean), L.ptr(rstd), L.c_int64(rows),
+                                        L.c_int(cols), L.c_float(eps), L.c_int(L.dtype_code(x)), L.stream()), "layer_norm_fwd")
+    return (y, mean, rstd) if want_stats else y
+
+
+def layer_norm_bwd(x, g, gamma, mean, rstd, want_param_grads=True):
+    """Returns (dx, dgamma, dbeta) — dgamma/dbeta fp32 [cols] (None unless want_param_grads)."""
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    dx = torch.empty_like(x)
+    ga = _f32(gamma)
+    partial = sums = None
+    gy = int(L.hip().dl4j_layer_norm_bwd_rows(L.c_int64(rows)))
+    if want_param_grads:
+        partial = torch.empty(gy * 2 * cols, device=x.device, dtype=torch.float32)
+        sums = torch.empty(2 * cols, device=x.device, dtype=torch.float32)
+    L.check(L.hip().dl4j_layer_norm_bwd(L.ptr(x), L.ptr(g), L.ptr(ga), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(partial),
+                                        L.c_int64(rows), L.c_int(cols), L.c_int(L.dtype_code(x)), L.stream()), "layer_norm_bwd")
+    if not want_param_grads:
+        return dx, None, None
+    L.check(L.hip().dl4j_bn_sum_partials(L.ptr(partial), L.c_int(gy), L.c_int(cols), L.ptr(sums), None, None, L.stream()),
+            "layer_norm_param_sums")
+    return dx, sums[:cols], sums[cols:]
+
+
+# ----------------------------------------------------------------------------- bias / prelu / lrn / clip / dropout
+def _channel_geom(x, channel_axis):
+    ax = channel_axis % x.dim()
+    inner = 1
+    for s in x.shape[ax + 1:]:
+        inner *= int(s)
+    return int(x.shape[ax]), inner
+
+
+def bias_add(x, bias, channel_axis=-1):
+    C, inner = _channel_geom(x, channel_axis)
+    b = _f32(bias)
+    assert b.numel() == C
+    y = torch.empty_like(x)
+    L.check(L.hip().dl4j_bias_add(L.ptr(x), L.ptr(b), L.ptr(y), L.c_int64(x.numel()), L.c_int(C), L.c_int64(inner),
+                                  L.c_int(L.dtype_code(x)), L.stream()), "bias_add")
+    return y
+
+
+def prelu(x, alpha, channel_axis=1):
+    C, inner = _channel_geom(x, channel_axis)
+    a = _f32(alpha)
+    assert a.numel() == C
+    y = torch.empty_like(x)
+    L.check(L.hip().dl4j_prelu(L.ptr(x), L.ptr(a), L.ptr(y), L.c_int64(x.numel()), L.c_int(C), L.c_int64(inner),
+                               L.c_int(L.dtype_code(x)), L.stream()), "prelu")
+    return y
+
+
+def lrn_last(x, depth, bias, alpha, beta, want_scale=False):
+    """LRN across the last (channel) axis of a contiguous tensor (channels_last activations viewed as [M, C])."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = torch.empty_like(x)
+    sc = torch.empty(x.shape, device=x.device, dtype=torch.float32) if want_scale else None
+    L.check(L.hip().dl4j_lrn_fwd(L.ptr(x), L.ptr(y), L.ptr(sc), L.c_int64(M), L.c_int(C), L.c_int(int(depth)), L.c_float(bias),
+                                 L.c_float(alpha), L.c_float(beta), L.c_int(L.dtype_code(x)), L.stream()), "lrn_fwd")
+    return (y, sc) if want_scale else y
+
+
+def clip_by_norm(x, clip, want_norm=False):
+    dev = x.device
+    ws = torch.empty(int(L.hip().dl4j_clip_ws_floats()), device=dev, dtype=torch.float32)     # stream-ordered scratch
+    y = torch.empty_like(x)
+    nrm = torch.empty(1, device=dev, dtype=torch.float32) if want_norm else None
+    L.check(L.hip().dl4j_clip_by_norm(L.ptr(x), L.ptr(y), L.ptr(ws), L.c_int64(x.numel()), L.c_float(clip), L.ptr(nrm),
+                                      L.c_int(L.dtype_code(x)), L.stream()), "clip_by_norm")
+    return (y, nrm) if want_norm else y
+
+
+def dropout(x, keep_prob, seed, stream_id=0, want_mask=True):
+    """Inverted dropout with DL4J's retain-probability convention; returns (y, uint8 mask)."""
+    y = torch.empty_like(x)
+    mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8) if want_mask else None
+    L.check(L.hip().dl4j_dropout(L.ptr(x), L.ptr(y), L.ptr(mask), L.c_int64(x.numel()), L.c_float(keep_prob),
+                                 ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.c_uint64(int(stream_id) & (2 ** 64 - 1)),
+                                 L.c_int(L.dtype_code(x)), L.stream()), "dropout")
+    return y, mask
+
+
+def dropout_bwd(g, mask, keep_prob):
+    assert mask.dtype == torch.uint8 and mask.numel() == g.numel() and mask.is_contiguous()
+    dx = torch.empty_like(g)
+    L.check(L.hip().dl4j_dropout_bwd(L.ptr(g), L.ptr(mask), L.ptr(dx), L.c_int64(g.numel()), L.c_float(keep_prob),
+                                     L.c_int(L.dtype_code(g)), L.stream()), "dropout_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------- indexed
+def gather_rows(table, idx):
+    """table [V, D] (any 1/2/4/8-byte dtype), idx int32/int64 of any shape -> [*idx.shape, D]."""
+    V, D = table.shape
+    out = torch.empty(tuple(idx.shape) + (D,), device=table.device, dtype=table.dtype)
+    L.check(L.hip().dl4j_gather_rows(L.ptr(table), L.ptr(idx), L.ptr(out), L.c_int64(idx.numel()), L.c_int(D), L.c_int64(V),
+                                     L.c_int(table.element_size()), L.c_int(1 if idx.dtype == torch.int64 else 0), L.stream()),
+            "gather_rows")
+    return out
+
+
+def scatter_add_rows_(table_f32, idx, src, alpha=1.0):
+    """table[idx[r]] += alpha * src[r] in place (fp32 table; duplicate indices accumulate)."""
+    V, D = table_f32.shape
+    assert table_f32.dtype == torch.float32 and table_f32.is_contiguous()
+    assert src.numel() == idx.numel() * D and src.dtype in _F and src.is_contiguous()
+    L.check(L.hip().dl4j_scatter_add_rows(L.ptr(src), L.ptr(idx), L.ptr(table_f32), L.c_int64(idx.numel()), L.c_int(D), L.c_int64(V),
+                                          L.c_float(alpha), L.c_int(L.dtype_code(src)),
+                                          L.c_int(1 if idx.dtype == torch.int64 else 0), L.stream()), "scatter_add_rows")
+    return table_f32
+
+
+def one_hot(idx, depth, on=1.0, off=0.0, dtype=torch.float32):
+    out = torch.empty(tuple(idx.shape) + (int(depth),), device=idx.device, dtype=dtype)
+    L.check(L.hip().dl4j_one_hot(L.ptr(idx), L.ptr(out), L.c_int64(idx.numel()), L.c_int(int(depth)), L.c_float(on), L.c_float(off),
+                                 L.c_int(L.dtype_code(out)), L.c_int(1 if idx.dtype == torch.int64 else 0), L.stream()), "one_hot")
+    return out
+
+
+def segment_sum(x, seg, num_segments):
+    """x [rows, ...] -> [num_segments, ...] (fp32 accumulate, cast back); ids outside [0, num_segments) are dropped."""
+    rows = x.shape[0]
+    D = x.numel() // max(rows, 1)
+    out = torch.zeros((int(num_segments),) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    L.check(L.hip().dl4j_segment_sum(L.ptr(x), L.ptr(seg), L.ptr(out), L.c_int64(rows), L.c_int(D), L.c_int64(int(num_segments)),
+                                     L.c_int(L.dtype_code(x)), L.c_int(1 if seg.dtype == torch.int64 else 0), L.stream()),
+            "segment_sum")
+    return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+
+def cumsum_last(x, exclusive=False, reverse=False):
+    cols = x.shape[-1]
+    y = torch.empty_like(x)
+    L.check(L.hip().dl4j_cumsum_rows(L.ptr(x), L.ptr(y), L.c_int64(x.numel() // cols), L.c_int(cols), L.c_int(int(exclusive)),
+                                     L.c_int(int(reverse)), L.c_int(L.dtype_code(x)), L.stream()), "cumsum_rows")
+    return y
+
+
+def merge(arrays, mode):
+    """mode: 'add' | 'avg' | 'max' over same-shape contiguous tensors."""
+    a0 = arrays[0]
+    for a in arrays:
+        assert a.shape == a0.shape and a.dtype == a0.dtype and a.is_contiguous() and a.is_cuda
+    ptrs = torch.tensor([a.data_ptr() for a in arrays], dtype=torch.int64).to(a0.device, non_blocking=False)
+    out = torch.empty_like(a0)
+    L.check(L.hip().dl4j_merge(L.ptr(ptrs), L.c_int(len(arrays)), L.ptr(out), L.c_int64(a0.numel()),
+                               L.c_int({"add": 0, "avg": 1, "max": 2}[mode]), L.c_int(L.dtype_code(a0)), L.stream()), "merge")
+    return out
+
+
+# ----------------------------------------------------------------------------- im2col / col2im / upsampling / resize
+def _geom(N, C, H, W, kH, kW, sH, sW, pH, pW, dH, dW):
+    oH = (H + 2 * pH - dH * (kH - 1) - 1) // sH + 1
+    oW = (W + 2 * pW - dW * (kW - 1) - 1) // sW + 1
+    return (ctypes.c_int * 14)(N, C, H, W, kH, kW, oH, oW, sH, sW, pH, pW, dH, dW), oH, oW
+
+
+def im2col(x, kH, kW, sH, sW, pH, pW, dH=1, dW=1, pad_value=0.0):
+    N, C, H, W = x.shape
+    g, oH, oW = _geom(N, C, H, W, kH, kW, sH, sW, pH, pW, dH, dW)
+    assert oH > 0 and oW > 0
+    col = torch.empty((N, C, kH, kW, oH, oW), device=x.device, dtype=x.dtype)
+    L.check(L.hip().dl4j_im2col(L.ptr(x), L.ptr(col), g, L.c_float(pad_value), L.c_int(L.dtype_code(x)), L.stream()), "im2col")
+    return col
+
+
+def col2im(col, H, W, sH, sW, pH, pW, dH=1, dW=1):
+    N, C, kH, kW, oH, oW = col.shape
+    g, oH2, oW2 = _geom(N, C, H, W, kH, kW, sH, sW, pH, pW, dH, dW)
+    assert (oH2, oW2) == (oH, oW), "col2im: column shape does not match the image geometry"
+    x = torch.empty((N, C, H, W), device=col.device, dtype=col.dtype)
+    L.check(L.hip().dl4j_col2im(L.ptr(col), L.ptr(x), g, L.c_int(L.dtype_code(col)), L.stream()), "col2im")
+    return x
+
+
+def upsample2d(x, fH, fW):
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H * fH, W * fW), device=x.device, dtype=x.dtype)
+    L.check(L.hip().dl4j_upsample2d_fwd(L.ptr(x), L.ptr(y), L.c_int64(N * C), L.c_int(H), L.c_int(W), L.c_int(fH), L.c_int(fW),
+                                        L.c_int(x.element_size()), L.stream()), "upsample2d_fwd")
+    return y
+
+
+def upsample2d_bwd(g, fH, fW):
+    N, C, oH, oW = g.shape
+    assert oH % fH == 0 and oW % fW == 0
+    H, W = oH // fH, oW // fW
+    dx = torch.empty((N, C, H, W), device=g.device, dtype=g.dtype)
+    L.check(L.hip().dl4j_upsample2d_bwd(L.ptr(g), L.ptr(dx), L.c_int64(N * C), L.c_int(H), L.c_int(W), L.c_int(fH), L.c_int(fW),
+                                        L.c_int(L.dtype_code(g)), L.stream()), "upsample2d_bwd")
+    return dx
+
+
+def resize_nhwc(x, oH, oW, mode="bilinear", align_corners=False, half_pixel=False):
+    N, H, W, C = x.shape
+    y = torch.empty((N, int(oH), int(oW), C), device=x.device, dtype=x.dtype)
+    L.check(L.hip().dl4j_resize_nhwc(L.ptr(x), L.ptr(y), L.c_int(N), L.c_int(H), L.c_int(W), L.c_int(C), L.c_int(int(oH)),
+                                     L.c_int(int(oW)), L.c_int(0 if mode == "nearest" else 1), L.c_int(int(align_corners)),
+                                     L.c_int(int(half_pixel)), L.c_int(L.dtype_code(x)), L.stream()), "resize_nhwc")
+    return y
+
+
+# ----------------------------------------------------------------------------- word2vec batched step
+def sg_pairs_(syn0, syn1, in_idx, tgt_idx, label, lr, hidden=None, scale=1.0):
+    """One batched skip-gram / CBOW update: syn1 rows are updated in place, returns dh [n_pairs, D] (the input-side
+    gradient of each pair, to be scatter-added into syn0 — or distributed over the context for CBOW)."""
+    n = tgt_idx.numel()
+    D = syn0.shape[1]
+    for t in (syn0, syn1):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+    assert in_idx.dtype == torch.int64 and tgt_idx.dtype == torch.int64 and label.dtype == torch.float32
+    assert in_idx.numel() == n and label.numel() == n and in_idx.is_contiguous() and tgt_idx.is_contiguous() and label.is_contiguous()
+    if hidden is not None:
+        assert hidden.dtype == torch.float32 and hidden.is_contiguous() and hidden.shape == (n, D)
+    dh = torch.empty(n, D, device=syn0.device, dtype=torch.float32)
+    L.check(L.hip().dl4j_sg_pairs(L.ptr(syn0), L.ptr(syn1), L.ptr(hidden), L.ptr(in_idx), L.ptr(tgt_idx), L.ptr(label), L.ptr(dh),
+                                  L.c_int64(n), L.c_int(D), L.c_float(lr), L.c_float(scale), L.c_int64(syn0.shape[0]),
+                                  L.c_int64(syn1.shape[0]), L.stream()), "sg_pairs")
+    return dh
