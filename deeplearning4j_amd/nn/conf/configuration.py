@@ -323,6 +323,10 @@ class MultiLayerConfiguration:
             l.setNIn(cur, override)
             cur = l.getOutputType(i, cur)
 
+    def getMemoryReport(self, inputType=None):
+        from .memory import memory_report_mln
+        return memory_report_mln(self, inputType)
+
     def getLayerActivationTypes(self, inputType=None):
         cur = inputType or self.inputType
         out = []
@@ -587,6 +591,10 @@ class ComputationGraphConfiguration:
         if len(order) != len(self.vertices) + len(self.networkInputs):
             raise ValueError("Invalid configuration: cycle detected in graph")
         return order
+
+    def getMemoryReport(self, *inputTypes):
+        from .memory import memory_report_graph
+        return memory_report_graph(self, *inputTypes)
 
     def getLayerActivationTypes(self, *inputTypes):
         its = list(inputTypes) if inputTypes else list(self.inputTypes or [])

@@ -539,3 +539,8 @@ class MultiLayerNetwork(BaseNetwork):
         from .graph_capture import CapturedTrainStep
         self._graph_step = CapturedTrainStep(self) if enabled and self.ctx.device.type == "cuda" else None
         return self
+
+
+from ..utils.crash_reporting import install as _install_crash_reporting  # noqa: E402
+
+_install_crash_reporting(MultiLayerNetwork)

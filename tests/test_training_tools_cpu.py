@@ -239,3 +239,35 @@ def test_parallel_inference_graph_and_errors():
     pi2.shutdown()
     with pytest.raises(RuntimeError):
         pi2.output(x)
+
+
+def test_memory_report_and_crash_dump(tmp_path):
+    from deeplearning4j_amd.models.lenet import LeNet
+    from deeplearning4j_amd.nn.conf.base import InputType
+    from deeplearning4j_amd.nn.conf.memory import MemoryType, MemoryUseMode
+    from deeplearning4j_amd.utils.crash_reporting import CrashReportingUtil
+    m = LeNet(inputShape=(1, 28, 28), numClasses=10)
+    net = m.init(device="cpu")
+    rep = net.conf.getMemoryReport(InputType.convolutionalFlat(28, 28, 1))
+    assert rep.getMemoryBytes(MemoryType.PARAMETERS, 1, MemoryUseMode.INFERENCE) == net.numParams() * 4
+    assert rep.getMemoryBytes(MemoryType.UPDATER_STATE, 1, MemoryUseMode.TRAINING) == int(net._state_size) * 4
+    assert rep.getMemoryBytes(MemoryType.ACTIVATIONS, 64, MemoryUseMode.TRAINING) == 2 * rep.getMemoryBytes(MemoryType.ACTIVATIONS, 32, MemoryUseMode.TRAINING)
+    assert rep.getTotalMemoryBytes(32, MemoryUseMode.TRAINING) > rep.getTotalMemoryBytes(32, MemoryUseMode.INFERENCE)
+    assert "Network Memory Report" in str(rep) and '"layers"' in rep.toJson()
+    # an OOM inside fit() writes the dump and re-raises
+    CrashReportingUtil.crashDumpOutputDirectory(tmp_path)
+    orig = type(net).computeGradientAndScore
+
+    def boom(self, *a, **k):
+        raise RuntimeError("HIP out of memory. Tried to allocate 1.00 TiB")
+    type(net).computeGradientAndScore = boom
+    try:
+        with pytest.raises(RuntimeError):
+            net.fit(torch.rand(4, 784), torch.eye(10)[:4])
+    finally:
+        type(net).computeGradientAndScore = orig
+        CrashReportingUtil.crashDumpOutputDirectory(None)
+    dumps = list(tmp_path.glob("dl4j-memory-crash-dump-*.txt"))
+    assert len(dumps) == 1
+    txt = dumps[0].read_text()
+    assert "out of memory" in txt and "Network # parameters: %d" % net.numParams() in txt and "Network Memory Report" in txt
