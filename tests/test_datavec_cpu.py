@@ -188,3 +188,54 @@ def test_image_pipeline(tmp_path):
     assert pipe.transform(t, random.Random(0)).shape == (2, 8, 8)
     back = NativeImageLoader.toImage(img)
     assert back.size == (16, 16) and back.getpixel((8, 8)) == (0, 0, 255)
+
+
+def test_arrow_jdbc_excel_readers(tmp_path):
+    import sqlite3
+    from deeplearning4j_amd.datavec.arrow import ArrowConverter, ArrowRecordReader, ArrowRecordWriter
+    from deeplearning4j_amd.datavec.jdbc import JDBCRecordReader
+    from deeplearning4j_amd.datavec.excel import ExcelRecordReader, ExcelRecordWriter
+    from deeplearning4j_amd.datavec.records import CollectionInputSplit
+    from deeplearning4j_amd.datavec.transform import Schema
+    from deeplearning4j_amd.datavec.writable import DoubleWritable, IntWritable, Text, BooleanWritable
+    schema = Schema.Builder().addColumnInteger("id").addColumnDouble("x").addColumnString("name").addColumnBoolean("flag").build()
+    recs = [[IntWritable(i), DoubleWritable(i * 0.5), Text("n%d" % i), BooleanWritable(i % 2 == 0)] for i in range(7)]
+    # arrow + parquet round trips
+    for fmt, ext in (("arrow", ".arrow"), ("parquet", ".parquet")):
+        p = tmp_path / ("d" + ext)
+        w = ArrowRecordWriter(schema, fmt).initialize(p)
+        w.writeBatch(recs)
+        w.close()
+        rr = ArrowRecordReader().initialize(CollectionInputSplit([str(p)]))
+        back = list(rr)
+        assert [[v.get() for v in r] for r in back] == [[v.get() for v in r] for r in recs]
+        assert rr.schema.getColumnNames() == ["id", "x", "name", "flag"]
+    t = ArrowConverter.toArrowTable(schema, recs)
+    m = ArrowConverter.toTensor(t, ["id", "x"])
+    assert m.shape == (7, 2) and float(m[3, 1]) == 1.5
+    # jdbc over sqlite
+    db = tmp_path / "t.db"
+    conn = sqlite3.connect(db)
+    conn.execute("create table coffee (id integer primary key, name text, price real)")
+    conn.executemany("insert into coffee values (?, ?, ?)", [(i, " c%d " % i, 1.0 + i) for i in range(5)])
+    conn.commit()
+    jr = JDBCRecordReader("select * from coffee order by id", conn, "select * from coffee where id = ?", [0])
+    jr.setTrimStrings(True)
+    jr.initialize()
+    rows = []
+    while jr.hasNext():
+        rows.append(jr.nextRecord())
+    assert len(rows) == 5 and rows[2].getRecord()[1].toString() == "c2" and rows[4].getRecord()[2].toDouble() == 5.0
+    again = jr.loadFromMetaData(rows[3].getMetaData())
+    assert again.getRecord()[0].toInt() == 3
+    jr.reset()
+    assert jr.hasNext() and jr.columnNames == ["id", "name", "price"]
+    # excel
+    xp = tmp_path / "b.xlsx"
+    ew = ExcelRecordWriter().initialize(xp)
+    ew.write(["id", "x", "name", "flag"])
+    ew.writeBatch(recs)
+    ew.close()
+    er = ExcelRecordReader(skipNumLines=1).initialize(CollectionInputSplit([str(xp)]))
+    rows = list(er)
+    assert len(rows) == 7 and rows[3][0].toInt() == 3 and rows[3][1].toDouble() == 1.5 and rows[3][2].toString() == "n3" and rows[2][3].get() is True
