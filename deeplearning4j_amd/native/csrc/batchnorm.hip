@@ -243,6 +243,58 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
   }
 }
 
+// Fused "reduce the conv-epilogue partials + finalize": partial is [gy][2][C] (row 0 sum, row 1 sum of squares per M tile).
+// One block owns 8 channels; its 32 row groups stride over the gy tiles (4 independent loads in flight per thread), an LDS
+// tree-less reduction (32 adds by 8 threads) finishes the sums and the same threads run the finalize math. Replaces two
+// latency-bound launches per BatchNorm (bn_sum_partials + bn_finalize) by one with 2-8x more blocks.
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(
+    const float* __restrict__ partial, int gy, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ conv_bias, const float* __restrict__ gmean, const float* __restrict__ gvar, float* __restrict__ mean,
+    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ dgmean,
+    float* __restrict__ dgvar, int C, float invM, float eps, float decay, int stat_mode) {
+  __shared__ float s0[32][9], s1[32][9];
+  const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  if (c < C) {
+    const int64_t C2 = 2 * (int64_t)C;
+    int r = rg;
+    for (; r + 32 < gy; r += 64) {
+      a0 += partial[r * C2 + c];
+      b0 += partial[r * C2 + C + c];
+      a1 += partial[(r + 32) * C2 + c];
+      b1 += partial[(r + 32) * C2 + C + c];
+    }
+    if (r < gy) { a0 += partial[r * C2 + c]; b0 += partial[r * C2 + C + c]; }
+  }
+  s0[rg][cl] = a0 + a1;
+  s1[rg][cl] = b0 + b1;
+  __syncthreads();
+  if (rg != 0 || c >= C) return;
+  float su = 0.f, sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) { su += s0[k][cl]; sq += s1[k][cl]; }
+  const float m = su * invM;
+  float var = sq * invM - m * m;
+  var = var < 0.f ? 0.f : var;
+  const float is = rsqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean[c] = m; invstd[c] = is;
+  const float sc = g * is;
+  scale[c] = sc; shift[c] = b - m * sc;
+  if (stat_mode != 0) {
+    const float bm = m + (conv_bias ? conv_bias[c] : 0.f);
+    dgmean[c] = (gmean[c] - bm) * (1.f - decay);
+    if (stat_mode == 1) {
+      dgvar[c] = (gvar[c] - var) * (1.f - decay);
+    } else {
+      const float vt = powf(10.f, 2.f * gvar[c]);
+      const float vnew = decay * vt + (1.f - decay) * var;
+      dgvar[c] = logf(vt / vnew) * (0.5f / 2.302585092994046f);
+    }
+  }
+}
+
 // Inference-time scale/shift from global statistics.
 __global__ void bn_infer_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ gmean, const float* __restrict__ gvar,
@@ -446,6 +498,16 @@ DL4J_API int dl4j_bn_finalize(const float* sums, const float* gamma, const float
                               float* shift, float* dgmean, float* dgvar, int C, int64_t M, float eps, float decay,
                               int stat_mode, hipStream_t st) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, gamma, beta, conv_bias, gmean,
+                     gvar, mean, invstd, scale, shift, dgmean, dgvar, C, 1.f / (float)M, eps, decay, stat_mode);
+  DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_bn_finalize_partials(const float* partial, int gy, const float* gamma, const float* beta, const float* conv_bias,
+                                       const float* gmean, const float* gvar, float* mean, float* invstd, float* scale, float* shift,
+                                       float* dgmean, float* dgvar, int C, int64_t M, float eps, float decay, int stat_mode,
+                                       hipStream_t st) {
+  if (C <= 0 || gy <= 0) return 0;
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((C + 7) / 8), dim3(256), 0, st, partial, gy, gamma, beta, conv_bias, gmean,
                      gvar, mean, invstd, scale, shift, dgmean, dgvar, C, 1.f / (float)M, eps, decay, stat_mode);
   DL4J_RET_LAST();
 }

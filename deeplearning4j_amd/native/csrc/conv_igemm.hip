@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const WGradP p) {
 }
 
 template <int BK_, int BC_>
-static int launch_wgrad(WGradP& p, int target_blocks, hipStream_t st) {
+static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t st) {
   p.ktiles = p.K / BK_;
   p.ctiles = p.C / BC_;
   const int tiles = p.ktiles * p.ctiles * p.R * p.S;
@@ -416,7 +416,7 @@ static int launch_wgrad(WGradP& p, int target_blocks, hipStream_t st) {
   splits = (p.P + pps - 1) / pps;
   p.splits = splits; p.pps = pps;
   p.use_atomic = splits > 1;
-  if (p.use_atomic) hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.K * p.R * p.S * p.C, st);
+  if (p.use_atomic && !prezeroed) hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.K * p.R * p.S * p.C, st);
   const int smem = 2 * 64 * (BK_ + BC_) * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -429,7 +429,9 @@ static int launch_wgrad(WGradP& p, int target_blocks, hipStream_t st) {
 }
 
 // geom = [N,H,W,C, OH,OW,K, R,S, sh,sw, ph,pw, dh,dw]; dw_out fp32 [K][R*S][C]
-DL4J_API int dl4j_igemm_wgrad(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks,
+// prezeroed: the caller guarantees dw_out is all zeros (flat gradient vector cleared once per iteration, or the
+// self-cleaning scratch of the 3x3 path), so the per-layer memset in front of the split-K atomics is skipped.
+DL4J_API int dl4j_igemm_wgrad(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks, int prezeroed,
                               hipStream_t st) {
   WGradP p;
   p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw_out;
@@ -438,25 +440,29 @@ DL4J_API int dl4j_igemm_wgrad(const void* dy, const void* x, float* dw_out, cons
   p.P = p.N * p.OH * p.OW;
   if (p.C % 64 != 0 || p.K % 64 != 0) return -2;
   const bool k128 = (p.K % 128) == 0, c128 = (p.C % 128) == 0;
-  if (k128 && c128) return launch_wgrad<128, 128>(p, target_blocks, st);
-  if (k128) return launch_wgrad<128, 64>(p, target_blocks, st);
-  if (c128) return launch_wgrad<64, 128>(p, target_blocks, st);
-  return launch_wgrad<64, 64>(p, target_blocks, st);
+  if (k128 && c128) return launch_wgrad<128, 128>(p, target_blocks, prezeroed, st);
+  if (k128) return launch_wgrad<128, 64>(p, target_blocks, prezeroed, st);
+  if (c128) return launch_wgrad<64, 128>(p, target_blocks, prezeroed, st);
+  return launch_wgrad<64, 64>(p, target_blocks, prezeroed, st);
 }
 
 // fp32 [K][RS][C] -> [K][C][RS]  (OHWI -> DL4J OIHW gradient view)
-__global__ void __launch_bounds__(256) ohwi_to_oihw_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                           int64_t total, int RS, int C) {
+// clear_src: zero every source element after reading it (each is read exactly once), leaving the scratch ready for the next
+// layer's split-K atomics without a memset
+__global__ void __launch_bounds__(256) ohwi_to_oihw_kernel(float* __restrict__ src, float* __restrict__ dst,
+                                                           int64_t total, int RS, int C, int clear_src) {
   for (int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x; d < total; d += (int64_t)gridDim.x * 256) {
     const int64_t k = d / ((int64_t)C * RS);
     const int64_t rem = d - k * (int64_t)C * RS;
     const int c = (int)(rem / RS), rs = (int)(rem - (int64_t)c * RS);
-    dst[d] = src[(k * RS + rs) * C + c];
+    const int64_t si = (k * RS + rs) * C + c;
+    dst[d] = src[si];
+    if (clear_src) src[si] = 0.f;
   }
 }
 
-DL4J_API int dl4j_ohwi_to_oihw(const float* src, float* dst, int K, int RS, int C, hipStream_t st) {
+DL4J_API int dl4j_ohwi_to_oihw(float* src, float* dst, int K, int RS, int C, int clear_src, hipStream_t st) {
   const int64_t total = (int64_t)K * RS * C;
-  hipLaunchKernelGGL(ohwi_to_oihw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, src, dst, total, RS, C);
+  hipLaunchKernelGGL(ohwi_to_oihw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, src, dst, total, RS, C, clear_src);
   DL4J_RET_LAST();
 }

@@ -511,6 +511,10 @@ class ComputationGraph(BaseNetwork):
             s = ol.compute_score_sum()
             total = s if total is None else total + s
         self._score = (total / mb) if self._minibatch else total
+        if self._grads.is_cuda:
+            # one clear of the flat gradient vector replaces a memset in front of every split-K wgrad (53 on ResNet-50)
+            self._grads.zero_()
+            self.ctx.grads_zeroed = True
         self._backward(mb)
         for lst in self.listeners:
             if hasattr(lst, "onGradientCalculation"):

@@ -31,6 +31,7 @@ class LayerCtx:
         self.channels_last = (self.device.type == "cuda") if channels_last is None else channels_last
         self.iteration = 0
         self.epoch = 0
+        self.grads_zeroed = False        # set by the network once it clears the flat gradient vector before backward
         self.fused_bias_into_bn = set()  # names of conv layers whose bias is folded into the following BN
 
     @property

@@ -411,7 +411,8 @@ class ConvolutionLayerImpl(LayerImpl):
         need_dx = getattr(self, "needs_input_grad", True)
         dx, dW, db = CONV.conv2d_backward(dz, self.input, self.w("W"), c.stride, self._pad, c.dilation,
                                           need_dx, True, has_b, w_dgrad=self.cparams.get("W_dgrad"),
-                                          dw_out=self.grads["W"], dx_accum=accum if need_dx else None)
+                                          dw_out=self.grads["W"], dx_accum=accum if need_dx else None,
+                                          dw_prezeroed=getattr(self.ctx, "grads_zeroed", False))
         if dW is not None:
             self.grads["W"].copy_(dW)
         if "b" in self.grads:

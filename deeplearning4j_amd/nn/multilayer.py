@@ -304,6 +304,10 @@ class MultiLayerNetwork(BaseNetwork):
         out_layer.setLabels(y, lmask)
         ssum = out_layer.compute_score_sum()
         self._score = (ssum / mb) if self._minibatch else ssum
+        if self._grads.is_cuda:
+            # one clear of the flat gradient vector replaces a memset in front of every split-K wgrad (53 on ResNet-50)
+            self._grads.zero_()
+            self.ctx.grads_zeroed = True
         self._backward(mb)
         for lst in self.listeners:
             if hasattr(lst, "onGradientCalculation"):

@@ -107,6 +107,14 @@ def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std
         buf = torch.empty(6 * C, device=dev, dtype=torch.float32)
         mean, invstd, scale, shift = buf[2 * C:3 * C], buf[3 * C:4 * C], buf[4 * C:5 * C], buf[5 * C:]
         h = L.hip()
+        if sums is not None and hasattr(sums, "partial"):
+            # conv-epilogue partials: reduce + finalize in one launch
+            assert sums.K == C and sums.partial.numel() >= sums.gy * 2 * C
+            L.check(h.dl4j_bn_finalize_partials(L.ptr(sums.partial), L.c_int(sums.gy), L.ptr(gamma), L.ptr(beta), L.ptr(conv_bias),
+                                                L.ptr(gmean), L.ptr(gvar), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift),
+                                                L.ptr(dgmean_out), L.ptr(dgvar_out), L.c_int(C), L.c_int64(M), L.c_float(eps),
+                                                L.c_float(decay), L.c_int(stat_mode), L.stream()), "bn_finalize_partials")
+            return mean, invstd, scale, shift
         if sums is None:
             sums = buf[:2 * C]
             ws = _workspace(C, dev)

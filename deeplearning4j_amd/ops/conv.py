@@ -46,7 +46,7 @@ def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False):
 
 
 def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=True, need_db=False, w_dgrad=None,
-                    dw_out=None, dx_accum=None):
+                    dw_out=None, dx_accum=None, dw_prezeroed=False):
     """Returns (dx, dW, db); dW has logical shape [nOut, nIn, kH, kW] — or None when it was written
     straight into ``dw_out`` (fp32 gradient view) by the HIP wgrad kernel."""
     if _hip_eligible(x, w, stride, padding, dilation) and dz.dtype == torch.bfloat16:
@@ -55,7 +55,7 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
         if need_db:
             db = dz.float().sum((0, 2, 3))
         if need_dw:
-            dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out)
+            dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
         if need_dx:
             if w_dgrad is not None and IG.dgrad_supported(w, stride, padding):
                 acc = dx_accum if IG.accum_ok(dx_accum, x.shape) else None

@@ -18,10 +18,11 @@ _WS = {}
 
 
 def _ws(n_floats, device, tag):
+    """Stream-keyed scratch, allocated ZEROED: the wgrad scratch relies on it (its consumer re-zeroes what it read)."""
     key = (tag, device.index, torch.cuda.current_stream().cuda_stream)
     t = _WS.get(key)
     if t is None or t.numel() < n_floats:
-        t = torch.empty(max(int(n_floats), 1 << 18), device=device, dtype=torch.float32)
+        t = torch.zeros(max(int(n_floats), 1 << 18), device=device, dtype=torch.float32)
         _WS[key] = t
     return t
 
@@ -62,25 +63,38 @@ def _out_hw(H, W, R, S, stride, padding, dilation):
     return OH, OW
 
 
+class StatPartials:
+    """Per-M-tile (sum, sum of squares) rows written by the conv epilogue: tensor [gy, 2, K] fp32. The consuming BatchNorm
+    reduces them inside its finalize kernel (ops/batchnorm.batch_stats), so no separate reduction launch is needed."""
+    __slots__ = ("partial", "gy", "K")
+
+    def __init__(self, partial, gy, K):
+        self.partial, self.gy, self.K = partial, gy, K
+
+    def sums(self):
+        out = torch.empty(2 * self.K, device=self.partial.device, dtype=torch.float32)
+        L.check(L.hip().dl4j_bn_sum_partials(L.ptr(self.partial), L.c_int(self.gy), L.c_int(self.K), L.ptr(out), None, None, L.stream()),
+                "bn_sum_partials")
+        return out
+
+
 def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False):
     tile = pick_tile(M, Kout)
     stats = None
     mt = int(L.hip().dl4j_igemm_mtiles(L.c_int64(M), L.c_int(tile)))
     if want_stats:
-        stats = _ws(mt * 2 * Kout, x_t.device, "igemm_stats")
+        # own buffer per call (not the shared scratch): two convs may run before their fused BN node consumes both
+        stats = torch.empty(mt * 2 * Kout, device=x_t.device, dtype=torch.float32)
     g = (ctypes.c_int * 19)(*geom)
     L.check(L.hip().dl4j_igemm_conv(L.ptr(x_t), L.ptr(w_t), L.ptr(y_t), L.ptr(bias), L.ptr(stats), g, L.c_int(tile),
                                     L.c_int(1 if accum else 0), None, L.stream()), "igemm_conv")
     if not want_stats:
         return None
-    sums = torch.empty(2 * Kout, device=x_t.device, dtype=torch.float32)
-    L.check(L.hip().dl4j_bn_sum_partials(L.ptr(stats), L.c_int(mt), L.c_int(Kout), L.ptr(sums), None, None, L.stream()),
-            "bn_sum_partials")
-    return sums
+    return StatPartials(stats, mt, Kout)
 
 
 def forward(x, w, b, stride, padding, dilation, want_stats=False):
-    """Returns (y, sums) — sums is a [2*K] fp32 tensor (sum, sumsq per channel) when want_stats."""
+    """Returns (y, stats) — stats is a StatPartials (per-tile sum / sumsq rows) when want_stats."""
     N, C, H, W = x.shape
     K, _, R, S = w.shape
     OH, OW = _out_hw(H, W, R, S, stride, padding, dilation)
@@ -131,9 +145,10 @@ def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation, accum_into=None):
     return dx
 
 
-def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=512):
+def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=512, prezeroed=False):
     """dW. If ``dw_out`` (fp32, contiguous, logical [K,C,R,S]) is given the result is written there and
-    None is returned; otherwise a new fp32 [K,C,R,S] tensor is returned."""
+    None is returned; otherwise a new fp32 [K,C,R,S] tensor is returned. ``prezeroed``: dw_out is known to be all
+    zeros (the network clears the flat gradient vector once per iteration), so no per-layer memset is issued."""
     N, C, H, W = x.shape
     K, _, R, S = w_shape
     OH, OW = dz.shape[2], dz.shape[3]
@@ -148,14 +163,15 @@ def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=
     g = (ctypes.c_int * 15)(N, H, W, C, OH, OW, K, R, S, stride[0], stride[1], padding[0], padding[1], dilation[0],
                             dilation[1])
     if R * S == 1:
-        L.check(L.hip().dl4j_igemm_wgrad(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.stream()),
-                "igemm_wgrad")
+        L.check(L.hip().dl4j_igemm_wgrad(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks),
+                                         L.c_int(1 if (prezeroed and tgt is dw_out) else 0), L.stream()), "igemm_wgrad")
     else:
+        # scratch starts zeroed and the layout transposer re-zeroes exactly what it read: no memset per layer
         scratch = _ws(K * R * S * C, x.device, "igemm_wgrad")
-        L.check(L.hip().dl4j_igemm_wgrad(L.ptr(dz), L.ptr(x), L.ptr(scratch), g, L.c_int(target_blocks), L.stream()),
+        L.check(L.hip().dl4j_igemm_wgrad(L.ptr(dz), L.ptr(x), L.ptr(scratch), g, L.c_int(target_blocks), L.c_int(1), L.stream()),
                 "igemm_wgrad")
-        L.check(L.hip().dl4j_ohwi_to_oihw(L.ptr(scratch), L.ptr(tgt), L.c_int(K), L.c_int(R * S), L.c_int(C), L.stream()),
-                "ohwi_to_oihw")
+        L.check(L.hip().dl4j_ohwi_to_oihw(L.ptr(scratch), L.ptr(tgt), L.c_int(K), L.c_int(R * S), L.c_int(C), L.c_int(1),
+                                          L.stream()), "ohwi_to_oihw")
     if ret is not None and dw_out is not None:
         dw_out.copy_(ret)
         return None

@@ -34,7 +34,8 @@ def test_forward_and_stats(case):
     x, w = _mk(N, C, H, W, K, R)
     b = torch.randn(K, device="cuda")
     assert IG.supported(x, w, (s, s), (p, p), (d, d))
-    y, sums = IG.forward(x, w, b, (s, s), (p, p), (d, d), want_stats=True)
+    y, st = IG.forward(x, w, b, (s, s), (p, p), (d, d), want_stats=True)
+    sums = st.sums()
     ref = F.conv2d(x.float(), w.float(), b, s, p, d)
     assert y.shape == ref.shape
     err = (y.float() - ref).abs().max().item()
