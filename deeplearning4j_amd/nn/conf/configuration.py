@@ -481,6 +481,8 @@ class GraphBuilder:
                 p = self._pre.get(name, pre)
                 verts[name] = G.LayerVertex(nnc, p, name in self._outputs)
             else:
+                if hasattr(obj, "apply_global"):
+                    obj.apply_global(self._gb._g)
                 verts[name] = obj
         conf = ComputationGraphConfiguration(verts, OrderedDict((k, list(v)) for k, v in self._vertexInputs.items()),
                                              list(self._inputs), list(self._outputs),

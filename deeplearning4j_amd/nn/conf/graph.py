@@ -275,7 +275,27 @@ class ReverseTimeSeriesVertex(GraphVertex):
         self.maskArrayInputName = maskArrayInputName
 
 
-class AttentionVertex(GraphVertex):
+class _ParamVertexMixin:
+    """Vertices that own parameters take the network-wide updater / weight init (GraphBuilder.build -> apply_global)."""
+    iupdater = None
+    weightInitFn = None
+
+    def apply_global(self, g):
+        import copy
+        if self.iupdater is None and g.get("iupdater") is not None:
+            self.iupdater = copy.deepcopy(g["iupdater"])
+        if self.weightInitFn is None and g.get("weightInitFn") is not None:
+            self.weightInitFn = copy.deepcopy(g["weightInitFn"])
+
+    def getUpdaterByParam(self, spec):
+        from ...nd4j.learning import NoOp
+        return self.iupdater or NoOp()
+
+    def getRegularizationByParam(self, spec):
+        return []
+
+
+class AttentionVertex(_ParamVertexMixin, GraphVertex):
     JAVA_CLASS = _G + "AttentionVertex"
     FIELDS = ("nInKeys", "nInValues", "nInQueries", "nOut", "headSize", "nHeads", "projectInput")
 
@@ -311,6 +331,53 @@ class DotProductAttentionVertex(GraphVertex):
 
     def maxVertexInputs(self):
         return 3
+
+
+class SameDiffVertex(_ParamVertexMixin, GraphVertex):
+    """User-defined vertex with parameters (reference: nn/conf/layers/samediff/SameDiffVertex.java): subclass and implement
+    ``defineParameters() -> {name: shape}``, ``defineVertex(inputs: list, params: dict) -> tensor`` (torch ops; autograd supplies
+    the backward) and ``getOutputType``."""
+    JAVA_CLASS = "org.deeplearning4j.nn.conf.layers.samediff.SameDiffVertex"
+
+    def defineParameters(self):
+        return {}
+
+    def defineVertex(self, inputs, params):
+        raise NotImplementedError
+
+    def minVertexInputs(self):
+        return 1
+
+    def maxVertexInputs(self):
+        return 1 << 30
+
+    def param_specs(self):
+        from .layers import ParamSpec
+        return [ParamSpec(k, tuple(shp), "c", shp[0] if shp else 1, shp[-1] if shp else 1, "b" if k.startswith("b") else "W")
+                for k, shp in self.defineParameters().items()]
+
+    def numParams(self, backprop=False):
+        return sum(sp.numel for sp in self.param_specs())
+
+    def getOutputType(self, layerIndex, *its):
+        return its[0]
+
+    def to_json(self):
+        return {"@class": self.JAVA_CLASS, "pythonClass": type(self).__module__ + "." + type(self).__qualname__}
+
+
+class SameDiffLambdaVertex(SameDiffVertex):
+    """Parameter-free vertex from a callable over its inputs (SameDiffLambdaVertex.java)."""
+    JAVA_CLASS = "org.deeplearning4j.nn.conf.layers.samediff.SameDiffLambdaVertex"
+
+    def __init__(self, fn=None, outputTypeFn=None):
+        self.fn, self.outputTypeFn = fn, outputTypeFn
+
+    def defineVertex(self, inputs, params):
+        return self.fn(*inputs)
+
+    def getOutputType(self, layerIndex, *its):
+        return self.outputTypeFn(*its) if self.outputTypeFn else its[0]
 
 
 _VERTS = {c.JAVA_CLASS: c for c in (MergeVertex, ElementWiseVertex, SubsetVertex, StackVertex, UnstackVertex, ScaleVertex,

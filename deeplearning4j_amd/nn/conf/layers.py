@@ -1620,6 +1620,20 @@ class SameDiffLayer(BaseLayer):
                 for k, shp in self.defineParameters().items()]
 
 
+class SameDiffOutputLayer(SameDiffLayer):
+    """User-defined output layer: implement defineParameters() and
+    ``defineLayer(x, labels, params) -> (activations, per_example_loss[mb])`` with torch ops; the backward pass comes from
+    autograd (reference: nn/conf/layers/samediff/SameDiffOutputLayer.java — defineLayer returns the loss variable,
+    activationsVertexName names the prediction)."""
+    JAVA_CLASS = _L + "samediff.SameDiffOutputLayer"
+
+    def defineLayer(self, x, labels, params):
+        raise NotImplementedError
+
+    def labelsRequired(self):
+        return True
+
+
 LambdaLayer = SameDiffLambdaLayer
 
 

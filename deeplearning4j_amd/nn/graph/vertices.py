@@ -340,6 +340,35 @@ class DotProductAttentionVertexImpl(VertexImpl):
         return list(torch.autograd.grad(self._y, self._in, eps, allow_unused=True))
 
 
+class SameDiffVertexImpl(VertexImpl):
+    """Runs a user-defined SameDiffVertex / SameDiffLambdaVertex; gradients for inputs and parameters come from autograd."""
+
+    def param_specs(self):
+        return self.conf.param_specs()
+
+    def forward(self, xs, train=False):
+        if not train:
+            with torch.no_grad():
+                return self.conf.defineVertex(list(xs), dict(self.params))
+        self._in = [t.detach().requires_grad_(True) if t.is_floating_point() else t for t in xs]
+        self._leaves = {k: p.detach().requires_grad_(True) for k, p in self.params.items()}
+        with torch.enable_grad():
+            self._y = self.conf.defineVertex(list(self._in), self._leaves)
+        return self._y.detach()
+
+    def backward(self, eps):
+        keys = list(self._leaves)
+        diff_in = [t for t in self._in if t.requires_grad]
+        gs = torch.autograd.grad(self._y, diff_in + [self._leaves[k] for k in keys], eps.to(self._y.dtype), allow_unused=True)
+        for k, g in zip(keys, gs[len(diff_in):]):
+            if g is None:
+                self.grads[k].zero_()
+            else:
+                self.grads[k].copy_(g.reshape(self.grads[k].shape))
+        it = iter(gs[:len(diff_in)])
+        return [next(it) if t.requires_grad else None for t in self._in]
+
+
 _MAP = {G.MergeVertex: MergeVertexImpl, G.ElementWiseVertex: ElementWiseVertexImpl, G.SubsetVertex: SubsetVertexImpl,
         G.StackVertex: StackVertexImpl, G.UnstackVertex: UnstackVertexImpl, G.ScaleVertex: ScaleVertexImpl,
         G.ShiftVertex: ShiftVertexImpl, G.L2Vertex: L2VertexImpl, G.L2NormalizeVertex: L2NormalizeVertexImpl,
@@ -354,4 +383,6 @@ def create_vertex(conf, ctx):
     for k, v in _MAP.items():
         if type(conf) is k:
             return v(conf, ctx)
+    if isinstance(conf, G.SameDiffVertex):
+        return SameDiffVertexImpl(conf, ctx)
     raise ValueError("No runtime implementation for vertex %s" % type(conf).__name__)

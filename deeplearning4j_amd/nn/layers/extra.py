@@ -462,6 +462,54 @@ class SameDiffLayerImpl(AutogradLayerImpl):
         return self.conf.defineLayer(x, P, self.maskArray)
 
 
+class SameDiffOutputLayerImpl(LayerImpl):
+    """User-defined output layer (SameDiffOutputLayer): activations + per-example loss from one torch function."""
+    is_output = True
+
+    def setLabels(self, labels, mask=None):
+        self.labels, self.labelMask = labels, mask
+
+    def forward(self, x, train=False):
+        self.input = x
+        with torch.no_grad():
+            lab = getattr(self, "labels", None)
+            if lab is None or lab.shape[0] != x.shape[0]:
+                lab = None
+            y, _ = self.conf.defineLayer(x, lab, {k: self.w(k) for k in self.params})
+        return y
+
+    def _loss(self):
+        xin = self.input.detach().requires_grad_(True)
+        leaves = {k: self.w(k).detach().requires_grad_(True) for k in self.params}
+        with torch.enable_grad():
+            _, per_ex = self.conf.defineLayer(xin, self.labels, leaves)
+            per_ex = per_ex.reshape(per_ex.shape[0], -1).sum(1)
+            if getattr(self, "labelMask", None) is not None:
+                per_ex = per_ex * self.labelMask.reshape(per_ex.shape[0], -1)[:, 0].to(per_ex.dtype)
+            total = per_ex.sum()
+        return xin, leaves, per_ex, total
+
+    def compute_score_sum(self):
+        xin, leaves, per_ex, total = self._loss()
+        keys = list(leaves)
+        gs = torch.autograd.grad(total, [xin] + [leaves[k] for k in keys], allow_unused=True)
+        self._gs = (gs[0], dict(zip(keys, gs[1:])))
+        return total.detach()
+
+    def score_array(self):
+        return self._loss()[2].detach()
+
+    def backward(self, eps=None):
+        dx, dps = self._gs
+        for k, g in dps.items():
+            if k in self.grads:
+                if g is None:
+                    self.grads[k].zero_()
+                else:
+                    self.grads[k].copy_(g.reshape(self.grads[k].shape))
+        return dx
+
+
 class OCNNOutputLayerImpl(LayerImpl):
     """One-class NN output (conf/ocnn/OCNNOutputLayer.java): score = 0.5|W|^2+0.5|V|^2 + 1/nu*mean(relu(r - y)) - r."""
     is_output = True

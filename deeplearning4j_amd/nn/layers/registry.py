@@ -60,6 +60,7 @@ def _table():
         (C.CapsuleLayer, extra.CapsuleLayerImpl),
         (C.CapsuleStrengthLayer, extra.CapsuleStrengthLayerImpl),
         (C.SameDiffLambdaLayer, extra.LambdaLayerImpl),
+        (C.SameDiffOutputLayer, extra.SameDiffOutputLayerImpl),
         (C.SameDiffLayer, extra.SameDiffLayerImpl),
     ]
 

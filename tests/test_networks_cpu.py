@@ -195,3 +195,59 @@ def test_model_serializer_roundtrip(tmp_path):
     net.fit(x, y)
     net2.fit(x, y)
     assert torch.allclose(net.params(), net2.params(), atol=1e-7)
+
+
+def test_samediff_output_layer_vertex_and_lambda_vertex_train():
+    """User-defined SameDiffOutputLayer / SameDiffVertex / SameDiffLambdaVertex (reference: TestSameDiffOutput, TestSameDiffVertex,
+    TestSameDiffLambda in deeplearning4j-core samediff tests): parameters are allocated in the flat vector, take the global
+    updater and train."""
+    from deeplearning4j_amd.nn.conf.graph import SameDiffVertex, SameDiffLambdaVertex
+    from deeplearning4j_amd.nn.conf.layers import SameDiffOutputLayer
+
+    class MseOut(SameDiffOutputLayer):
+        def defineParameters(self):
+            return {"W": (self.nIn, self.nOut), "b": (1, self.nOut)}
+
+        def defineLayer(self, x, labels, params):
+            y = torch.tanh(x @ params["W"] + params["b"])
+            loss = None if labels is None else ((y - labels) ** 2).sum(1)
+            return y, loss
+
+    class ScaleAddVertex(SameDiffVertex):
+        def __init__(self, n):
+            self.n = n
+
+        def defineParameters(self):
+            return {"W": (self.n, self.n)}
+
+        def defineVertex(self, inputs, params):
+            return inputs[0] @ params["W"] + inputs[1]
+
+    torch.manual_seed(0)
+    conf = (NeuralNetConfiguration.Builder().seed(7).updater(Adam(0.02)).weightInit("XAVIER").graphBuilder()
+            .addInputs("in")
+            .addLayer("d0", DenseLayer(nIn=4, nOut=6, activation="TANH"), "in")
+            .addLayer("d1", DenseLayer(nIn=4, nOut=6, activation="TANH"), "in")
+            .addVertex("sd", ScaleAddVertex(6), "d0", "d1")
+            .addVertex("lam", SameDiffLambdaVertex(lambda a, b: a * 0.5 + b), "sd", "d0")
+            .addLayer("out", MseOut(nIn=6, nOut=2), "lam")
+            .setOutputs("out").build())
+    net = ComputationGraph(conf, device="cpu").init()
+    assert net.numParams() == 2 * (4 * 6 + 6) + 36 + (6 * 2 + 2)
+    x = torch.randn(32, 4)
+    y = torch.tanh(x[:, :2] * 0.7 - x[:, 2:] * 0.3)
+    net.fit([x], [y])
+    s0 = net.score()
+    w_vertex0 = net._impls["sd"].params["W"].clone()
+    for _ in range(150):
+        net.fit([x], [y])
+    assert net.score() < 0.25 * s0
+    assert not torch.equal(w_vertex0, net._impls["sd"].params["W"])          # vertex parameters are updated too
+    out = net.outputSingle(x)
+    assert out.shape == (32, 2) and float(((out - y) ** 2).sum(1).mean()) < 0.25 * s0 + 1e-3
+    # numerical gradient check through the autograd-backed pieces
+    conf2 = (NeuralNetConfiguration.Builder().seed(3).updater(NoOp()).dataType("DOUBLE").graphBuilder()
+             .addInputs("in").addLayer("d0", DenseLayer(nIn=3, nOut=4, activation="TANH"), "in")
+             .addVertex("sd", ScaleAddVertex(4), "d0", "d0").addLayer("out", MseOut(nIn=4, nOut=2), "sd").setOutputs("out").build())
+    n2 = ComputationGraph(conf2, device="cpu").init()
+    assert GradientCheckUtil.checkGradients(n2, [torch.randn(5, 3, dtype=torch.float64)], [torch.rand(5, 2, dtype=torch.float64)], epsilon=1e-6, maxRelError=1e-5)
