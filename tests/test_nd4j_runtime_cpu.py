@@ -466,3 +466,68 @@ def test_calculate_output_shape_and_dynamic_custom_op():
             return ins[0] * 2
     assert torch.equal(Twice("my_twice", [torch.ones(3)]).exec()[0], torch.full((3,), 2.0))
     assert describe("my_twice") is not None
+
+
+def test_backend_spi_device_local_events_validator_inspect():
+    import gc
+    from deeplearning4j_amd.nd4j.backend import (CpuBackend, DeallocatorService, DeviceLocalNDArray, DeviceValidator, EventLogger,
+                                                 Nd4jBackend, RocmBackend, UnifiedProfiler, inspectArray, DL4JSystemProperties)
+    b = Nd4jBackend.load()
+    assert isinstance(b, RocmBackend if torch.cuda.is_available() else CpuBackend)
+    assert "opexec" in b.getProperties() and b.device().type in ("cpu", "cuda")
+    assert RocmBackend().getPriority() > CpuBackend().getPriority()
+    assert DL4JSystemProperties.get(DL4JSystemProperties.UI_SERVER_PORT_PROPERTY, "9000") == os.environ.get("DL4J_UI_PORT", "9000")
+    # device-local replicas: delayed materialisation, update in place
+    src = torch.arange(6.0).reshape(2, 3)
+    dl = DeviceLocalNDArray(src, delayedMode=True)
+    r0 = dl.get()
+    assert torch.equal(r0.tensor().cpu(), src)
+    dl.update(src * 2)
+    assert torch.equal(dl.get().tensor().cpu(), src * 2)
+    # event logger + deallocator service
+    ev = EventLogger.getInstance()
+    ev.events.clear()
+    ev.setEnabled(True)
+    seen = []
+    ev.addEventLogListener(seen.append)
+    freed = []
+
+    class Owner:
+        pass
+    o = Owner()
+    ds = DeallocatorService.getInstance()
+    ds.pickObject(o, lambda: freed.append(1), nbytes=128)
+    assert ds.numLive() >= 1
+    del o
+    gc.collect()
+    assert freed == [1]
+    agg = ev.aggregate()
+    assert agg[("ALLOCATION", "DATA_BUFFER")] == [1, 128] and agg[("DEALLOCATION", "DATA_BUFFER")] == [1, 128] and len(seen) == 2
+    ev.setEnabled(False)
+    # blocked deallocation (DeallocationExtension)
+    o2 = Owner()
+    ds.toggleDeallocationBlock(True)
+    ds.pickObject(o2, lambda: freed.append(2))
+    del o2
+    gc.collect()
+    assert freed == [1]
+    ds.toggleDeallocationBlock(False)
+    assert freed == [1, 2]
+    # unified profiler wraps op statistics + memory snapshots
+    up = UnifiedProfiler.getInstance()
+    up.start()
+    from deeplearning4j_amd.nd4j.ops.custom import OpExecutioner
+    OpExecutioner.getInstance().exec("add", [torch.ones(3), torch.ones(3)])
+    rep = up.stop()
+    assert len(rep["memory"]) >= 2 and rep["memory"][0]["tag"] == "start"
+    # launch validation against gfx950 limits
+    lim = DeviceValidator.limits()
+    assert lim["waveSize"] == 64 and lim["numCu"] == 256 and lim["ldsPerCu"] == 160 * 1024
+    ok = DeviceValidator.validate(2048, 256, 64 * 1024, 128)
+    assert ok["valid"] and ok["wavesPerBlock"] == 4 and ok["blocksPerCu"] == 2 and ok["ldsLimited"]
+    assert not DeviceValidator.validate(1, 2048)["valid"]
+    assert not DeviceValidator.validate(1, 256, 200 * 1024)["valid"]
+    assert DeviceValidator.validate(1, 96)["mask"] == DeviceValidator.PARTIAL_WAVE
+    info = inspectArray(torch.tensor([0.0, 1.0, -2.0, float("nan"), float("inf"), 3.0]))
+    assert (info.min, info.max, info.zeroCount, info.positiveCount, info.negativeCount, info.nanCount, info.infCount) == (-2.0, 3.0, 1, 3, 1, 1, 1)
+    assert abs(info.mean - 0.5) < 1e-12
