@@ -349,3 +349,180 @@ _MGR = MemoryWorkspaceManager()
 
 def getWorkspaceManager() -> MemoryWorkspaceManager:
     return _MGR
+
+
+# ----------------------------------------------------------------------------- DL4J LayerWorkspaceMgr
+class ArrayType:
+    """What an array is used for inside a network (reference: deeplearning4j-nn nn/workspace/ArrayType.java)."""
+    INPUT, ACTIVATIONS, ACTIVATION_GRAD, FF_WORKING_MEM, BP_WORKING_MEM, RNN_FF_LOOP_WORKING_MEM, RNN_BP_LOOP_WORKING_MEM, \
+        UPDATER_WORKING_MEM, FF_CACHE = ("INPUT", "ACTIVATIONS", "ACTIVATION_GRAD", "FF_WORKING_MEM", "BP_WORKING_MEM",
+                                         "RNN_FF_LOOP_WORKING_MEM", "RNN_BP_LOOP_WORKING_MEM", "UPDATER_WORKING_MEM", "FF_CACHE")
+    ALL = [INPUT, ACTIVATIONS, ACTIVATION_GRAD, FF_WORKING_MEM, BP_WORKING_MEM, RNN_FF_LOOP_WORKING_MEM, RNN_BP_LOOP_WORKING_MEM,
+           UPDATER_WORKING_MEM, FF_CACHE]
+
+
+class _EnteredScope:
+    """`try (MemoryWorkspace ws = mgr.notifyScopeEntered(type))` in Python: the scope is already entered, leaving the
+    ``with`` block closes it exactly once."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        return self.ws
+
+    def __exit__(self, *exc):
+        self.ws.notifyScopeLeft()
+        return False
+
+    def close(self):
+        self.ws.notifyScopeLeft()
+
+    def __getattr__(self, k):
+        return getattr(self.ws, k)
+
+
+class LayerWorkspaceMgr:
+    """Maps ArrayType -> named workspace (reference: nn/workspace/LayerWorkspaceMgr.java; names WS_ALL_LAYERS_ACT,
+    WS_LAYER_WORKING_MEM, WS_RNN_LOOP_WORKING_MEM set up at MultiLayerNetwork.java:1688-1705).
+
+    The networks of this framework run on the HIP caching allocator (and, captured, on a static HIP-graph pool), so by default
+    they use ``noWorkspaces()``; the manager exists for API parity and for code that wants arena allocation of scratch."""
+    WS_ALL_LAYERS_ACT, WS_LAYER_WORKING_MEM, WS_LAYER_ACT_1, WS_LAYER_ACT_2, WS_RNN_LOOP_WORKING_MEM, WS_OUTPUT_MEM = (
+        "WS_ALL_LAYERS_ACT", "WS_LAYER_WORKING_MEM", "WS_LAYER_ACT_1", "WS_LAYER_ACT_2", "WS_RNN_LOOP_WORKING_MEM", "WS_OUTPUT_MEM")
+
+    class Builder:
+        def __init__(self):
+            self._m = LayerWorkspaceMgr()
+
+        def with_(self, arrayType, wsName, conf=None):
+            self._m._names[arrayType] = wsName
+            self._m._confs[wsName] = conf or WorkspaceConfiguration()
+            self._m._scoped_out.discard(arrayType)
+            return self
+
+        def noWorkspaceFor(self, arrayType):
+            self._m._scoped_out.add(arrayType)
+            self._m._names.pop(arrayType, None)
+            return self
+
+        def defaultNoWorkspace(self):
+            for t in ArrayType.ALL:
+                if t not in self._m._names:
+                    self._m._scoped_out.add(t)
+            return self
+
+        def defaultWorkspace(self, wsName, conf=None):
+            for t in ArrayType.ALL:
+                if t not in self._m._names and t not in self._m._scoped_out:
+                    self.with_(t, wsName, conf)
+            return self
+
+        def build(self):
+            return self._m
+
+    def __init__(self):
+        self._names: Dict[str, str] = {}
+        self._confs: Dict[str, WorkspaceConfiguration] = {}
+        self._scoped_out = set()
+        self._helper_ws: Dict[str, object] = {}
+        self.device = None
+
+    @staticmethod
+    def builder():
+        return LayerWorkspaceMgr.Builder()
+
+    @staticmethod
+    def noWorkspaces():
+        return LayerWorkspaceMgr.Builder().defaultNoWorkspace().build()
+
+    noWorkspacesImmutable = noWorkspaces
+
+    def hasConfiguration(self, arrayType):
+        return arrayType in self._names or arrayType in self._scoped_out
+
+    def isScopedOut(self, arrayType):
+        return arrayType in self._scoped_out
+
+    def getWorkspaceName(self, arrayType):
+        self._check(arrayType)
+        return self._names.get(arrayType)
+
+    def getConfiguration(self, arrayType):
+        return self._confs.get(self._names.get(arrayType))
+
+    def setScopedOutFor(self, arrayType):
+        self._scoped_out.add(arrayType)
+        self._names.pop(arrayType, None)
+
+    def setWorkspace(self, arrayType, wsName, conf=None):
+        self._names[arrayType] = wsName
+        self._confs[wsName] = conf or WorkspaceConfiguration()
+        self._scoped_out.discard(arrayType)
+
+    def _check(self, arrayType):
+        if not self.hasConfiguration(arrayType):
+            raise ValueError("No workspace configuration has been provided for array type %s" % arrayType)
+
+    def _ws(self, arrayType) -> "MemoryWorkspace":
+        return getWorkspaceManager().getWorkspaceForCurrentThread(self._confs[self._names[arrayType]], self._names[arrayType], self.device)
+
+    def notifyScopeEntered(self, arrayType):
+        self._check(arrayType)
+        if arrayType in self._scoped_out:
+            return getWorkspaceManager().scopeOutOfWorkspaces()
+        return _EnteredScope(self._ws(arrayType).notifyScopeEntered())
+
+    def notifyScopeBorrowed(self, arrayType):
+        self._check(arrayType)
+        if arrayType in self._scoped_out:
+            return getWorkspaceManager().scopeOutOfWorkspaces()
+        return self._ws(arrayType).notifyScopeBorrowed()
+
+    def isWorkspaceOpen(self, arrayType):
+        self._check(arrayType)
+        return arrayType not in self._scoped_out and getWorkspaceManager().checkIfWorkspaceExistsAndActive(self._names[arrayType])
+
+    def assertOpen(self, arrayType, msg=""):
+        if arrayType not in self._scoped_out and not self.isWorkspaceOpen(arrayType):
+            raise RuntimeError("Assertion failed: expected workspace for array type %s to be open: %s" % (arrayType, msg))
+
+    def assertNotOpen(self, arrayType, msg=""):
+        if arrayType not in self._scoped_out and self.isWorkspaceOpen(arrayType):
+            raise RuntimeError("Assertion failed: expected workspace for array type %s to not be open: %s" % (arrayType, msg))
+
+    def create(self, arrayType, dtype, *shape, order="c"):
+        t = self.createUninitialized(arrayType, dtype, *shape)
+        return t.zero_()
+
+    def createUninitialized(self, arrayType, dtype, *shape, order="c"):
+        self._check(arrayType)
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (list, tuple)) else tuple(shape)
+        if arrayType in self._scoped_out or not self.isWorkspaceOpen(arrayType):
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        return self._ws(arrayType).alloc(shape, dtype, False, self.device)
+
+    def leverageTo(self, arrayType, array):
+        """Move an array into the workspace for ``arrayType`` (detached copy when scoped out)."""
+        self._check(arrayType)
+        t = getattr(array, "_t", array)
+        if arrayType in self._scoped_out or not self.isWorkspaceOpen(arrayType):
+            return t.clone()
+        out = self._ws(arrayType).alloc(tuple(t.shape), t.dtype, False, t.device)
+        return out.copy_(t)
+
+    def dup(self, arrayType, array):
+        return self.leverageTo(arrayType, array)
+
+    def castTo(self, arrayType, dtype, array, dupIfCorrectType=True):
+        t = getattr(array, "_t", array)
+        if t.dtype == dtype:
+            return self.dup(arrayType, t) if dupIfCorrectType else t
+        out = self.createUninitialized(arrayType, dtype, *t.shape)
+        return out.copy_(t)
+
+    def setHelperWorkspace(self, key, value):
+        self._helper_ws[key] = value
+
+    def getHelperWorkspace(self, key):
+        return self._helper_ws.get(key)

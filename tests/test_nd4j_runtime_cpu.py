@@ -531,3 +531,28 @@ def test_backend_spi_device_local_events_validator_inspect():
     info = inspectArray(torch.tensor([0.0, 1.0, -2.0, float("nan"), float("inf"), 3.0]))
     assert (info.min, info.max, info.zeroCount, info.positiveCount, info.negativeCount, info.nanCount, info.infCount) == (-2.0, 3.0, 1, 3, 1, 1, 1)
     assert abs(info.mean - 0.5) < 1e-12
+
+
+def test_layer_workspace_mgr():
+    from deeplearning4j_amd.nd4j.workspace import ArrayType, LayerWorkspaceMgr, WorkspaceConfiguration
+    mgr = (LayerWorkspaceMgr.builder()
+           .with_(ArrayType.ACTIVATIONS, LayerWorkspaceMgr.WS_ALL_LAYERS_ACT, WorkspaceConfiguration(initialSize=1 << 20))
+           .with_(ArrayType.FF_WORKING_MEM, LayerWorkspaceMgr.WS_LAYER_WORKING_MEM, WorkspaceConfiguration(initialSize=1 << 20))
+           .noWorkspaceFor(ArrayType.INPUT).build())
+    assert mgr.getWorkspaceName(ArrayType.ACTIVATIONS) == "WS_ALL_LAYERS_ACT" and mgr.isScopedOut(ArrayType.INPUT)
+    with pytest.raises(ValueError):
+        mgr.getWorkspaceName(ArrayType.BP_WORKING_MEM)
+    mgr.assertNotOpen(ArrayType.ACTIVATIONS)
+    with mgr.notifyScopeEntered(ArrayType.ACTIVATIONS) as ws:
+        mgr.assertOpen(ArrayType.ACTIVATIONS)
+        a = mgr.create(ArrayType.ACTIVATIONS, torch.float32, 4, 5)
+        assert a.shape == (4, 5) and float(a.abs().sum()) == 0 and ws.getThisCycleAllocations() >= 80
+        b = mgr.leverageTo(ArrayType.ACTIVATIONS, torch.ones(3))
+        assert torch.equal(b, torch.ones(3))
+        c = mgr.castTo(ArrayType.ACTIVATIONS, torch.float64, torch.ones(2))
+        assert c.dtype == torch.float64
+    mgr.assertNotOpen(ArrayType.ACTIVATIONS)
+    x = mgr.createUninitialized(ArrayType.INPUT, torch.float32, [2, 2])     # scoped out: plain allocation
+    assert x.shape == (2, 2)
+    none = LayerWorkspaceMgr.noWorkspaces()
+    assert all(none.isScopedOut(t) for t in ArrayType.ALL)
