@@ -63,3 +63,40 @@ def test_sdpa_fully_masked_rows_and_backward():
     mask0[0] = 0
     o0 = A.sdpa(q.detach(), k.detach(), v.detach(), mask0, scale, False)
     assert torch.isfinite(o0.float()).all() and float(o0[0].abs().max()) == 0.0
+
+
+def test_self_attention_network_uses_flash_kernel_and_trains():
+    """SelfAttentionLayer (multi-head, head size 64) in a bf16 network: the layer's SDPA goes through the HIP kernel."""
+    from deeplearning4j_amd.nd4j.learning import Adam
+    from deeplearning4j_amd.nn.conf.base import InputType
+    from deeplearning4j_amd.nn.conf.configuration import NeuralNetConfiguration
+    from deeplearning4j_amd.nn.conf.layers import SelfAttentionLayer, GlobalPoolingLayer, OutputLayer
+    from deeplearning4j_amd.nn.multilayer import MultiLayerNetwork
+    from deeplearning4j_amd.ops import attention as A
+    calls = []
+    orig = A._FlashSDPA.apply
+
+    def spy(*a):
+        calls.append(a[0].shape)
+        return orig(*a)
+    A._FlashSDPA.apply = spy
+    try:
+        conf = (NeuralNetConfiguration.Builder().seed(1).updater(Adam(2e-3)).weightInit("XAVIER").computeDataType("BFLOAT16").list()
+                .layer(SelfAttentionLayer(nIn=32, nOut=64, nHeads=2, headSize=64, projectInput=True))
+                .layer(GlobalPoolingLayer(poolingType="AVG"))
+                .layer(OutputLayer(nIn=64, nOut=3, activation="SOFTMAX", lossFunction="MCXENT"))
+                .setInputType(InputType.recurrent(32, 48)).build())
+        net = MultiLayerNetwork(conf, device="cuda").init()
+        torch.manual_seed(0)
+        x = torch.randn(24, 32, 48, device="cuda")
+        cls = torch.arange(24, device="cuda") % 3
+        x[:, :3, :] += torch.nn.functional.one_hot(cls, 3).float().unsqueeze(2) * 2.0
+        y = torch.nn.functional.one_hot(cls, 3).float()
+        net.fit(x, y)
+        s0 = net.score()
+        for _ in range(80):
+            net.fit(x, y)
+        assert calls and calls[0][1] == 2 and calls[0][3] == 64, "flash SDPA kernel was not used by the attention layer"
+        assert net.score() < 0.5 * s0, (s0, net.score())
+    finally:
+        A._FlashSDPA.apply = orig
