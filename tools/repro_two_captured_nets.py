@@ -3,7 +3,10 @@
 Net `a` captured, then net `b` captured: b's second and later replays read garbage (first bad tensor: output of the first
 stride-2 1x1 igemm conv), even if `a` is never replayed again. One captured net per process (the bench / DP layout: one
 process per GPU, one model) is unaffected, as is an eager net next to a captured one. Ruled out so far: shared workspace
-caches (CLEARWS=1), capture stream sharing, torch.cuda.empty_cache (NOEMPTY=1), replay concurrency (MIDSYNC=1), pool id clash.
+caches (CLEARWS=1), capture stream sharing, torch.cuda.empty_cache (NOEMPTY=1), replay concurrency (MIDSYNC=1), pool id clash,
+the fusion planner (NOFUSE=1), the HIP conv kernels (DL4J_AMD_CONV=library). Observation: with lr 0 the second net's data loss
+is off by the SAME constant (+394.54) for every seed while its parameters stay bit-identical to the first net's; a 6-layer
+conv/BN graph captured twice does not reproduce it.
 Env knobs: NOSEG=1 single-graph capture for b, AEAGER=1 keep a eager, ASTOP=1 stop replaying a after capture.
 """
 import torch, sys
@@ -19,6 +22,10 @@ if os.environ.get('NOEMPTY') == '1':
     _g.torch.cuda.empty_cache = torch.cuda.empty_cache
 m = ResNet50(numClasses=5, inputShape=(3, 160, 160), computeDataType="BFLOAT16", updater=Sgd(0.0))
 a = m.init(device=dev); b = m.init(device=dev)
+if os.environ.get('NOFUSE') == '1':
+    for n_ in (a, b):
+        n_.fusion_enabled = False
+        n_._plan = n_._build_plan()
 import os
 if os.environ.get('AEAGER') != '1':
     a.enableGraphCapture(True)
