@@ -402,6 +402,18 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const WGradP p) {
       }
 }
 
+// fill kernel instead of hipMemsetAsync: memset NODES of captured HIP graphs were observed to misbehave on replay once a
+// second graph exists in the process (see softmax_xent.hip / tools/repro_two_captured_nets.py)
+__global__ void __launch_bounds__(256) zero_f32x4_kernel(float* __restrict__ p, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
+}
+__global__ void __launch_bounds__(256) zero_f32_scalar_kernel(float* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+}
+
 template <int BK_, int BC_>
 static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t st) {
   p.ktiles = p.K / BK_;
@@ -416,7 +428,13 @@ static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t
   splits = (p.P + pps - 1) / pps;
   p.splits = splits; p.pps = pps;
   p.use_atomic = splits > 1;
-  if (p.use_atomic && !prezeroed) hipMemsetAsync(p.dw, 0, sizeof(float) * (size_t)p.K * p.R * p.S * p.C, st);
+  if (p.use_atomic && !prezeroed) {
+    const int64_t n = (int64_t)p.K * p.R * p.S * p.C;
+    if ((reinterpret_cast<uintptr_t>(p.dw) & 15) == 0)
+      hipLaunchKernelGGL(zero_f32x4_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, st, p.dw, n);
+    else    // gradient view at an odd offset of the flat vector
+      hipLaunchKernelGGL(zero_f32_scalar_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, p.dw, n);
+  }
   const int smem = 2 * 64 * (BK_ + BC_) * 2;
   static bool attr_set = false;
   if (!attr_set) {

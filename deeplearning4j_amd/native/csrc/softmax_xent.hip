@@ -72,9 +72,17 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// Zeroing through a kernel, not hipMemsetAsync: a 4-byte memset NODE inside a captured HIP graph was observed to be dropped /
+// mis-ordered on replay when a second graph had been instantiated earlier in the process (the score then accumulated on top
+// of whatever the recycled block held; tools/repro_two_captured_nets.py).
+__global__ void zero_f32_kernel(float* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 DL4J_API int dl4j_softmax_xent(const void* z, const void* y, const int64_t* ylab, void* probs, void* grad,
                                float* row_loss, float* score, int64_t M, int N, int dtype, hipStream_t st) {
-  if (score) hipMemsetAsync(score, 0, sizeof(float), st);
+  if (score) hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(64), 0, st, score, 1);
   if (M <= 0) return 0;
   if (dtype == 1)
     hipLaunchKernelGGL(softmax_xent_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, st, (const bf16_t*)z,

@@ -228,3 +228,30 @@ def test_segmented_graph_capture_matches_eager():
     # every bucket launched exactly once per replayed iteration, tail first
     per_iter = launched[-len(buckets.ranges):]
     assert per_iter == list(range(len(buckets.ranges) - 1, -1, -1))
+
+
+def test_two_captured_networks_in_one_process():
+    """Regression: memset NODES in captured HIP graphs misbehaved once a second graph existed (score / split-K wgrad buffers were
+    not re-zeroed on replay). All zero-fills inside captured regions are kernels now; two captured nets must stay identical."""
+    from tests.test_networks_cpu import _onehot
+    from deeplearning4j_amd.models.resnet50 import ResNet50
+    from deeplearning4j_amd.nd4j.learning import Sgd
+    m = ResNet50(numClasses=5, inputShape=(3, 160, 160), computeDataType="BFLOAT16", updater=Sgd(0.0))
+    a = m.init(device=dev())
+    b = m.init(device=dev())
+    a.enableGraphCapture(True)
+    b.enableGraphCapture(True)
+    x = torch.rand(8, 3, 160, 160, device=dev())
+    y = _onehot(8, 5).float().to(dev())
+    scores = []
+    for it in range(7):
+        a.fit(x, y)
+        b.fit(x, y)
+        junk = [torch.randn(1 << 20, device=dev()) for _ in range(4)]      # churn the general pool between replays
+        scores.append((float(a._score), float(b._score)))
+    assert a._graph_step.graph_a is not None and b._graph_step.graph_a is not None
+    s0 = scores[0][0]
+    for sa, sb in scores:
+        assert abs(sa - s0) < 1e-3 * abs(s0) and abs(sb - s0) < 1e-3 * abs(s0), scores
+    rel = (a._grads - b._grads).norm() / a._grads.norm()
+    assert rel < 1e-3, float(rel)

@@ -1,4 +1,8 @@
-"""KNOWN ISSUE repro (round 1): two HIP-graph-captured networks in ONE process.
+"""RESOLVED (round 1) — bisection script kept as evidence. Root cause: hipMemsetAsync memset nodes inside captured HIP graphs
+(loss accumulator, split-K wgrad buffers) misbehave on replay once a second graph exists in the process; all in-capture zero fills
+are kernels now (softmax_xent.hip zero_f32_kernel, conv_igemm.hip zero_f32x4_kernel).
+
+Original notes: two HIP-graph-captured networks in ONE process.
 
 Net `a` captured, then net `b` captured: b's second and later replays read garbage (first bad tensor: output of the first
 stride-2 1x1 igemm conv), even if `a` is never replayed again. One captured net per process (the bench / DP layout: one
@@ -50,6 +54,8 @@ for it in range(6):
         print("pools", a._graph_step.graph_a.pool(), a._graph_step.graph_b.pool(), b._graph_step.graph_a.pool(), b._graph_step.graph_b.pool())
     print("   cparams nan a/b", int(torch.isnan(a._cparams_flat.float()).sum()), int(torch.isnan(b._cparams_flat.float()).sum()),
           "cparams a==b", bool(torch.equal(a._cparams_flat, b._cparams_flat)), "params a==b", float((a.params()-b.params()).abs().max()))
+    print("   raw _score a/b", float(a._score), float(b._score), "reg a/b", float(a.calcRegularizationScore()), float(b.calcRegularizationScore()),
+          "score ptr a/b", a._score.data_ptr(), b._score.data_ptr())
     ga, gb = a._grads, b._grads
     print(it, "score", a.score(), b.score(), "nan a/b", int(torch.isnan(a.params()).sum()), int(torch.isnan(b.params()).sum()),
           "segs", None if b._graph_step.segments is None else [nb for _, nb in b._graph_step.segments])
@@ -77,3 +83,26 @@ for k, nd in enumerate(b._plan):
                         print(k, nd.out, type(impl).__name__, an, j, tuple(t.shape), "nan", n); cnt += 1
     if cnt > 12:
         break
+print("---- first differing saved tensors a vs b (plan order)")
+cnt = 0
+for k, (na, nb_) in enumerate(zip(a._plan, b._plan)):
+    ia = [na.impl] + ([na.bn2] if getattr(na, "bn2", None) is not None else [])
+    ib = [nb_.impl] + ([nb_.bn2] if getattr(nb_, "bn2", None) is not None else [])
+    for xa, xb in zip(ia, ib):
+        for an, av in vars(xa).items():
+            bv = getattr(xb, an, None)
+            if isinstance(av, torch.Tensor) and isinstance(bv, torch.Tensor) and av.shape == bv.shape and av.is_cuda and av.is_floating_point() and av.numel():
+                d = float((av.float() - bv.float()).abs().max())
+                ref = float(av.float().abs().max())
+                if d > 1e-2 * max(ref, 1e-6) or d != d:
+                    print(k, na.out, type(xa).__name__, an, tuple(av.shape), "maxdiff", d, "ref", ref)
+                    cnt += 1
+    if cnt > 8:
+        break
+print("---- zero-input hypothesis")
+gs = b._graph_step
+print("staging _x equals x:", bool(torch.equal(gs._x.float().reshape(-1)[:1000], b._prep_features(x).float().reshape(-1)[:1000])), gs._x.dtype, tuple(gs._x.shape))
+b._graph_step = None
+for name, xin in (("x", x), ("zeros", torch.zeros_like(x)), ("ones", torch.ones_like(x))):
+    b.computeGradientAndScore([xin], [y])
+    print("eager b score on", name, float(b._score))
