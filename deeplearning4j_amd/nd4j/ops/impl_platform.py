@@ -237,3 +237,59 @@ def _resize(mode):
 
 platform("resize_bilinear", _resize_ok)(_resize("bilinear"))
 platform("resize_nearest_neighbor", _resize_ok)(_resize("nearest"))
+
+
+# ----------------------------------------------------------------------------- index-map family
+def _mv(x):
+    return (isinstance(x, torch.Tensor) and L.use_hip(x) and x.element_size() in (1, 2, 4, 8) and 1 <= x.dim() <= 8 and x.numel() > 0
+            and x.numel() < 2 ** 31 and not x.is_complex())
+
+
+def _pads_of(ins):
+    return [(int(lo), int(hi)) for lo, hi in ins[1].long().reshape(-1, 2).tolist()]
+
+
+def _pad_ok(ins, i, t, b, d):
+    if not (_mv(ins[0]) and len(ins) > 1 and ins[1].numel() == 2 * ins[0].dim()):
+        return False
+    mode = int(i[0]) if i else 0
+    pads = _pads_of(ins)
+    if mode == 1:
+        return all(lo < s and hi < s and lo >= 0 and hi >= 0 for s, (lo, hi) in zip(ins[0].shape, pads))
+    if mode == 2:
+        return all(lo <= s and hi <= s and lo >= 0 and hi >= 0 for s, (lo, hi) in zip(ins[0].shape, pads))
+    return mode == 0 and all(s + lo + hi > 0 for s, (lo, hi) in zip(ins[0].shape, pads))
+
+
+@platform("pad", _pad_ok)
+def _pad(ins, i, t, b, d):
+    mode = {0: "constant", 1: "reflect", 2: "symmetric"}[int(i[0]) if i else 0]
+    val = t[0] if t else (float(ins[2]) if len(ins) > 2 else 0.0)
+    return H.pad_nd(ins[0], _pads_of(ins), mode, val)
+
+
+@platform("mirror_pad", lambda ins, i, t, b, d: _pad_ok(ins, [2 if (i and i[0] == 1) else 1], t, b, d))
+def _mirror_pad(ins, i, t, b, d):
+    return H.pad_nd(ins[0], _pads_of(ins), "symmetric" if (i and i[0] == 1) else "reflect")
+
+
+@platform("reverse", lambda ins, i, t, b, d: _mv(ins[0]) and (bool(i) or len(ins) == 1))
+def _reverse(ins, i, t, b, d):
+    return H.reverse_dims(ins[0], list(i) if i else list(range(ins[0].dim())))
+
+
+@platform("tile", lambda ins, i, t, b, d: _mv(ins[0]) and bool(i) and len(i) >= ins[0].dim() and len(i) <= 8 and all(int(r) >= 1 for r in i))
+def _tile(ins, i, t, b, d):
+    return H.tile_nd(ins[0], list(i))
+
+
+@platform("roll", lambda ins, i, t, b, d: _mv(ins[0]) and len(i) >= 2)
+def _roll(ins, i, t, b, d):
+    dims = list(i[1:])
+    return H.roll_nd(ins[0], [int(i[0])] * len(dims), dims)
+
+
+@platform("concat", lambda ins, i, t, b, d: not (b and b[0]) and len(ins) >= 2 and all(_mv(x) for x in ins)
+          and all(x.dim() == ins[0].dim() and x.dtype == ins[0].dtype for x in ins))
+def _concat(ins, i, t, b, d):
+    return H.concat_nd(list(ins), int(i[0]) if i else 0)

@@ -279,3 +279,129 @@ def sg_pairs_(syn0, syn1, in_idx, tgt_idx, label, lr, hidden=None, scale=1.0):
                                   L.c_int64(n), L.c_int(D), L.c_float(lr), L.c_float(scale), L.c_int64(syn0.shape[0]),
                                   L.c_int64(syn1.shape[0]), L.stream()), "sg_pairs")
     return dh
+
+
+# ----------------------------------------------------------------------------- index-map family (native/csrc/index_map.hip)
+SHIFT, REVERSE, WRAP, REFLECT, SYMMETRIC, STRIDE = 0, 1, 2, 3, 4, 5
+
+
+def _pad_bits(value, dtype):
+    t = torch.tensor([value], dtype=dtype)
+    nbytes = t.element_size()
+    raw = t.view(torch.uint8).numpy().tobytes() if dtype != torch.bfloat16 else t.view(torch.int16).numpy().tobytes()
+    return int.from_bytes(raw[:nbytes], "little")
+
+
+def index_map(x, out, maps, out_base=0, pad_value=0.0):
+    """out[out_base + sum c_d*out_stride_d] = x[sum f_d(c_d)*in_stride_d] over the region; ``maps`` = list of
+    (out_stride, in_stride, region, in_dim, a, b, mode) per dimension. x must be contiguous-or-strided with the given strides
+    and every produced offset in range (validated here on the host)."""
+    assert x.is_cuda and out.is_cuda and x.dtype == out.dtype and 1 <= len(maps) <= 8
+    assert x.element_size() in (1, 2, 4, 8)
+    lo = hi = 0
+    olo = ohi = int(out_base)
+    for (os_, is_, region, in_dim, a, b, mode) in maps:
+        assert region >= 0 and in_dim > 0
+        if region == 0:
+            return out
+        if is_ >= 0:
+            hi += (in_dim - 1) * is_
+        else:
+            lo += (in_dim - 1) * is_
+        if os_ >= 0:
+            ohi += (region - 1) * os_
+        else:
+            olo += (region - 1) * os_
+    xs, os2 = x.untyped_storage().nbytes() // x.element_size(), out.untyped_storage().nbytes() // out.element_size()
+    assert x.storage_offset() + lo >= 0 and x.storage_offset() + hi < xs, "index_map: input range outside the tensor's storage"
+    assert out.storage_offset() + olo >= 0 and out.storage_offset() + ohi < os2, "index_map: output range outside the tensor's storage"
+    flat = []
+    for m in maps:
+        flat += [int(v) for v in m]
+    arr = (ctypes.c_int64 * len(flat))(*flat)
+    rc = L.hip().dl4j_index_map(L.ptr(x), L.ptr(out), L.c_int(len(maps)), arr, L.c_int64(int(out_base)),
+                                ctypes.c_uint64(_pad_bits(pad_value, x.dtype)), L.c_int(x.element_size()), L.stream())
+    L.check(rc, "index_map")
+    return out
+
+
+def _cstrides(shape):
+    st, acc = [], 1
+    for s in reversed(shape):
+        st.append(acc)
+        acc *= int(s)
+    return list(reversed(st))
+
+
+def _merge_to_8(x):
+    if x.dim() > 8:
+        raise ValueError("index_map supports rank <= 8")
+    return x
+
+
+def pad_nd(x, pads, mode="constant", value=0.0):
+    """pads: [(lo, hi)] per dimension (negative = crop); mode constant | reflect | symmetric."""
+    _merge_to_8(x)
+    oshape = [int(s) + int(lo) + int(hi) for s, (lo, hi) in zip(x.shape, pads)]
+    out = torch.empty(oshape, device=x.device, dtype=x.dtype)
+    md = {"constant": SHIFT, "reflect": REFLECT, "symmetric": SYMMETRIC}[mode]
+    ost = _cstrides(oshape)
+    maps = [(ost[k], x.stride(k), oshape[k], x.shape[k], -int(pads[k][0]), 0, md) for k in range(x.dim())]
+    return index_map(x, out, maps, 0, value)
+
+
+def reverse_dims(x, dims):
+    out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    ost = _cstrides(x.shape)
+    ds = {d % x.dim() for d in dims}
+    maps = [(ost[k], x.stride(k), x.shape[k], x.shape[k], 0, 0, REVERSE if k in ds else SHIFT) for k in range(x.dim())]
+    return index_map(x, out, maps)
+
+
+def tile_nd(x, reps):
+    reps = [1] * (x.dim() - len(reps)) + [int(r) for r in reps]
+    xv = x.reshape([1] * (len(reps) - x.dim()) + list(x.shape))
+    oshape = [int(s) * r for s, r in zip(xv.shape, reps)]
+    out = torch.empty(oshape, device=x.device, dtype=x.dtype)
+    ost = _cstrides(oshape)
+    maps = [(ost[k], xv.stride(k), oshape[k], xv.shape[k], 0, 0, WRAP) for k in range(xv.dim())]
+    return index_map(xv, out, maps)
+
+
+def roll_nd(x, shifts, dims):
+    out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    ost = _cstrides(x.shape)
+    sh = {d % x.dim(): int(s) for s, d in zip(shifts, dims)}
+    maps = [(ost[k], x.stride(k), x.shape[k], x.shape[k], -sh.get(k, 0), 0, WRAP) for k in range(x.dim())]
+    return index_map(x, out, maps)
+
+
+def permute_copy(x, perm):
+    """Materialised permute (contiguous result)."""
+    xv = x.permute(*perm)
+    out = torch.empty(xv.shape, device=x.device, dtype=x.dtype)
+    ost = _cstrides(xv.shape)
+    maps = [(ost[k], xv.stride(k), xv.shape[k], xv.shape[k], 0, 0, SHIFT) for k in range(xv.dim())]
+    return index_map(xv, out, maps)
+
+
+def concat_nd(xs, axis):
+    axis = axis % xs[0].dim()
+    oshape = list(xs[0].shape)
+    oshape[axis] = sum(int(t.shape[axis]) for t in xs)
+    out = torch.empty(oshape, device=xs[0].device, dtype=xs[0].dtype)
+    ost = _cstrides(oshape)
+    off = 0
+    for t in xs:
+        maps = [(ost[k], t.stride(k), t.shape[k], t.shape[k], 0, 0, SHIFT) for k in range(t.dim())]
+        index_map(t, out, maps, off * ost[axis])
+        off += int(t.shape[axis])
+    return out
+
+
+def strided_slice_nd(x, begins, steps, counts):
+    oshape = [int(c) for c in counts]
+    out = torch.empty(oshape, device=x.device, dtype=x.dtype)
+    ost = _cstrides(oshape)
+    maps = [(ost[k], x.stride(k), oshape[k], x.shape[k], int(begins[k]), int(steps[k]), STRIDE) for k in range(x.dim())]
+    return index_map(x, out, maps)

@@ -189,3 +189,33 @@ def test_word2vec_trains_on_gpu_with_fused_kernel(algo, hs, neg):
     m.fit()
     assert m.lookupTable.syn0.is_cuda and torch.isfinite(m.lookupTable.syn0).all()
     assert _topic_margin(m, a, b) > 0.25
+
+
+def test_index_map_family():
+    torch.manual_seed(8)
+    x = torch.randn(3, 5, 7)
+    p = torch.tensor([[1, 2], [0, 3], [2, 0]])
+    _platform_vs_generic("pad", [x, p], [0], [1.5])
+    _platform_vs_generic("pad", [x, torch.tensor([[1, 2], [2, 3], [4, 0]])], [1])
+    _platform_vs_generic("pad", [x, torch.tensor([[3, 2], [5, 1], [0, 7]])], [2])
+    _platform_vs_generic("mirror_pad", [x, torch.tensor([[1, 1], [2, 2], [3, 3]])], [0])
+    _platform_vs_generic("mirror_pad", [x, torch.tensor([[1, 1], [2, 2], [3, 3]])], [1])
+    _platform_vs_generic("pad", [x.bfloat16(), p], [0], [-2.0])
+    _platform_vs_generic("pad", [torch.arange(24).reshape(2, 3, 4), torch.tensor([[1, 0], [0, 1], [2, 2]])], [0], [7.0])
+    _platform_vs_generic("reverse", [x], [0, 2])
+    _platform_vs_generic("reverse", [x], [])
+    _platform_vs_generic("tile", [x], [2, 1, 3])
+    _platform_vs_generic("tile", [x], [2, 2, 1, 3])
+    _platform_vs_generic("roll", [x], [3, 2])
+    _platform_vs_generic("roll", [x], [-2, 1])
+    _platform_vs_generic("concat", [x, torch.randn(3, 2, 7), torch.randn(3, 1, 7)], [1])
+    _platform_vs_generic("concat", [x, x * 2], [-1])
+    from deeplearning4j_amd.ops import helpers as H
+    xc = x.to(dev())
+    assert torch.equal(H.permute_copy(xc, (2, 0, 1)).cpu(), x.permute(2, 0, 1).contiguous())
+    assert torch.equal(H.strided_slice_nd(xc, [1, 0, 6], [1, 2, -2], [2, 3, 3]).cpu(), x[1:3, 0:5:2][:, :, [6, 4, 2]])
+    xt = xc.transpose(0, 2)                     # non-contiguous input view
+    assert torch.equal(H.reverse_dims(xt, [1]).cpu(), torch.flip(x.transpose(0, 2), [1]))
+    # indices that leave the input extent are never dereferenced: the kernel writes the pad value instead
+    oob = H.strided_slice_nd(xc, [0, 0, 0], [1, 1, 3], [3, 5, 7]).cpu()
+    assert torch.equal(oob[:, :, :3], x[:, :, 0:7:3]) and float(oob[:, :, 3:].abs().max()) == 0.0
