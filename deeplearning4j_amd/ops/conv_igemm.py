@@ -44,13 +44,23 @@ def supported(x, w, stride, padding, dilation):
     return True
 
 
+_FORCE_TILE = None       # tools/tile_sweep.py sets this to measure every tile on every layer shape
+
+
 def pick_tile(M, K):
+    if _FORCE_TILE is not None and K % _TILES[_FORCE_TILE][1] == 0:
+        return _FORCE_TILE
+    # measured per layer shape with tools/tile_sweep.py (profiles/r1_tile_sweep.md): the largest tile wins as soon as it
+    # gives 1.5 blocks per CU; with 64 output channels the 64x64 tile beats 128x64 (these layers are HBM-bound and the
+    # smaller tile doubles the resident blocks per CU)
+    if K == 64:
+        return 2
     best, best_blocks = None, -1
     for t, (bm, bn) in enumerate(_TILES):
         if K % bn:
             continue
         blocks = ((M + bm - 1) // bm) * (K // bn)
-        if blocks >= 512:
+        if blocks >= 384:
             return t
         if blocks > best_blocks:
             best, best_blocks = t, blocks
