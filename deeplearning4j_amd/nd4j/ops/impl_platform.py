@@ -293,3 +293,258 @@ def _roll(ins, i, t, b, d):
           and all(x.dim() == ins[0].dim() and x.dtype == ins[0].dtype for x in ins))
 def _concat(ins, i, t, b, d):
     return H.concat_nd(list(ins), int(i[0]) if i else 0)
+
+
+# ----------------------------------------------------------------------------- selection / indexed reductions (helpers_select.hip)
+def _reg_segment(kind):
+    platform("unsorted_segment_" + kind, _seg_ok(False))(
+        lambda ins, i, t, b, d: H.segment_reduce(ins[0], ins[1], int(i[0]) if i else int(ins[2]), kind))
+    platform("segment_" + kind, _seg_ok(True))(
+        lambda ins, i, t, b, d: H.segment_reduce(ins[0], ins[1], int(ins[1].max()) + 1, kind))
+
+
+for _kind in ("max", "min", "prod", "mean"):
+    _reg_segment(_kind)
+
+
+def _nd_ok(x, idx):
+    return (L.use_hip(x) and x.is_contiguous() and x.numel() > 0 and x.element_size() in (1, 2, 4, 8) and _idx(idx) and idx.dim() >= 2
+            and 1 <= idx.shape[-1] <= min(8, x.dim()))
+
+
+@platform("gather_nd", lambda ins, i, t, b, d: _nd_ok(ins[0], ins[1]))
+def _gather_nd(ins, i, t, b, d):
+    return H.gather_nd(ins[0], ins[1])
+
+
+def _scatter_nd_ok(ins, i, t, b, d):
+    return (len(ins) >= 3 and _fx(ins[0]) and _nd_ok(ins[0], ins[1]) and isinstance(ins[2], torch.Tensor) and ins[2].is_cuda
+            and ins[2].is_floating_point())
+
+
+for _kind in ("add", "sub", "update"):
+    platform("scatter_nd_" + _kind, _scatter_nd_ok)(lambda ins, i, t, b, d, _k=_kind: H.scatter_nd(ins[0], ins[1], ins[2], _k))
+
+
+@platform("scatter_nd", lambda ins, i, t, b, d: len(ins) >= 3 and _idx(ins[0]) and ins[0].dim() >= 2 and _fx(ins[1])
+          and 1 <= ins[0].shape[-1] <= min(8, ins[2].numel()))
+def _scatter_nd_new(ins, i, t, b, d):
+    shape = [int(v) for v in ins[2].tolist()]
+    return H.scatter_nd(torch.zeros(shape, dtype=ins[1].dtype, device=ins[1].device), ins[0], ins[1], "add")
+
+
+@platform("top_k", lambda ins, i, t, b, d: _fx(ins[0]) and ins[0].dim() >= 1 and 0 < (int(i[0]) if i else int(ins[1])) <= min(ins[0].shape[-1], 256))
+def _top_k(ins, i, t, b, d):
+    from .impl_core import dtype_arg
+    v, ix = H.top_k(ins[0], int(i[0]) if i else int(ins[1]))
+    return v, (ix.to(dtype_arg(d, None, 0, torch.int32)) if d else ix)
+
+
+@platform("histogram_fixed_width", lambda ins, i, t, b, d: _fx(ins[0]) and (len(ins) > 2 or bool(i)) and float(ins[1].reshape(-1)[1]) > float(ins[1].reshape(-1)[0]))
+def _hist_fw(ins, i, t, b, d):
+    rng = ins[1].reshape(-1).float()
+    return H.histogram_fixed_width(ins[0], float(rng[0]), float(rng[1]), int(ins[2]) if len(ins) > 2 else int(i[0]))
+
+
+@platform("lrn_bp", lambda ins, i, t, b, d: _fx(ins[0]) and ins[0].dim() == 4 and ins[0].shape[1] <= 4096 and _fx(ins[1])
+          and ins[1].shape == ins[0].shape and ins[1].dtype == ins[0].dtype)
+def _lrn_bp(ins, i, t, b, d):
+    bias, alpha, beta = (list(t) + [1.0, 1.0, 0.5])[:3] if t else (1.0, 1.0, 0.5)
+    xl = ins[0].permute(0, 2, 3, 1).contiguous()
+    gl = ins[1].permute(0, 2, 3, 1).contiguous()
+    return H.lrn_bwd_last(xl, gl, int(i[0]) if i else 5, bias, alpha, beta).permute(0, 3, 1, 2).contiguous()
+
+
+def _sru_ok(ins, i, t, b, d):
+    if len(ins) < 4 or not all(isinstance(v, torch.Tensor) and L.use_hip(v) and v.dtype == torch.float32 for v in ins[:4]):
+        return False
+    x, w, bias, c0 = ins[:4]
+    return x.dim() == 3 and w.shape == (3 * x.shape[1], x.shape[1]) and bias.numel() == 2 * x.shape[1] and c0.shape == x.shape[:2]
+
+
+@platform("sru", _sru_ok)
+def _sru(ins, i, t, b, d):
+    h, c, _, _ = H.sru_fwd(ins[0], ins[1], ins[2], ins[3], ins[4] if len(ins) > 4 else None)
+    return h, c
+
+
+@platform("sru_bp", lambda ins, i, t, b, d: _sru_ok(ins, i, t, b, d) and len(ins) == 5 and ins[4].shape == ins[0].shape)
+def _sru_bp(ins, i, t, b, d):
+    return H.sru_bwd(ins[0], ins[1], ins[2], ins[3], ins[4])
+
+
+def _color_ok(ins, i, t, b, d):
+    x = ins[0]
+    return _fx(x) and x.dim() >= 1 and x.shape[-1] == 3 and ((int(i[0]) if i else -1) % x.dim()) == x.dim() - 1
+
+
+platform("rgb_to_hsv", _color_ok)(lambda ins, i, t, b, d: H.color_convert(ins[0], "rgb_to_hsv"))
+platform("hsv_to_rgb", _color_ok)(lambda ins, i, t, b, d: H.color_convert(ins[0], "hsv_to_rgb"))
+
+
+def _reg_color_matrix():
+    from . import impl_misc as M
+    inv = lambda m: torch.linalg.inv(torch.tensor(m, dtype=torch.float64)).tolist()
+    for name, mat in (("rgb_to_yuv", M._YUV), ("yuv_to_rgb", inv(M._YUV)), ("rgb_to_yiq", M._YIQ), ("yiq_to_rgb", inv(M._YIQ))):
+        platform(name, _color_ok)(lambda ins, i, t, b, d, _m=mat: H.color_convert(ins[0], "matrix", _m))
+
+
+_reg_color_matrix()
+
+
+def _nms_ok(ins, i, t, b, d):
+    return (len(ins) >= 2 and L.use_hip(ins[0]) and ins[0].dim() == 2 and ins[0].shape[1] == 4 and ins[0].is_floating_point()
+            and ins[1].is_cuda and ins[1].numel() == ins[0].shape[0] and (bool(i) or len(ins) > 2))
+
+
+@platform("non_max_suppression", _nms_ok)
+def _nms(ins, i, t, b, d):
+    max_out = int(i[0]) if i else int(ins[2])
+    thr = t[0] if t else (float(ins[3]) if len(ins) > 3 else 0.5)
+    sthr = t[1] if len(t) > 1 else (float(ins[4]) if len(ins) > 4 else float("-inf"))
+    return H.nms(ins[0], ins[1].reshape(-1), max_out, thr, sthr)
+
+
+platform("non_max_suppression_v3", _nms_ok)(_nms)
+
+
+@platform("non_max_suppression_overlaps", lambda ins, i, t, b, d: len(ins) >= 2 and L.use_hip(ins[0]) and ins[0].dim() == 2
+          and ins[0].shape[0] == ins[0].shape[1] == ins[1].numel() and ins[0].is_floating_point() and (bool(i) or len(ins) > 2))
+def _nms_ov(ins, i, t, b, d):
+    return H.nms(None, ins[1].reshape(-1), int(i[0]) if i else int(ins[2]), t[0] if t else 0.5, t[1] if len(t) > 1 else float("-inf"),
+                 overlaps=ins[0])
+
+
+# ----------------------------------------------------------------------------- spatial (helpers_spatial.hip)
+def _dw_parse(ins, i):
+    from .impl_nn import _conv2d_args, _same_pad
+    c = _conv2d_args(i)
+    x, w = ins[0], ins[1]
+    kH, kW, iC, mC = w.shape
+    if c["same"]:
+        ph, pw = _same_pad(x.shape[2], kH, c["s"][0], c["dl"][0]), _same_pad(x.shape[3], kW, c["s"][1], c["dl"][1])
+        p_lo, out = [ph[0], pw[0]], (-(-x.shape[2] // c["s"][0]), -(-x.shape[3] // c["s"][1]))
+    else:
+        p_lo, out = list(c["p"]), None
+    return c, p_lo, out
+
+
+def _dw_ok(ins, i, t, b, d):
+    from .impl_nn import _conv2d_args
+    c = _conv2d_args(i)
+    x, w = ins[0], ins[1]
+    return (_fx(x) and x.dim() == 4 and isinstance(w, torch.Tensor) and w.is_cuda and w.dim() == 4 and w.dtype == x.dtype and not c["nhwc"]
+            and c["wfmt"] == 0 and w.shape[2] == x.shape[1] and min(c["s"]) > 0)
+
+
+@platform("depthwise_conv2d", _dw_ok)
+def _depthwise(ins, i, t, b, d):
+    c, p_lo, out = _dw_parse(ins, i)
+    w = ins[1]
+    kH, kW, iC, mC = w.shape
+    wk = w.permute(2, 3, 0, 1).reshape(iC * mC, kH, kW).contiguous()
+    return H.depthwise_fwd(ins[0], wk, ins[2] if len(ins) > 2 else None, c["s"], p_lo, c["dl"], out)
+
+
+@platform("depthwise_conv2d_bp", lambda ins, i, t, b, d: len(ins) >= 3 and _dw_ok(ins[:-1], i, t, b, d) and _fx(ins[-1]) and ins[-1].dtype == ins[0].dtype)
+def _depthwise_bp(ins, i, t, b, d):
+    *fw, g = ins
+    c, p_lo, out = _dw_parse(fw, i)
+    x, w = fw[0], fw[1]
+    kH, kW, iC, mC = w.shape
+    wk = w.permute(2, 3, 0, 1).reshape(iC * mC, kH, kW).contiguous()
+    dx, dw, db = H.depthwise_bwd(x, wk, g, c["s"], p_lo, c["dl"], want_bias=len(fw) > 2)
+    dwk = dw.reshape(iC, mC, kH, kW).permute(2, 3, 0, 1).contiguous().to(w.dtype)
+    return (dx, dwk) + ((db.reshape(fw[2].shape).to(fw[2].dtype),) if len(fw) > 2 else ())
+
+
+def _p3_parse(i):
+    a = list(i) + [0] * (15 - len(i))
+    return dict(k=a[0:3], s=a[3:6], p=a[6:9], dl=[max(v, 1) for v in a[9:12]], same=bool(a[12]), extra=a[13], ndhwc=a[14] == 1)
+
+
+def _p3_ok(kind):
+    def ok(ins, i, t, b, d):
+        c = _p3_parse(i)
+        return (_fx(ins[0]) and ins[0].dim() == 5 and not c["ndhwc"] and not c["same"] and min(c["k"]) > 0 and min(c["s"]) > 0
+                and (kind == "max" or c["dl"] == [1, 1, 1]) and all(2 * c["p"][a] <= c["k"][a] for a in range(3)))
+    return ok
+
+
+def _reg_pool3d(kind):
+    @platform(kind + "pool3dnew", _p3_ok(kind))
+    def fwd(ins, i, t, b, d):
+        c = _p3_parse(i)
+        return H.pool3d(ins[0], c["k"], c["s"], c["p"], c["dl"], kind, include_pad=(c["extra"] == 0))
+
+    @platform(kind + "pool3dnew_bp", lambda ins, i, t, b, d: len(ins) == 2 and _p3_ok(kind)(ins, i, t, b, d) and _fx(ins[1]) and ins[1].dtype == ins[0].dtype)
+    def bwd(ins, i, t, b, d):
+        c = _p3_parse(i)
+        x, g = ins
+        y = H.pool3d(x, c["k"], c["s"], c["p"], c["dl"], kind, include_pad=(c["extra"] == 0))
+        return H.pool3d_bwd(x, y, g, c["k"], c["s"], c["p"], c["dl"], kind, include_pad=(c["extra"] == 0))
+
+
+_reg_pool3d("max")
+_reg_pool3d("avg")
+
+
+@platform("upsampling3d", lambda ins, i, t, b, d: L.use_hip(ins[0]) and ins[0].dim() == 5 and ins[0].is_contiguous() and len(i) >= 3
+          and (len(i) < 4 or bool(i[3])) and ins[0].element_size() in (1, 2, 4, 8) and min(i[:3]) > 0)
+def _upsampling3d(ins, i, t, b, d):
+    return H.upsample3d(ins[0], int(i[0]), int(i[1]), int(i[2]))
+
+
+@platform("upsampling3d_bp", lambda ins, i, t, b, d: _fx(ins[1]) and ins[1].dim() == 5 and (not i or bool(i[0]))
+          and all(ins[1].shape[2 + a] % ins[0].shape[2 + a] == 0 for a in range(3)))
+def _upsampling3d_bp(ins, i, t, b, d):
+    x, g = ins[0], ins[1]
+    return H.upsample3d_bwd(g, *[g.shape[2 + a] // x.shape[2 + a] for a in range(3)])
+
+
+def _nhwc_window(x, kH, kW, sH, sW, rH, rW, same):
+    from .impl_nn import _same_pad
+    H_, W_ = x.shape[1], x.shape[2]
+    if same:
+        ph, pw = _same_pad(H_, kH, sH, rH), _same_pad(W_, kW, sW, rW)
+        return [ph[0], pw[0]], (-(-H_ // sH), -(-W_ // sW))
+    return [0, 0], ((H_ - (kH - 1) * rH - 1) // sH + 1, (W_ - (kW - 1) * rW - 1) // sW + 1)
+
+
+def _dil_args(i):
+    rates = list(i[1:5]) if len(i) >= 9 else [1, 1, 1, 1]
+    strides = list(i[5:9]) if len(i) >= 9 else [1, 1, 1, 1]
+    return bool(i[0]) if i else False, rates[1], rates[2], strides[1], strides[2]
+
+
+def _dil_ok(ins, i, t, b, d):
+    x, w = ins[0], ins[1]
+    if not (_fx(x) and x.dim() == 4 and _fx(w) and w.dim() == 3 and w.dtype == x.dtype and w.shape[2] == x.shape[3]):
+        return False
+    same, rH, rW, sH, sW = _dil_args(i)
+    _, out = _nhwc_window(x, w.shape[0], w.shape[1], sH, sW, rH, rW, same)
+    return min(rH, rW, sH, sW) > 0 and min(out) > 0
+
+
+@platform("dilation2d", _dil_ok)
+def _dilation2d(ins, i, t, b, d):
+    x, w = ins[0], ins[1]
+    same, rH, rW, sH, sW = _dil_args(i)
+    p_lo, out = _nhwc_window(x, w.shape[0], w.shape[1], sH, sW, rH, rW, same)
+    return H.dilation2d(x, w, (sH, sW), p_lo, (rH, rW), out)
+
+
+def _patches_ok(ins, i, t, b, d):
+    x = ins[0]
+    if not (L.use_hip(x) and x.dim() == 4 and x.is_contiguous() and x.element_size() in (1, 2, 4, 8) and len(i) >= 6 and min(i[:6]) > 0):
+        return False
+    _, out = _nhwc_window(x, i[0], i[1], i[2], i[3], i[4], i[5], bool(i[6]) if len(i) > 6 else False)
+    return min(out) > 0
+
+
+@platform("extract_image_patches", _patches_ok)
+def _extract_patches(ins, i, t, b, d):
+    x = ins[0]
+    kH, kW, sH, sW, rH, rW = [int(v) for v in i[:6]]
+    p_lo, out = _nhwc_window(x, kH, kW, sH, sW, rH, rW, bool(i[6]) if len(i) > 6 else False)
+    return H.extract_patches(x, kH, kW, (sH, sW), p_lo, (rH, rW), out)

@@ -37,6 +37,14 @@ def _same_or(conf, sizes):
     return tuple(0 for _ in pads), extra
 
 
+def _pad_pairs(conf, sizes):
+    """(lo, hi) padding per spatial dim (Same mode may be asymmetric)."""
+    mode = conf.convolutionMode or ConvolutionMode.Truncate
+    if mode != ConvolutionMode.Same:
+        return [(int(p), int(p)) for p in conf.padding]
+    return [C.same_pad(sz, conf.kernelSize[i], conf.stride[i], conf.dilation[i]) for i, sz in enumerate(sizes)]
+
+
 class Convolution1DLayerImpl(AutogradLayerImpl):
     def type(self):
         return "RECURRENT"
@@ -93,27 +101,25 @@ class Deconvolution3DImpl(AutogradLayerImpl):
 
 
 class DepthwiseConvolution2DImpl(AutogradLayerImpl):
+    """Depthwise stencil through ops/spatial.py (HIP kernels on the GPU in both directions)."""
+
     def _forward(self, x, P, train):
+        from ...ops import spatial as SP
         c = self.conf
-        pad, extra = _same_or(c, x.shape[2:])
-        if extra:
-            x = F.pad(x, extra)
-        # DL4J depthwise weights [kH, kW, nIn, depthMult] -> torch [nIn*mult, 1, kH, kW]
-        W = P["W"].permute(2, 3, 0, 1).reshape(c.nIn * c.depthMultiplier, 1, c.kernelSize[0], c.kernelSize[1])
+        # DL4J depthwise weights [kH, kW, nIn, depthMult] -> [nIn*mult, kH, kW]
+        W = P["W"].permute(2, 3, 0, 1).reshape(c.nIn * c.depthMultiplier, c.kernelSize[0], c.kernelSize[1])
         b = P["b"].reshape(-1) if "b" in P else None
-        return c.activationFn.forward(F.conv2d(x, W, b, c.stride, pad, c.dilation, groups=c.nIn), train)
+        return c.activationFn.forward(SP.depthwise_conv2d(x, W, b, c.stride, _pad_pairs(c, x.shape[2:]), c.dilation), train)
 
 
 class SeparableConvolution2DImpl(AutogradLayerImpl):
     def _forward(self, x, P, train):
+        from ...ops import spatial as SP
         c = self.conf
-        pad, extra = _same_or(c, x.shape[2:])
-        if extra:
-            x = F.pad(x, extra)
-        dw = P["W"].permute(1, 0, 2, 3).reshape(c.nIn * c.depthMultiplier, 1, c.kernelSize[0], c.kernelSize[1])
-        z = F.conv2d(x, dw, None, c.stride, pad, c.dilation, groups=c.nIn)
+        dw = P["W"].permute(1, 0, 2, 3).reshape(c.nIn * c.depthMultiplier, c.kernelSize[0], c.kernelSize[1])
+        z = SP.depthwise_conv2d(x, dw, None, c.stride, _pad_pairs(c, x.shape[2:]), c.dilation)
         b = P["b"].reshape(-1) if "b" in P else None
-        return c.activationFn.forward(F.conv2d(z, P["pW"], b), train)
+        return c.activationFn.forward(F.conv2d(z, P["pW"].to(z.dtype), None if b is None else b.to(z.dtype)), train)
 
 
 class Subsampling1DLayerImpl(AutogradLayerImpl):
@@ -138,13 +144,9 @@ class Subsampling1DLayerImpl(AutogradLayerImpl):
 
 class Subsampling3DLayerImpl(AutogradLayerImpl):
     def _forward(self, x, P, train):
+        from ...ops import spatial as SP
         c = self.conf
-        pad, extra = _same_or(c, x.shape[2:])
-        if extra:
-            x = F.pad(x, extra, value=float("-inf") if c.poolingType == "MAX" else 0.0)
-        if c.poolingType == "MAX":
-            return F.max_pool3d(x, c.kernelSize, c.stride, pad, c.dilation)
-        return F.avg_pool3d(x, c.kernelSize, c.stride, pad)
+        return SP.pool3d(x, c.kernelSize, c.stride, _pad_pairs(c, x.shape[2:]), c.dilation, "max" if c.poolingType == "MAX" else "avg", True)
 
 
 class UpsamplingImpl(AutogradLayerImpl):
@@ -153,6 +155,9 @@ class UpsamplingImpl(AutogradLayerImpl):
 
     def _forward(self, x, P, train):
         s = self.conf.size
+        if len(s) == 3 and x.dim() == 5:
+            from ...ops import spatial as SP
+            return SP.upsample3d(x, s)
         for d, r in enumerate(s):
             x = x.repeat_interleave(r, dim=2 + d)
         return x
@@ -203,13 +208,9 @@ class SpaceToBatchImpl(AutogradLayerImpl):
 
 class LocalResponseNormalizationImpl(AutogradLayerImpl):
     def _forward(self, x, P, train):
+        from ...ops import spatial as SP
         c = self.conf
-        n = int(c.n)
-        sq = (x * x).unsqueeze(1)
-        pad = n // 2
-        sq = F.pad(sq, (0, 0, 0, 0, pad, n - 1 - pad))
-        s = F.avg_pool3d(sq, (n, 1, 1), stride=1).squeeze(1) * n
-        return x / (c.k + c.alpha * s) ** c.beta
+        return SP.lrn(x, int(c.n), c.k, c.alpha, c.beta)
 
 
 class PReLULayerImpl(AutogradLayerImpl):

@@ -405,3 +405,263 @@ def strided_slice_nd(x, begins, steps, counts):
     ost = _cstrides(oshape)
     maps = [(ost[k], x.stride(k), oshape[k], x.shape[k], int(begins[k]), int(steps[k]), STRIDE) for k in range(x.dim())]
     return index_map(x, out, maps)
+
+
+# ----------------------------------------------------------------------------- selection / indexed reductions (helpers_select.hip)
+def segment_reduce(x, seg, num_segments, kind):
+    """kind: 'max' | 'min' | 'prod' | 'mean'. Empty segments keep the identity (-/+ finfo.max, 1) or 0 for mean."""
+    if kind == "mean":
+        s = segment_sum(x, seg, num_segments).float()
+        cnt = segment_sum(torch.ones(x.shape[0], 1, device=x.device), seg, num_segments).clamp_min(1.0)
+        return (s / cnt.reshape([-1] + [1] * (x.dim() - 1))).to(x.dtype)
+    rows = x.shape[0]
+    D = x.numel() // max(rows, 1)
+    big = torch.finfo(x.dtype).max
+    init = {"max": -big, "min": big, "prod": 1.0}[kind]
+    out = torch.full((int(num_segments),) + tuple(x.shape[1:]), init, device=x.device, dtype=torch.float32)
+    L.check(L.hip().dl4j_segment_reduce(L.ptr(x), L.ptr(seg), L.ptr(out), L.c_int64(rows), L.c_int(D), L.c_int64(int(num_segments)),
+                                        L.c_int({"max": 1, "min": 2, "prod": 3}[kind]), L.c_int(L.dtype_code(x)),
+                                        L.c_int(1 if seg.dtype == torch.int64 else 0), L.stream()), "segment_reduce")
+    return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+
+def nd_flatten(idx, shape):
+    """idx [..., k] int tuples into the leading k dims `shape` -> int64 flat row numbers [...], -1 where out of range."""
+    k = idx.shape[-1]
+    assert 1 <= k <= 8 and len(shape) == k and _idx_ok(idx)
+    flat = torch.empty(idx.shape[:-1], device=idx.device, dtype=torch.int64)
+    shp = (ctypes.c_int64 * k)(*[int(v) for v in shape])
+    L.check(L.hip().dl4j_nd_flatten(L.ptr(idx), L.ptr(flat), L.c_int64(flat.numel()), L.c_int(k), shp,
+                                    L.c_int(1 if idx.dtype == torch.int64 else 0), L.stream()), "nd_flatten")
+    return flat
+
+
+def gather_nd(x, idx):
+    k = idx.shape[-1]
+    rows = 1
+    for v in x.shape[:k]:
+        rows *= int(v)
+    flat = nd_flatten(idx, x.shape[:k])
+    out = gather_rows(x.reshape(rows, -1), flat)
+    return out.reshape(tuple(idx.shape[:-1]) + tuple(x.shape[k:]))
+
+
+def scatter_set_rows_(table, flat_idx, src):
+    V, D = table.shape
+    assert table.is_contiguous() and src.is_contiguous() and src.dtype == table.dtype and src.numel() == flat_idx.numel() * D
+    assert flat_idx.dtype == torch.int64 and flat_idx.is_contiguous()
+    L.check(L.hip().dl4j_scatter_set_rows(L.ptr(src), L.ptr(flat_idx), L.ptr(table), L.c_int64(flat_idx.numel()), L.c_int(D), L.c_int64(V),
+                                          L.c_int(table.element_size()), L.stream()), "scatter_set_rows")
+    return table
+
+
+def scatter_nd(x, idx, upd, kind):
+    """kind 'add' | 'sub' | 'update'; returns a new tensor shaped like x."""
+    k = idx.shape[-1]
+    rows = 1
+    for v in x.shape[:k]:
+        rows *= int(v)
+    flat = nd_flatten(idx, x.shape[:k]).reshape(-1)
+    D = x.numel() // max(rows, 1)
+    u = upd.to(x.dtype).contiguous()
+    assert u.numel() == flat.numel() * D, "scatter_nd: updates do not match indices x slice size"
+    if kind == "update":
+        out = x.clone().reshape(rows, D)
+        return scatter_set_rows_(out, flat, u).reshape(x.shape)
+    acc = x.float().reshape(rows, D).contiguous()
+    if acc.data_ptr() == x.data_ptr():
+        acc = acc.clone()
+    scatter_add_rows_(acc, flat, u, -1.0 if kind == "sub" else 1.0)
+    return acc.reshape(x.shape).to(x.dtype)
+
+
+def top_k(x, k):
+    """Values and int64 indices of the k largest entries along the last axis, sorted descending (ties: lower index first)."""
+    cols = x.shape[-1]
+    assert 0 < k <= cols
+    rows = x.numel() // cols
+    vals = torch.empty(tuple(x.shape[:-1]) + (k,), device=x.device, dtype=x.dtype)
+    inds = torch.empty(tuple(x.shape[:-1]) + (k,), device=x.device, dtype=torch.int64)
+    L.check(L.hip().dl4j_top_k(L.ptr(x), L.ptr(vals), L.ptr(inds), L.c_int64(rows), L.c_int(cols), L.c_int(int(k)), L.c_int(L.dtype_code(x)),
+                               L.stream()), "top_k")
+    return vals, inds
+
+
+def histogram_fixed_width(x, lo, hi, bins):
+    counts = torch.zeros(int(bins), device=x.device, dtype=torch.int64)
+    L.check(L.hip().dl4j_histogram(L.ptr(x), L.ptr(counts), L.c_int64(x.numel()), L.c_int(int(bins)), L.c_float(lo), L.c_float(hi),
+                                   L.c_int(L.dtype_code(x)), L.stream()), "histogram")
+    return counts
+
+
+def lrn_bwd_last(x, g, depth, bias, alpha, beta):
+    C = x.shape[-1]
+    assert C <= 4096 and g.shape == x.shape and g.dtype == x.dtype and g.is_contiguous()
+    dx = torch.empty_like(x)
+    L.check(L.hip().dl4j_lrn_bwd(L.ptr(x), L.ptr(g), L.ptr(dx), L.c_int64(x.numel() // C), L.c_int(C), L.c_int(int(depth)), L.c_float(bias),
+                                 L.c_float(alpha), L.c_float(beta), L.c_int(L.dtype_code(x)), L.stream()), "lrn_bwd")
+    return dx
+
+
+def sru_fwd(x, w, bias, c0, mask=None):
+    """x [B, K, T] fp32, w [3K, K], bias [2K], c0 [B, K] -> (h, c) [B, K, T]; the projection is a library GEMM, the recurrence one kernel."""
+    B, K, T = x.shape
+    assert w.shape == (3 * K, K) and bias.numel() == 2 * K and c0.shape == (B, K)
+    xm = (x * mask.unsqueeze(-1) if mask is not None else x).float().contiguous()
+    z = torch.matmul(w.float(), xm).contiguous()                      # [B, 3K, T]
+    h = torch.empty_like(xm)
+    cs = torch.empty_like(xm)
+    L.check(L.hip().dl4j_sru_fwd(L.ptr(xm), L.ptr(z), L.ptr(_f32(bias)), L.ptr(c0.float().contiguous()), L.ptr(h), L.ptr(cs), L.c_int(B),
+                                 L.c_int(K), L.c_int(T), L.stream()), "sru_fwd")
+    return h, cs, z, xm
+
+
+def sru_bwd(x, w, bias, c0, gh, gc_last=None, mask=None):
+    """Returns (dx, dw, db, dc0) for sru_fwd given dL/dh (and optionally dL/dc_T)."""
+    B, K, T = x.shape
+    h, cs, z, xm = sru_fwd(x, w, bias, c0, mask)
+    dz = torch.empty_like(z)
+    dxd = torch.empty_like(xm)
+    dc0 = torch.empty(B, K, device=x.device, dtype=torch.float32)
+    ghc = gh.float().contiguous()
+    gcl = None if gc_last is None else gc_last.float().contiguous()
+    L.check(L.hip().dl4j_sru_bwd(L.ptr(xm), L.ptr(z), L.ptr(_f32(bias)), L.ptr(c0.float().contiguous()), L.ptr(cs), L.ptr(ghc), L.ptr(gcl),
+                                 L.ptr(dz), L.ptr(dxd), L.ptr(dc0), L.c_int(B), L.c_int(K), L.c_int(T), L.stream()), "sru_bwd")
+    wf = w.float()
+    dx = torch.matmul(wf.t(), dz) + dxd
+    if mask is not None:
+        dx = dx * mask.unsqueeze(-1)
+    dw = torch.einsum("bot,bkt->ok", dz, xm)
+    db = dz[:, K:].sum((0, 2))
+    return dx, dw, db, dc0
+
+
+def color_convert(x, mode, matrix=None):
+    """x [..., 3] channel-last; mode 'rgb_to_hsv' | 'hsv_to_rgb' | 'matrix' (3x3 nested list, out = M @ pixel)."""
+    assert x.shape[-1] == 3
+    y = torch.empty_like(x)
+    m = None
+    if mode == "matrix":
+        m = (ctypes.c_float * 9)(*[float(v) for row in matrix for v in row])
+    L.check(L.hip().dl4j_color_convert(L.ptr(x), L.ptr(y), L.c_int64(x.numel() // 3), L.c_int({"rgb_to_hsv": 0, "hsv_to_rgb": 1, "matrix": 2}[mode]),
+                                       m, L.c_int(L.dtype_code(x)), L.stream()), "color_convert")
+    return y
+
+
+def nms(boxes, scores, max_out, iou_thr, score_thr=float("-inf"), overlaps=None):
+    """Greedy NMS; boxes [N, 4] fp32 (or a precomputed overlaps [N, N]); returns int32 kept indices in selection order."""
+    N = scores.numel()
+    if N == 0 or max_out <= 0:
+        return torch.empty(0, dtype=torch.int32, device=scores.device)
+    sc = scores.float().contiguous()
+    order = torch.argsort(sc, descending=True, stable=True)
+    keep = torch.empty(int(min(max_out, N)), device=sc.device, dtype=torch.int32)
+    count = torch.empty(1, device=sc.device, dtype=torch.int32)
+    bx = None if boxes is None else boxes.float().contiguous()
+    ov = None if overlaps is None else overlaps.float().contiguous()
+    assert (bx is not None and bx.shape == (N, 4)) or (ov is not None and ov.shape == (N, N))
+    st = max(float(score_thr), -3.0e38)
+    L.check(L.hip().dl4j_nms(L.ptr(bx), L.ptr(ov), L.ptr(sc), L.ptr(order), L.ptr(keep), L.ptr(count), L.c_int(N), L.c_int(keep.numel()),
+                             L.c_float(iou_thr), L.c_float(st), L.stream()), "nms")
+    return keep[:int(count.item())]
+
+
+# ----------------------------------------------------------------------------- spatial (helpers_spatial.hip)
+def _dw_geom(x, w, s, p_lo, dl, out_hw=None):
+    N, C, H, W = x.shape
+    OC, kH, kW = w.shape
+    assert OC % C == 0
+    if out_hw is None:
+        oH = (H + 2 * p_lo[0] - dl[0] * (kH - 1) - 1) // s[0] + 1
+        oW = (W + 2 * p_lo[1] - dl[1] * (kW - 1) - 1) // s[1] + 1
+    else:
+        oH, oW = out_hw
+    assert oH > 0 and oW > 0
+    return (ctypes.c_int * 15)(N, C, OC // C, H, W, kH, kW, oH, oW, s[0], s[1], p_lo[0], p_lo[1], dl[0], dl[1]), oH, oW
+
+
+def depthwise_fwd(x, w, bias, s, p_lo, dl, out_hw=None):
+    """x [N, C, H, W], w [C*mC, kH, kW] (same dtype), bias fp32-able [C*mC]; p_lo = top/left padding, out_hw overrides the output size
+    (asymmetric SAME padding: the bottom/right padding is implied by the bounds checks)."""
+    g, oH, oW = _dw_geom(x, w, s, p_lo, dl, out_hw)
+    y = torch.empty((x.shape[0], w.shape[0], oH, oW), device=x.device, dtype=x.dtype)
+    L.check(L.hip().dl4j_depthwise_fwd(L.ptr(x), L.ptr(w), L.ptr(_f32(bias)), L.ptr(y), g, L.c_int(L.dtype_code(x)), L.stream()), "depthwise_fwd")
+    return y
+
+
+def depthwise_bwd(x, w, dy, s, p_lo, dl, want_bias=True):
+    """Returns (dx, dw fp32 [C*mC, kH, kW], db fp32 [C*mC] or None)."""
+    g, oH, oW = _dw_geom(x, w, s, p_lo, dl, (dy.shape[2], dy.shape[3]))
+    assert dy.shape[:2] == (x.shape[0], w.shape[0]) and dy.dtype == x.dtype and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    L.check(L.hip().dl4j_depthwise_bwd_x(L.ptr(dy), L.ptr(w), L.ptr(dx), g, L.c_int(L.dtype_code(x)), L.stream()), "depthwise_bwd_x")
+    dw = torch.empty(w.shape, device=x.device, dtype=torch.float32)
+    db = torch.empty(w.shape[0], device=x.device, dtype=torch.float32) if want_bias else None
+    L.check(L.hip().dl4j_depthwise_bwd_w(L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), g, L.c_int(L.dtype_code(x)), L.stream()), "depthwise_bwd_w")
+    return dx, dw, db
+
+
+def _p3_geom(shape, k, s, p, dl, mode, include_pad, out=None):
+    D, H, W = shape
+    if out is None:
+        out = [(n + 2 * p[a] - dl[a] * (k[a] - 1) - 1) // s[a] + 1 for a, n in enumerate((D, H, W))]
+    assert all(o > 0 for o in out)
+    return (ctypes.c_int * 20)(D, H, W, *k, *out, *s, *p, *dl, {"max": 0, "avg": 1, "pnorm": 2}[mode], int(include_pad)), out
+
+
+def pool3d(x, k, s, p, dl=(1, 1, 1), mode="max", include_pad=True, pnorm=2.0, out_dhw=None):
+    """x [N, C, D, H, W] contiguous -> [N, C, oD, oH, oW]; p = front/top/left padding (trailing padding is implied by out_dhw)."""
+    N, C = x.shape[:2]
+    g, out = _p3_geom(x.shape[2:], list(k), list(s), list(p), list(dl), mode, include_pad, out_dhw)
+    y = torch.empty((N, C) + tuple(out), device=x.device, dtype=x.dtype)
+    L.check(L.hip().dl4j_pool3d_fwd(L.ptr(x), L.ptr(y), L.c_int64(N * C), g, L.c_float(pnorm), L.c_int(L.dtype_code(x)), L.stream()), "pool3d_fwd")
+    return y
+
+
+def pool3d_bwd(x, y, gy, k, s, p, dl=(1, 1, 1), mode="max", include_pad=True, pnorm=2.0):
+    N, C = x.shape[:2]
+    assert y.shape == gy.shape and y.dtype == x.dtype == gy.dtype and y.is_contiguous() and gy.is_contiguous()
+    g, _ = _p3_geom(x.shape[2:], list(k), list(s), list(p), list(dl), mode, include_pad, list(y.shape[2:]))
+    dx = torch.empty_like(x)
+    L.check(L.hip().dl4j_pool3d_bwd(L.ptr(x), L.ptr(y), L.ptr(gy), L.ptr(dx), L.c_int64(N * C), g, L.c_float(pnorm), L.c_int(L.dtype_code(x)),
+                                    L.stream()), "pool3d_bwd")
+    return dx
+
+
+def upsample3d(x, fD, fH, fW):
+    N, C, D, H, W = x.shape
+    y = torch.empty((N, C, D * fD, H * fH, W * fW), device=x.device, dtype=x.dtype)
+    L.check(L.hip().dl4j_upsample3d_fwd(L.ptr(x), L.ptr(y), L.c_int64(N * C), L.c_int(D), L.c_int(H), L.c_int(W), L.c_int(fD), L.c_int(fH),
+                                        L.c_int(fW), L.c_int(x.element_size()), L.stream()), "upsample3d_fwd")
+    return y
+
+
+def upsample3d_bwd(g, fD, fH, fW):
+    N, C, oD, oH, oW = g.shape
+    assert oD % fD == 0 and oH % fH == 0 and oW % fW == 0
+    dx = torch.empty((N, C, oD // fD, oH // fH, oW // fW), device=g.device, dtype=g.dtype)
+    L.check(L.hip().dl4j_upsample3d_bwd(L.ptr(g), L.ptr(dx), L.c_int64(N * C), L.c_int(oD // fD), L.c_int(oH // fH), L.c_int(oW // fW),
+                                        L.c_int(fD), L.c_int(fH), L.c_int(fW), L.c_int(L.dtype_code(g)), L.stream()), "upsample3d_bwd")
+    return dx
+
+
+def _nhwc_geom(x, kH, kW, s, p_lo, r, out_hw):
+    N, H, W, C = x.shape
+    return (ctypes.c_int * 14)(N, H, W, C, kH, kW, out_hw[0], out_hw[1], s[0], s[1], p_lo[0], p_lo[1], r[0], r[1])
+
+
+def dilation2d(x, w, s, p_lo, r, out_hw):
+    """x [N, H, W, C], w [kH, kW, C] -> [N, oH, oW, C] = max over taps of (x + w); out-of-image taps are skipped."""
+    assert w.shape[2] == x.shape[3] and w.dtype == x.dtype and w.is_contiguous()
+    y = torch.empty((x.shape[0], out_hw[0], out_hw[1], x.shape[3]), device=x.device, dtype=x.dtype)
+    L.check(L.hip().dl4j_dilation2d(L.ptr(x), L.ptr(w), L.ptr(y), _nhwc_geom(x, w.shape[0], w.shape[1], s, p_lo, r, out_hw),
+                                    L.c_int(L.dtype_code(x)), L.stream()), "dilation2d")
+    return y
+
+
+def extract_patches(x, kH, kW, s, p_lo, r, out_hw):
+    """x [N, H, W, C] -> [N, oH, oW, kH*kW*C] (zero padded)."""
+    y = torch.empty((x.shape[0], out_hw[0], out_hw[1], kH * kW * x.shape[3]), device=x.device, dtype=x.dtype)
+    L.check(L.hip().dl4j_extract_patches(L.ptr(x), L.ptr(y), _nhwc_geom(x, kH, kW, s, p_lo, r, out_hw), L.c_int(x.element_size()), L.stream()),
+            "extract_patches")
+    return y

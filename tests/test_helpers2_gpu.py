@@ -1,0 +1,227 @@
+"""Second batch of declarable-helper HIP kernels (helpers_select.hip, helpers_spatial.hip) vs the generic ops on CPU fp32.
+Every platform helper must accept the case through its isUsable predicate and agree with the generic implementation."""
+import pytest
+import torch
+
+from test_helpers_gpu import _platform_vs_generic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind", ["max", "min", "prod", "mean"])
+def test_segment_reductions(kind):
+    torch.manual_seed(0)
+    x = torch.randn(10, 6) + 0.5
+    ids = torch.tensor([0, 0, 1, 1, 1, 3, 3, 4, 4, 4])           # segment 2 is empty -> identity
+    _platform_vs_generic("segment_" + kind, [x, ids])
+    perm = torch.randperm(10)
+    _platform_vs_generic("unsorted_segment_" + kind, [x[perm], ids[perm].int()], [6])
+    x3 = torch.randn(9, 2, 5).bfloat16()
+    _platform_vs_generic("unsorted_segment_" + kind, [x3, torch.randint(0, 4, (9,))], [4], atol=3e-2, rtol=3e-2)
+
+
+def test_gather_scatter_nd():
+    torch.manual_seed(1)
+    x = torch.randn(4, 5, 6)
+    _platform_vs_generic("gather_nd", [x, torch.tensor([[0, 1], [3, 4], [2, 2]])])
+    _platform_vs_generic("gather_nd", [x, torch.stack([torch.randint(0, 4, (7,)), torch.randint(0, 5, (7,)), torch.randint(0, 6, (7,))], 1)])
+    _platform_vs_generic("gather_nd", [x, torch.randint(0, 4, (2, 3, 1)).int()])
+    base = torch.randn(6, 4)
+    idx = torch.tensor([[1], [3], [1], [5], [1]])
+    upd = torch.randn(5, 4)
+    _platform_vs_generic("scatter_nd_add", [base, idx, upd])
+    _platform_vs_generic("scatter_nd_sub", [base, idx, upd])
+    _platform_vs_generic("scatter_nd_update", [base, torch.tensor([[4], [0], [2]]), torch.randn(3, 4)])
+    _platform_vs_generic("scatter_nd", [torch.tensor([[0, 1], [2, 2], [0, 1]]), torch.randn(3, 5), torch.tensor([3, 4, 5])])
+    cube = torch.randn(3, 4, 5)
+    _platform_vs_generic("scatter_nd_add", [cube, torch.tensor([[0, 1], [2, 3], [0, 1]]), torch.randn(3, 5)])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_top_k(dtype):
+    torch.manual_seed(2)
+    x = torch.randperm(7 * 300).reshape(7, 300).float().div(8.0)                       # distinct values
+    if dtype == torch.bfloat16:
+        x = torch.stack([torch.randperm(200)[:130].float() for _ in range(7)]).to(dtype)   # integers < 256 are exact in bf16
+    v, ix = _platform_vs_generic("top_k", [x], [5])
+    assert ix.dtype == torch.int64
+    _platform_vs_generic("top_k", [x.reshape(7, 2, -1)], [3])
+    # ties: deterministic lower-index-first order
+    from deeplearning4j_amd.ops import helpers as H
+    tv, ti = H.top_k(torch.tensor([[1.0, 3.0, 3.0, 2.0, 3.0]], device="cuda"), 4)
+    assert ti.tolist() == [[1, 2, 4, 3]] and tv.tolist() == [[3.0, 3.0, 3.0, 2.0]]
+
+
+def test_histogram_fixed_width():
+    torch.manual_seed(3)
+    x = (torch.randint(0, 1000, (10000,)).float() + 0.5) / 1000 * 4 - 2
+    got = _platform_vs_generic("histogram_fixed_width", [x, torch.tensor([-2.0, 2.0])], [20])
+    assert int(got[0].sum()) == 10000
+    _platform_vs_generic("histogram_fixed_width", [x * 3, torch.tensor([-2.0, 2.0])], [7])        # out-of-range values clamp to the edge bins
+    from deeplearning4j_amd.ops import helpers as H
+    big = H.histogram_fixed_width(torch.rand(100000, device="cuda"), 0.0, 1.0, 5000)              # > LDS bins: global atomics path
+    assert int(big.sum()) == 100000 and big.numel() == 5000
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lrn_bp(dtype):
+    torch.manual_seed(4)
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=3e-2, rtol=3e-2)
+    x = torch.randn(2, 16, 5, 5).to(dtype)
+    g = torch.randn(2, 16, 5, 5).to(dtype)
+    _platform_vs_generic("lrn_bp", [x, g], [2], [1.0, 0.05, 0.75], **tol)
+    _platform_vs_generic("lrn_bp", [x, g], [5], [2.0, 1e-2, 0.5], **tol)
+
+
+def test_sru_fwd_bwd():
+    torch.manual_seed(5)
+    B, K, T = 3, 8, 11
+    x, w, bias, c0 = torch.randn(B, K, T), torch.randn(3 * K, K) * 0.4, torch.randn(2 * K) * 0.3, torch.randn(B, K)
+    _platform_vs_generic("sru", [x, w, bias, c0], atol=2e-5)
+    _platform_vs_generic("sru_bp", [x, w, bias, c0, torch.randn(B, K, T)], atol=1e-4, rtol=1e-3)
+    B, K, T = 70, 96, 5                                                                          # more than one block of (b, k) lanes
+    x, w, bias, c0 = torch.randn(B, K, T), torch.randn(3 * K, K) * 0.1, torch.randn(2 * K) * 0.3, torch.randn(B, K)
+    _platform_vs_generic("sru", [x, w, bias, c0], atol=5e-5)
+    _platform_vs_generic("sru_bp", [x, w, bias, c0, torch.randn(B, K, T)], atol=5e-4, rtol=1e-3)
+
+
+def test_colour_conversions():
+    torch.manual_seed(6)
+    rgb = torch.rand(4, 5, 3)
+    rgb[0, 0] = torch.tensor([0.3, 0.3, 0.3])          # grey: hue 0, saturation 0
+    rgb[0, 1] = torch.tensor([0.0, 0.0, 0.0])
+    hsv = _platform_vs_generic("rgb_to_hsv", [rgb])[0]
+    back = _platform_vs_generic("hsv_to_rgb", [hsv.cpu()])[0]
+    assert torch.allclose(back.cpu(), rgb, atol=1e-5)
+    for name in ("rgb_to_yuv", "yuv_to_rgb", "rgb_to_yiq", "yiq_to_rgb"):
+        _platform_vs_generic(name, [rgb])
+    _platform_vs_generic("rgb_to_hsv", [rgb.bfloat16()], atol=2e-2, rtol=2e-2)
+
+
+def test_non_max_suppression():
+    torch.manual_seed(7)
+    ctr = torch.rand(60, 2)
+    sz = torch.rand(60, 2) * 0.3 + 0.05
+    boxes = torch.cat([ctr - sz / 2, ctr + sz / 2], 1)
+    boxes[5] = boxes[5][[2, 3, 0, 1]]                  # flipped corners are normalised
+    scores = torch.randperm(60).float() / 60
+    got = _platform_vs_generic("non_max_suppression", [boxes, scores], [12], [0.3])
+    assert got[0].dtype == torch.int32
+    _platform_vs_generic("non_max_suppression", [boxes, scores], [100], [0.5, 0.405])           # score threshold cuts the list
+    from deeplearning4j_amd.nd4j.ops.impl_misc import _iou
+    _platform_vs_generic("non_max_suppression_overlaps", [_iou(boxes), scores], [15], [0.3])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_depthwise_conv2d_fwd_bwd(dtype):
+    torch.manual_seed(8)
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=8e-2, rtol=5e-2)
+    x = torch.randn(2, 3, 9, 10).to(dtype)
+    w = (torch.randn(3, 3, 3, 2) * 0.5).to(dtype)       # [kH, kW, iC, mC]
+    bias = torch.randn(6)
+    for args in ([3, 3, 1, 1, 1, 1, 1, 1, 0, 0], [3, 3, 2, 2, 0, 0, 1, 1, 1, 0], [3, 3, 1, 2, 2, 1, 2, 1, 0, 0], [3, 3, 2, 1, 0, 0, 1, 2, 1, 0]):
+        y = _platform_vs_generic("depthwise_conv2d", [x, w, bias], args, **tol)[0]
+        _platform_vs_generic("depthwise_conv2d", [x, w], args, **tol)
+        g = torch.randn(*y.shape).to(dtype)
+        bt = dict(atol=tol["atol"] * 8, rtol=tol["rtol"] * 2)
+        _platform_vs_generic("depthwise_conv2d_bp", [x, w, bias, g], args, **bt)
+
+
+@pytest.mark.parametrize("kind", ["max", "avg"])
+def test_pool3d_fwd_bwd(kind):
+    torch.manual_seed(9)
+    x = torch.randn(2, 3, 7, 8, 9)
+    for args in ([2, 2, 2, 2, 2, 2, 0, 0, 0, 1, 1, 1, 0, 0, 0], [3, 3, 3, 2, 2, 2, 1, 1, 1, 1, 1, 1, 0, 0, 0],
+                 [3, 2, 3, 1, 2, 1, 1, 0, 1, 1, 1, 1, 0, 1, 0]):
+        y = _platform_vs_generic(kind + "pool3dnew", [x], args)[0]
+        _platform_vs_generic(kind + "pool3dnew_bp", [x, torch.randn(*y.shape)], args)
+    if kind == "max":
+        args = [2, 2, 2, 1, 1, 1, 0, 0, 0, 2, 2, 2, 0, 0, 0]          # dilated windows
+        y = _platform_vs_generic("maxpool3dnew", [x], args)[0]
+        _platform_vs_generic("maxpool3dnew_bp", [x, torch.randn(*y.shape)], args)
+    xb = torch.randn(1, 2, 4, 6, 6).bfloat16()
+    _platform_vs_generic(kind + "pool3dnew", [xb], [2, 2, 2, 2, 2, 2, 0, 0, 0, 1, 1, 1, 0, 0, 0], atol=2e-2, rtol=2e-2)
+
+
+def test_upsampling3d_fwd_bwd():
+    torch.manual_seed(10)
+    x = torch.randn(2, 3, 2, 3, 4)
+    y = _platform_vs_generic("upsampling3d", [x], [2, 3, 2, 1])[0]
+    assert tuple(y.shape) == (2, 3, 4, 9, 8)
+    _platform_vs_generic("upsampling3d_bp", [x, torch.randn(2, 3, 4, 9, 8)], [1])
+    _platform_vs_generic("upsampling3d", [x.bfloat16()], [1, 2, 2, 1])
+    _platform_vs_generic("upsampling3d_bp", [x.bfloat16(), torch.randn(2, 3, 2, 6, 8).bfloat16()], [1], atol=3e-2, rtol=3e-2)
+
+
+def test_dilation2d_and_extract_patches():
+    torch.manual_seed(11)
+    x = torch.randn(2, 7, 8, 3)
+    w = torch.randn(3, 2, 3)
+    for same in (0, 1):
+        _platform_vs_generic("dilation2d", [x, w], [same, 1, 1, 1, 1, 1, 1, 1, 1])
+        _platform_vs_generic("dilation2d", [x, w], [same, 1, 2, 1, 1, 1, 1, 2, 1])
+        _platform_vs_generic("extract_image_patches", [x], [3, 2, 2, 1, 1, 2, same])
+        _platform_vs_generic("extract_image_patches", [x], [2, 2, 1, 1, 1, 1, same])
+    _platform_vs_generic("extract_image_patches", [x.bfloat16()], [3, 3, 2, 2, 1, 1, 1])
+
+
+def _grads(fn, tensors, device):
+    leaves = [t.detach().to(device).requires_grad_(True) for t in tensors]
+    y = fn(*leaves)
+    torch.manual_seed(99)
+    g = torch.randn(y.shape)
+    y.backward(g.to(device))
+    return [y.detach().cpu()] + [l.grad.cpu() for l in leaves]
+
+
+def test_spatial_autograd_entry_points_match_cpu_fallback():
+    """ops/spatial.py: the HIP path (GPU) and the ATen fallback (CPU) of the same entry point agree, forward and backward."""
+    from deeplearning4j_amd.ops import spatial as SP
+    torch.manual_seed(12)
+    x, w, b = torch.randn(2, 4, 9, 11), torch.randn(8, 3, 3) * 0.4, torch.randn(8)
+    cases = [
+        (lambda x, w, b: SP.depthwise_conv2d(x, w, b, (1, 1), ((1, 1), (1, 1)), (1, 1)), [x, w, b]),
+        (lambda x, w, b: SP.depthwise_conv2d(x, w, b, (2, 2), ((0, 1), (1, 1)), (1, 1)), [x, w, b]),          # asymmetric SAME padding
+        (lambda x, w: SP.depthwise_conv2d(x, w, None, (1, 2), ((2, 2), (1, 1)), (2, 1)), [x, w]),
+        (lambda v: SP.pool3d(v, (2, 2, 2), (2, 2, 2), ((0, 0), (0, 0), (0, 0)), (1, 1, 1), "max"), [torch.randn(2, 3, 6, 6, 8)]),
+        (lambda v: SP.pool3d(v, (3, 3, 3), (2, 2, 2), ((0, 1), (1, 1), (0, 1)), (1, 1, 1), "max"), [torch.randn(2, 3, 6, 7, 8)]),
+        (lambda v: SP.pool3d(v, (3, 3, 3), (2, 2, 2), ((0, 1), (1, 1), (0, 1)), (1, 1, 1), "avg", True), [torch.randn(2, 3, 6, 7, 8)]),
+        (lambda v: SP.pool3d(v, (2, 3, 2), (1, 2, 1), ((1, 1), (1, 1), (0, 0)), (1, 1, 1), "avg", False), [torch.randn(2, 3, 6, 7, 8)]),
+        (lambda v: SP.upsample3d(v, (2, 1, 3)), [torch.randn(2, 3, 3, 4, 5)]),
+        (lambda v: SP.lrn(v, 5, 2.0, 1e-2, 0.75), [torch.randn(2, 12, 5, 6)]),
+    ]
+    for k, (fn, ts) in enumerate(cases):
+        ref = _grads(fn, ts, "cpu")
+        got = _grads(fn, ts, "cuda")
+        for r, g in zip(ref, got):
+            assert r.shape == g.shape, (k, r.shape, g.shape)
+            assert torch.allclose(r, g, atol=2e-4, rtol=1e-4), (k, float((r - g).abs().max()))
+
+
+def test_long_tail_layers_train_on_gpu_through_hip_kernels():
+    """Depthwise / separable / LRN layers in a MultiLayerNetwork: one fit step on the GPU equals the CPU step."""
+    from deeplearning4j_amd.nd4j.learning import Sgd
+    from deeplearning4j_amd.nn.conf.base import InputType
+    from deeplearning4j_amd.nn.conf.configuration import NeuralNetConfiguration
+    from deeplearning4j_amd.nn.conf import layers as C
+    from deeplearning4j_amd.nn.multilayer import MultiLayerNetwork
+
+    def build(device):
+        conf = (NeuralNetConfiguration.Builder().seed(7).updater(Sgd(0.05)).weightInit("XAVIER").list()
+                .layer(C.DepthwiseConvolution2D(kernelSize=(3, 3), depthMultiplier=2, nIn=3, nOut=6, activation="RELU"))
+                .layer(C.LocalResponseNormalization())
+                .layer(C.SeparableConvolution2D(kernelSize=(3, 3), nIn=6, nOut=5, convolutionMode="Same", activation="TANH"))
+                .layer(C.OutputLayer(nOut=4, activation="SOFTMAX", lossFunction="MCXENT"))
+                .setInputType(InputType.convolutional(8, 8, 3)).build())
+        return MultiLayerNetwork(conf, device=device).init()
+
+    torch.manual_seed(13)
+    x = torch.randn(6, 3, 8, 8)
+    y = torch.nn.functional.one_hot(torch.randint(0, 4, (6,)), 4).float()
+    cpu = build("cpu")
+    gpu = build("cuda")
+    gpu.setParams(cpu.params().to("cuda"))
+    cpu.fit(x, y)
+    gpu.fit(x.cuda(), y.cuda())
+    pc, pg = cpu.params().reshape(-1).cpu(), gpu.params().reshape(-1).cpu()
+    assert torch.allclose(pc, pg, atol=2e-4, rtol=1e-3), float((pc - pg).abs().max())
