@@ -221,6 +221,331 @@ __global__ void __launch_bounds__(256) sdpa_fwd_kernel(const AttnP p) {
     p.lse[(int64_t)bh * p.Tq + qi] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : INFINITY;
 }
 
+
+// =====================================================================================================================
+// Backward. Two deterministic passes (no atomics), both recompute the probabilities from the saved log-sum-exp:
+//   pass Q  (one workgroup = 128 queries, streams over key tiles):   dQ   = dS K
+//   pass KV (one workgroup = 128 keys,    streams over query tiles): dV   = P^T dO,  dK = dS^T Q
+// with P = exp(S*scale - lse), dP = dO V^T, dS = P o (dP - delta) * scale, delta_i = <dO_i, O_i>.
+// Both passes keep the forward kernel's register trick: the first two GEMMs of a tile are computed with the streamed
+// operand's rows fed in swap23 order, so P and dS (32 x 32 per wave, one owner row/column per lane) are, after the bf16
+// pack, directly the B operands of the following GEMMs; the A operands of those (K^T, Q^T, dO^T) come from transposing
+// LDS reads of a second, tr-swizzled copy of the streamed tile. The owner-side operands (Q/dO or K/V of the lane's own
+// row) are loop invariant and live in registers.
+struct AttnBwdP {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  const float* kmask;
+  const bf16_t* dout;
+  const float* lse;     // [B*H][Tq] natural log
+  const float* delta;   // [B*H][Tq]
+  bf16_t* dq;
+  bf16_t* dk;
+  bf16_t* dv;
+  int H, Tq, Tk;
+  int nbh, nblk;
+  float scale, scale_log2e;
+  int causal;
+};
+
+// delta[row] = sum_d dO[row, d] * O[row, d]; HD/8 lanes per row, 16 bytes per lane
+template <int HD>
+__global__ void __launch_bounds__(256) sdpa_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int64_t rows) {
+  constexpr int LPR = HD / 8;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / LPR;
+  const int c = (int)(t - row * LPR);
+  float s = 0.f;
+  if (row < rows) {
+    const s16x8 a = *reinterpret_cast<const s16x8*>(o + row * HD + c * 8);
+    const s16x8 b = *reinterpret_cast<const s16x8*>(dout + row * HD + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += bf2f((bf16_t)a[j]) * bf2f((bf16_t)b[j]);
+  }
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (row < rows && c == 0) delta[row] = s;
+}
+
+__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int pitch, int row, int c) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + row * pitch + ((c ^ ((row >> 1) & 7)) << 4));
+}
+
+// ---- pass Q: dQ for 128 queries per workgroup, key tiles of 64
+template <int HD>
+__global__ void __launch_bounds__(256) sdpa_bwd_dq_kernel(const AttnBwdP p) {
+  constexpr int PITCH = HD * 2;
+  constexpr int KS = HD / 16;
+  constexpr int DB = HD / 32;
+  constexpr int CPR = HD / 8;
+  constexpr int RPP = 256 / CPR;
+  constexpr int NPASS = 64 / RPP;
+  __shared__ __attribute__((aligned(16))) char sK[64 * PITCH];      // row-fragment layout
+  __shared__ __attribute__((aligned(16))) char sKt[64 * PITCH];     // transposing-read layout
+  __shared__ __attribute__((aligned(16))) char sV[64 * PITCH];      // row-fragment layout
+  __shared__ float sM[64];
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / p.nblk) * 8 + xcd;
+  if (bh >= p.nbh) return;
+  const int qb = slot - (slot / p.nblk) * p.nblk;
+  const int b = bh / p.H;
+  const int q0 = (p.causal ? p.nblk - 1 - qb : qb) * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int qi = q0 + wid * 32 + l31;
+  const bf16_t* Q = p.q + (int64_t)bh * p.Tq * HD;
+  const bf16_t* DO = p.dout + (int64_t)bh * p.Tq * HD;
+  const bf16_t* K = p.k + (int64_t)bh * p.Tk * HD;
+  const bf16_t* V = p.v + (int64_t)bh * p.Tk * HD;
+
+  bf16x8_t qf[KS], dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    s16x8 t = {0, 0, 0, 0, 0, 0, 0, 0}, u = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qi < p.Tq) {
+      t = *reinterpret_cast<const s16x8*>(Q + (int64_t)qi * HD + ks * 16 + lh * 8);
+      u = *reinterpret_cast<const s16x8*>(DO + (int64_t)qi * HD + ks * 16 + lh * 8);
+    }
+    qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+    dof[ks] = __builtin_bit_cast(bf16x8_t, u);
+  }
+  const float lse2 = qi < p.Tq ? p.lse[(int64_t)bh * p.Tq + qi] * 1.4426950408889634f : INFINITY;
+  const float dlt = qi < p.Tq ? p.delta[(int64_t)bh * p.Tq + qi] : 0.f;
+
+  f32x16 dqacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
+
+  const int chunk = tid % CPR, lrow = tid / CPR;
+  int kend = p.Tk;
+  if (p.causal) {
+    const int last = q0 + 127 < p.Tq - 1 ? q0 + 127 : p.Tq - 1;
+    kend = last + 1 < p.Tk ? last + 1 : p.Tk;
+  }
+  const int ntiles = (kend + 63) / 64;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int key0 = kt * 64;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int row = lrow + i * RPP;
+      const int key = key0 + row;
+      s16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (key < p.Tk) {
+        kv = *reinterpret_cast<const s16x8*>(K + (int64_t)key * HD + chunk * 8);
+        vv = *reinterpret_cast<const s16x8*>(V + (int64_t)key * HD + chunk * 8);
+      }
+      *reinterpret_cast<s16x8*>(sK + row * PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
+      *reinterpret_cast<s16x8*>(sKt + row * PITCH + ((chunk ^ tr_swz<PITCH>(row)) << 4)) = kv;
+      *reinterpret_cast<s16x8*>(sV + row * PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = vv;
+    }
+    if (tid < 64) {
+      const int key = key0 + tid;
+      float mv = (key < p.Tk) ? 0.f : -INFINITY;
+      if (p.kmask != nullptr && key < p.Tk && p.kmask[(int64_t)b * p.Tk + key] == 0.f) mv = -INFINITY;
+      sM[tid] = mv;
+    }
+    __syncthreads();
+    if (p.causal && key0 > q0 + wid * 32 + 31) continue;
+
+    f32x16 sacc[2], dpacc[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { sacc[mb][e] = 0.f; dpacc[mb][e] = 0.f; }
+      const int row = mb * 32 + swap23(l31);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        sacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, PITCH, row, ks * 2 + lh), qf[ks], sacc[mb], 0, 0, 0);
+        dpacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, PITCH, row, ks * 2 + lh), dof[ks], dpacc[mb], 0, 0, 0);
+      }
+    }
+
+    bf16x8_t dsf[4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        s16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int e = hf * 8 + j;
+          const int kl = mb * 32 + 16 * hf + 8 * lh + j;
+          float sl = sacc[mb][e] * p.scale_log2e + sM[kl] - lse2;
+          if (p.causal && key0 + kl > qi) sl = -INFINITY;
+          const float pv = exp2f(sl);
+          t[j] = (short)f2bf(pv * (dpacc[mb][e] - dlt) * p.scale);
+        }
+        dsf[mb * 2 + hf] = __builtin_bit_cast(bf16x8_t, t);
+      }
+
+    // dQ^T += K^T dS^T
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+        dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<PITCH>(sKt, d * 32, s, lane), dsf[s], dqacc[d], 0, 0, 0);
+  }
+
+  if (qi >= p.Tq) return;
+  bf16_t* DQ = p.dq + ((int64_t)bh * p.Tq + qi) * HD;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      s16x4 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = (short)f2bf(dqacc[d][g * 4 + j]);
+      *reinterpret_cast<s16x4*>(DQ + d * 32 + 8 * g + 4 * lh) = t;
+    }
+}
+
+// ---- pass KV: dK, dV for 128 keys per workgroup, query tiles of QT = NMB * 32 (64 for HD 64, 32 for HD 128: 4 LDS tiles)
+template <int HD, int NMB>
+__global__ void __launch_bounds__(256) sdpa_bwd_dkv_kernel(const AttnBwdP p) {
+  constexpr int PITCH = HD * 2;
+  constexpr int KS = HD / 16;
+  constexpr int DB = HD / 32;
+  constexpr int CPR = HD / 8;
+  constexpr int RPP = 256 / CPR;
+  constexpr int QT = NMB * 32;
+  constexpr int NPASS = QT / RPP;
+  static_assert(NPASS >= 1, "tile smaller than one load pass");
+  __shared__ __attribute__((aligned(16))) char sQ[QT * PITCH];
+  __shared__ __attribute__((aligned(16))) char sQt[QT * PITCH];
+  __shared__ __attribute__((aligned(16))) char sO[QT * PITCH];
+  __shared__ __attribute__((aligned(16))) char sOt[QT * PITCH];
+  __shared__ float sL[QT];
+  __shared__ float sD[QT];
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bh = (slot / p.nblk) * 8 + xcd;
+  if (bh >= p.nbh) return;
+  const int kb = slot - (slot / p.nblk) * p.nblk;
+  const int b = bh / p.H;
+  const int k0 = kb * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int kj = k0 + wid * 32 + l31;                      // this lane's key
+  const bf16_t* Q = p.q + (int64_t)bh * p.Tq * HD;
+  const bf16_t* DO = p.dout + (int64_t)bh * p.Tq * HD;
+  const bf16_t* K = p.k + (int64_t)bh * p.Tk * HD;
+  const bf16_t* V = p.v + (int64_t)bh * p.Tk * HD;
+
+  bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    s16x8 t = {0, 0, 0, 0, 0, 0, 0, 0}, u = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kj < p.Tk) {
+      t = *reinterpret_cast<const s16x8*>(K + (int64_t)kj * HD + ks * 16 + lh * 8);
+      u = *reinterpret_cast<const s16x8*>(V + (int64_t)kj * HD + ks * 16 + lh * 8);
+    }
+    kf[ks] = __builtin_bit_cast(bf16x8_t, t);
+    vf[ks] = __builtin_bit_cast(bf16x8_t, u);
+  }
+  float maskk = kj < p.Tk ? 0.f : -INFINITY;
+  if (p.kmask != nullptr && kj < p.Tk && p.kmask[(int64_t)b * p.Tk + kj] == 0.f) maskk = -INFINITY;
+
+  f32x16 dkacc[DB], dvacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
+
+  const int chunk = tid % CPR, lrow = tid / CPR;
+  const int ntiles = (p.Tq + QT - 1) / QT;
+  const int t0 = p.causal ? k0 / QT : 0;                   // queries before the block's first key never see these keys
+
+  for (int qt = t0; qt < ntiles; ++qt) {
+    const int qs = qt * QT;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int row = lrow + i * RPP;
+      const int qr = qs + row;
+      s16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, ov = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (qr < p.Tq) {
+        qv = *reinterpret_cast<const s16x8*>(Q + (int64_t)qr * HD + chunk * 8);
+        ov = *reinterpret_cast<const s16x8*>(DO + (int64_t)qr * HD + chunk * 8);
+      }
+      const int ro = row * PITCH + ((chunk ^ ((row >> 1) & 7)) << 4), to = row * PITCH + ((chunk ^ tr_swz<PITCH>(row)) << 4);
+      *reinterpret_cast<s16x8*>(sQ + ro) = qv;
+      *reinterpret_cast<s16x8*>(sQt + to) = qv;
+      *reinterpret_cast<s16x8*>(sO + ro) = ov;
+      *reinterpret_cast<s16x8*>(sOt + to) = ov;
+    }
+    if (tid < QT) {
+      const int qr = qs + tid;
+      sL[tid] = qr < p.Tq ? p.lse[(int64_t)bh * p.Tq + qr] * 1.4426950408889634f : INFINITY;
+      sD[tid] = qr < p.Tq ? p.delta[(int64_t)bh * p.Tq + qr] : 0.f;
+    }
+    __syncthreads();
+    if (p.causal && qs + QT - 1 < k0 + wid * 32) continue;   // every query of this tile precedes this wave's keys
+
+    f32x16 sacc[NMB], dpacc[NMB];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { sacc[mb][e] = 0.f; dpacc[mb][e] = 0.f; }
+      const int row = mb * 32 + swap23(l31);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        sacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, PITCH, row, ks * 2 + lh), kf[ks], sacc[mb], 0, 0, 0);
+        dpacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sO, PITCH, row, ks * 2 + lh), vf[ks], dpacc[mb], 0, 0, 0);
+      }
+    }
+
+    bf16x8_t pf[NMB * 2], dsf[NMB * 2];
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        s16x8 tp, td;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int e = hf * 8 + j;
+          const int ql = mb * 32 + 16 * hf + 8 * lh + j;      // tile-local query of this accumulator slot
+          float sl = sacc[mb][e] * p.scale_log2e + maskk - sL[ql];
+          if (p.causal && kj > qs + ql) sl = -INFINITY;
+          const float pv = exp2f(sl);
+          tp[j] = (short)f2bf(pv);
+          td[j] = (short)f2bf(pv * (dpacc[mb][e] - sD[ql]) * p.scale);
+        }
+        pf[mb * 2 + hf] = __builtin_bit_cast(bf16x8_t, tp);
+        dsf[mb * 2 + hf] = __builtin_bit_cast(bf16x8_t, td);
+      }
+
+    // dV^T += dO^T P,  dK^T += Q^T dS   (rows = d, columns = this lane's key, k slots = the tile's queries)
+#pragma unroll
+    for (int s = 0; s < NMB * 2; ++s)
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<PITCH>(sOt, d * 32, s, lane), pf[s], dvacc[d], 0, 0, 0);
+        dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<PITCH>(sQt, d * 32, s, lane), dsf[s], dkacc[d], 0, 0, 0);
+      }
+  }
+
+  if (kj >= p.Tk) return;
+  bf16_t* DK = p.dk + ((int64_t)bh * p.Tk + kj) * HD;
+  bf16_t* DV = p.dv + ((int64_t)bh * p.Tk + kj) * HD;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      s16x4 tk, tv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { tk[j] = (short)f2bf(dkacc[d][g * 4 + j]); tv[j] = (short)f2bf(dvacc[d][g * 4 + j]); }
+      *reinterpret_cast<s16x4*>(DK + d * 32 + 8 * g + 4 * lh) = tk;
+      *reinterpret_cast<s16x4*>(DV + d * 32 + 8 * g + 4 * lh) = tv;
+    }
+}
+
 }  // namespace
 
 // q,k,v,o: bf16 [B*H, T, HD] contiguous; kmask: fp32 [B, Tk] or null; lse: fp32 [B*H, Tq] or null. HD in {64, 128}.
@@ -235,5 +560,36 @@ DL4J_API int dl4j_sdpa_fwd(const void* q, const void* k, const void* v, const fl
   const dim3 grid((unsigned)(((p.nbh + 7) / 8) * 8 * p.nqb));
   if (HD == 64) hipLaunchKernelGGL(sdpa_fwd_kernel<64>, grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(sdpa_fwd_kernel<128>, grid, dim3(256), 0, st, p);
+  DL4J_RET_LAST();
+}
+
+// Backward of dl4j_sdpa_fwd. o / lse are the forward outputs, dout = dL/do; delta_ws: fp32 [B*H*Tq] scratch.
+// dq [B*H, Tq, HD], dk / dv [B*H, Tk, HD] are fully written.
+DL4J_API int dl4j_sdpa_bwd(const void* q, const void* k, const void* v, const float* kmask, const void* o, const float* lse,
+                           const void* dout, void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Tq, int Tk, int HD,
+                           float scale, int causal, hipStream_t st) {
+  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
+  if (HD != 64 && HD != 128) return -2;
+  if (!lse || !delta_ws) return -3;
+  AttnBwdP p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.kmask = kmask; p.dout = (const bf16_t*)dout;
+  p.lse = lse; p.delta = delta_ws; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+  p.H = H; p.Tq = Tq; p.Tk = Tk; p.nbh = B * H; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f; p.causal = causal;
+  const int64_t rows = (int64_t)B * H * Tq;
+  const int64_t dthreads = rows * (HD / 8);
+  const unsigned dgrid = (unsigned)((dthreads + 255) / 256);
+  const int bh8 = ((p.nbh + 7) / 8) * 8;
+  AttnBwdP pq = p, pk = p;
+  pq.nblk = (Tq + 127) / 128;
+  pk.nblk = (Tk + 127) / 128;
+  if (HD == 64) {
+    hipLaunchKernelGGL(sdpa_delta_kernel<64>, dim3(dgrid), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout, delta_ws, rows);
+    hipLaunchKernelGGL(sdpa_bwd_dq_kernel<64>, dim3((unsigned)(bh8 * pq.nblk)), dim3(256), 0, st, pq);
+    hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<64, 2>), dim3((unsigned)(bh8 * pk.nblk)), dim3(256), 0, st, pk);
+  } else {
+    hipLaunchKernelGGL(sdpa_delta_kernel<128>, dim3(dgrid), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout, delta_ws, rows);
+    hipLaunchKernelGGL(sdpa_bwd_dq_kernel<128>, dim3((unsigned)(bh8 * pq.nblk)), dim3(256), 0, st, pq);
+    hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<128, 1>), dim3((unsigned)(bh8 * pk.nblk)), dim3(256), 0, st, pk);
+  }
   DL4J_RET_LAST();
 }

@@ -3,8 +3,8 @@
 Reference: libnd4j/include/ops/declarable/generic/nn/dot_product_attention_v2.cpp:35-181 (materialises
 the full [b,h,Tq,Tk] score matrix and returns it). On the GPU (bf16, head dim 64/128, key-padding mask or none, no
 attention dropout) the forward is the hand-written flash-style kernel native/csrc/attention.hip, which never materialises
-scores; its backward recomputes the probabilities from the saved log-sum-exp with library GEMMs (a fused backward kernel is
-future work). ``return_scores=True`` reproduces the reference outputs; other cases use ATen's SDPA.
+scores; the backward is fused too (delta pre-pass + a dQ pass + a dK/dV pass that recompute the probabilities from the
+saved log-sum-exp). ``return_scores=True`` reproduces the reference outputs; other cases use ATen's SDPA.
 """
 from __future__ import annotations
 
@@ -44,24 +44,36 @@ class _FlashSDPA(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do):
+        """Fused backward (native/csrc/attention.hip: delta pre-pass, dQ pass, dK/dV pass; P is recomputed from the LSE)."""
+        from ..native import lib as L
         q, k, v, o, lse, mk = ctx.saved_tensors
-        scale = ctx.scale
-        s = torch.matmul(q, k.transpose(-1, -2)).float() * scale
-        if mk is not None:
-            s = s.masked_fill(mk[:, None, None, :] == 0, float("-inf"))
-        if ctx.causal:
-            Tq, Tk = s.shape[-2:]
-            s = s.masked_fill(~torch.ones(Tq, Tk, dtype=torch.bool, device=s.device).tril(), float("-inf"))
-        p = torch.exp(s - lse.unsqueeze(-1))                      # fully masked rows: lse = +inf -> p = 0
-        dof = do.contiguous()
-        pb = p.to(q.dtype)
-        dv = torch.matmul(pb.transpose(-1, -2), dof)
-        dp = torch.matmul(dof, v.transpose(-1, -2)).float()
-        delta = (dof.float() * o.float()).sum(-1, keepdim=True)
-        ds = (p * (dp - delta) * scale).to(q.dtype)
-        dq = torch.matmul(ds, k)
-        dk = torch.matmul(ds.transpose(-1, -2), q)
+        B, H, Tq, D = q.shape
+        Tk = k.shape[2]
+        dof = do.to(q.dtype).contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
+        L.check(L.hip().dl4j_sdpa_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mk), L.ptr(o), L.ptr(lse), L.ptr(dof), L.ptr(dq), L.ptr(dk),
+                                      L.ptr(dv), L.ptr(delta), L.c_int(B), L.c_int(H), L.c_int(Tq), L.c_int(Tk), L.c_int(D),
+                                      L.c_float(ctx.scale), L.c_int(1 if ctx.causal else 0), L.stream()), "sdpa_bwd")
         return dq, dk, dv, None, None, None
+
+
+def sdpa_backward_reference(q, k, v, o, lse, mk, do, scale, causal):
+    """The same backward with library GEMMs and a materialised probability matrix (test oracle for the fused kernels)."""
+    s = torch.matmul(q, k.transpose(-1, -2)).float() * scale
+    if mk is not None:
+        s = s.masked_fill(mk[:, None, None, :] == 0, float("-inf"))
+    if causal:
+        Tq, Tk = s.shape[-2:]
+        s = s.masked_fill(~torch.ones(Tq, Tk, dtype=torch.bool, device=s.device).tril(), float("-inf"))
+    p = torch.exp(s - lse.unsqueeze(-1))                      # fully masked rows: lse = +inf -> p = 0
+    dof = do.contiguous()
+    pb = p.to(q.dtype)
+    dv = torch.matmul(pb.transpose(-1, -2), dof)
+    dp = torch.matmul(dof, v.transpose(-1, -2)).float()
+    delta = (dof.float() * o.float()).sum(-1, keepdim=True)
+    ds = (p * (dp - delta) * scale).to(q.dtype)
+    return torch.matmul(ds, k), torch.matmul(ds.transpose(-1, -2), q), dv
 
 
 def sdpa(q, k, v, mask=None, scale=None, causal=False, dropout_p=0.0, training=False, return_scores=False):

@@ -65,6 +65,41 @@ def test_sdpa_fully_masked_rows_and_backward():
     assert torch.isfinite(o0.float()).all() and float(o0[0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,D,causal,masked", [
+    (2, 3, 128, 128, 64, False, False),
+    (1, 2, 200, 200, 64, True, False),          # ragged tiles + causal
+    (2, 2, 77, 150, 64, False, True),           # cross attention lengths, key padding mask
+    (1, 2, 256, 256, 128, False, False),
+    (2, 1, 130, 130, 128, True, True),
+    (1, 9, 64, 320, 128, False, True),          # more (batch, head) pairs than XCDs
+])
+def test_sdpa_fused_backward_matches_fp32_reference(B, H, Tq, Tk, D, causal, masked):
+    """dq / dk / dv of the fused backward kernels vs autograd through a plain fp32 softmax(QK^T)V."""
+    from deeplearning4j_amd.ops import attention as A
+    torch.manual_seed(B * 1000 + Tq + Tk + D)
+    dev = torch.device("cuda")
+    q = torch.randn(B, H, Tq, D, device=dev).bfloat16().requires_grad_(True)
+    k = torch.randn(B, H, Tk, D, device=dev).bfloat16().requires_grad_(True)
+    v = torch.randn(B, H, Tk, D, device=dev).bfloat16().requires_grad_(True)
+    mask = None
+    if masked:
+        lens = torch.randint(Tk // 2, Tk + 1, (B,), device=dev)
+        mask = (torch.arange(Tk, device=dev)[None, :] < lens[:, None]).float()
+    scale = 1.0 / math.sqrt(D)
+    o = A.sdpa(q, k, v, mask, scale, causal)
+    g = torch.randn_like(o)
+    o.backward(g)
+    qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    r = _ref(qf, kf, vf, mask, scale, causal)
+    r.backward(g.float())
+    for a, b_, name in ((q.grad, qf.grad, "dq"), (k.grad, kf.grad, "dk"), (v.grad, vf.grad, "dv")):
+        assert torch.isfinite(a.float()).all(), name
+        rel = (a.float() - b_).norm() / b_.norm().clamp_min(1e-6)
+        assert rel < 2e-2, (name, float(rel))
+        # element-wise too: no mis-mapped rows hiding inside a small relative norm
+        assert float((a.float() - b_).abs().max()) < 0.05 * float(b_.abs().max()) + 1e-3, name
+
+
 def test_self_attention_network_uses_flash_kernel_and_trains():
     """SelfAttentionLayer (multi-head, head size 64) in a bf16 network: the layer's SDPA goes through the HIP kernel."""
     from deeplearning4j_amd.nd4j.learning import Adam
