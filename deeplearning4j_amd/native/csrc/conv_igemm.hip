@@ -289,16 +289,23 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int cb, int ks, in
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
+// Split-K atomics are the expensive part of this kernel (fp32 atomic adds retire at ~2 TB/s, measured with
+// tools/wgrad_sweep.py), so a workgroup is TWO 4-wave groups: each group runs the pipelined loop over its own half of the
+// workgroup's pixel range with its own LDS buffers, the halves are summed through LDS and only one group issues the
+// atomics — half the atomic traffic for the same number of waves in flight.
 template <int BK_, int BC_>   // BK_: out-channel tile (dy), BC_: in-channel tile (x)
-__global__ void __launch_bounds__(256) igemm_wgrad_kernel(const WGradP p) {
+__global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
   constexpr int PA = BK_ * 2, PB = BC_ * 2;          // row pitches in bytes
   constexpr int CPA = BK_ / 8, CPB = BC_ / 8;        // 16-byte chunks per pixel row
   constexpr int RPA = 256 / CPA, RPB = 256 / CPB;    // pixel rows covered per pass
   constexpr int NA = 64 / RPA, NB = 64 / RPB;        // passes per 64-pixel tile
   constexpr int TM = BK_ / 64, TN = BC_ / 64;
+  constexpr int GBYTES = 2 * 64 * (PA + PB);         // double-buffered operands of one group
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;
-  char* sB = smem + 2 * 64 * PA;
+  const int grp = threadIdx.x >> 8;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
+  char* sA = smem + grp * GBYTES;
+  char* sB = sA + 2 * 64 * PA;
 
   int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int RS = p.R * p.S;
@@ -308,9 +315,11 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const WGradP p) {
   const int split = lid / RS;
   const int k0 = kt * BK_, c0 = ct * BC_;
   const int r = rs / p.S, s = rs - r * p.S;
-  const int pstart = split * p.pps;
-  const int pend = (pstart + p.pps < p.P) ? pstart + p.pps : p.P;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int half = p.pps >> 1;                                      // pps is a multiple of 128
+  const int bend = (split * p.pps + p.pps < p.P) ? split * p.pps + p.pps : p.P;
+  const int pstart = split * p.pps + grp * half;
+  int pend = pstart + half;
+  if (pend > bend) pend = bend;
   const int wm = wid >> 1, wn = wid & 1;
   const int chA = tid % CPA, prA = tid / CPA;
   const int chB = tid % CPB, prB = tid / CPB;
@@ -360,11 +369,10 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const WGradP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int nsteps = (pend - pstart + 63) / 64;
-  if (nsteps > 0) {
-    gload(pstart);
-    swrite(0);
-  }
+  // the step count is workgroup-uniform (both groups run the same barriers); a group whose range is shorter loads zeros
+  const int nsteps = (half + 63) / 64;
+  gload(pstart);
+  swrite(0);
   __syncthreads();
   for (int t = 0; t < nsteps; ++t) {
     const int cur = t & 1;
@@ -387,6 +395,19 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const WGradP p) {
     if (t + 1 < nsteps) swrite(cur ^ 1);
     __syncthreads();
   }
+
+  // group 1 hands its partial tile to group 0 through LDS (the operand buffers are free now: BK_*BC_*4 <= 2*GBYTES)
+  float* xch = reinterpret_cast<float*>(smem);
+  if (grp == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xch[(((i * TN + j) * 16 + e) * 4 + wid) * 64 + lane] = acc[i][j][e];
+  }
+  __syncthreads();
+  if (grp == 1) return;
   const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -396,9 +417,10 @@ __global__ void __launch_bounds__(256) igemm_wgrad_kernel(const WGradP p) {
       for (int e = 0; e < 16; ++e) {
         const int k = k0 + wm * (BK_ / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         const int c = c0 + wn * (BC_ / 2) + j * 32 + l31;
+        const float v = acc[i][j][e] + xch[(((i * TN + j) * 16 + e) * 4 + wid) * 64 + lane];
         float* dst = p.dw + ((int64_t)k * RS + rs) * p.C + c;
-        if (p.use_atomic) atomicAdd(dst, acc[i][j][e]);
-        else *dst = acc[i][j][e];
+        if (p.use_atomic) atomicAdd(dst, v);
+        else *dst = v;
       }
 }
 
@@ -419,12 +441,20 @@ static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t
   p.ktiles = p.K / BK_;
   p.ctiles = p.C / BC_;
   const int tiles = p.ktiles * p.ctiles * p.R * p.S;
-  int splits = (target_blocks + tiles - 1) / tiles;
-  int maxs = (p.P + 255) / 256;
+  int splits;
+  if (target_blocks > 0) {
+    splits = (target_blocks + tiles - 1) / tiles;
+  } else {
+    // auto: fill the chip exactly once. A workgroup needs 512 * (BK_ + BC_) bytes of the 160 KB LDS, so one (two for the
+    // 64x64 tile) is resident per CU; a partial second round costs more than the shorter split saves (tools/wgrad_sweep.py)
+    const int capacity = DL4J_NUM_CU * ((160 * 1024) / (2 * 2 * 64 * (BK_ + BC_) * 2));
+    splits = capacity / tiles;
+  }
+  int maxs = (p.P + 511) / 512;
   if (splits > maxs) splits = maxs;
   if (splits < 1) splits = 1;
   int pps = (p.P + splits - 1) / splits;
-  pps = (pps + 63) / 64 * 64;
+  pps = (pps + 127) / 128 * 128;             // two 64-pixel-aligned halves, one per wave group
   splits = (p.P + pps - 1) / pps;
   p.splits = splits; p.pps = pps;
   p.use_atomic = splits > 1;
@@ -435,14 +465,15 @@ static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t
     else    // gradient view at an odd offset of the flat vector
       hipLaunchKernelGGL(zero_f32_scalar_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, p.dw, n);
   }
-  const int smem = 2 * 64 * (BK_ + BC_) * 2;
+  const int smem = 2 * 2 * 64 * (BK_ + BC_) * 2;      // two groups x double buffer
+  static_assert(BK_ * BC_ * 4 <= 2 * 2 * 64 * (BK_ + BC_) * 2, "exchange tile must fit the operand buffers");
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BK_, BC_>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_wgrad_kernel<BK_, BC_>), dim3(tiles * splits), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BK_, BC_>), dim3(tiles * splits), dim3(512), smem, st, p);
   DL4J_RET_LAST();
 }
 

@@ -155,7 +155,7 @@ def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation, accum_into=None):
     return dx
 
 
-def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=512, prezeroed=False):
+def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=0, prezeroed=False):
     """dW. If ``dw_out`` (fp32, contiguous, logical [K,C,R,S]) is given the result is written there and
     None is returned; otherwise a new fp32 [K,C,R,S] tensor is returned. ``prezeroed``: dw_out is known to be all
     zeros (the network clears the flat gradient vector once per iteration), so no per-layer memset is issued."""
