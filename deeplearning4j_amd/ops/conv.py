@@ -7,6 +7,8 @@ platform/cudnn/conv2d.cu:83):
 * ``hip``     – hand-written gfx950 implicit-GEMM MFMA kernels (native/csrc/conv_igemm.hip):
                 bf16 NHWC activations, OHWI filters, fp32 accumulation; forward optionally fuses the
                 per-channel batch statistics needed by a following BatchNorm into the epilogue.
+* ``stem``    – hand-written direct MFMA kernels for 3-channel 7x7/2 stems (native/csrc/conv_stem.hip): forward with
+                fused BatchNorm statistics, weight gradient.
 * ``library`` – MIOpen through ATen (also the CPU / fp64 path used by gradient checks).
 
 Weight layout contract matches DL4J: logical [nOut, nIn, kH, kW] (wFormat 1 of libnd4j conv2d,
@@ -36,12 +38,22 @@ def _hip_eligible(x, w, stride, padding, dilation):
     return conv_igemm.supported(x, w, stride, padding, dilation)
 
 
+def _stem_eligible(x, w, stride, padding, dilation):
+    if _FORCE == "library" or not L.use_hip(x, w):
+        return False
+    from . import conv_stem
+    return conv_stem.supported(x, w, stride, padding, dilation)
+
+
 def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False):
     """x: [N,C,H,W] logical (channels_last memory on GPU). Returns (z, sums): ``sums`` is the [2K] fp32
     per-channel (sum, sum of squares) of z when the HIP path fused it into its epilogue, else None."""
     if _hip_eligible(x, w, stride, padding, dilation):
         from . import conv_igemm
         return conv_igemm.forward(x, w, b, stride, padding, dilation, want_stats)
+    if _stem_eligible(x, w, stride, padding, dilation):
+        from . import conv_stem
+        return conv_stem.forward(x, w, b, stride, padding, dilation, want_stats)
     return F.conv2d(x, w, b, tuple(stride), tuple(padding), tuple(dilation)), None
 
 
@@ -68,6 +80,20 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
                     list(dilation), False, [0, 0], 1, [True, False, False])[0]
                 if dx_accum is not None:
                     dx = dx_accum + dx
+        return dx, dW, db
+    if dz.dtype == torch.bfloat16 and _stem_eligible(x, w, stride, padding, dilation):
+        from . import conv_stem
+        dx = dW = db = None
+        if need_db:
+            db = dz.float().sum((0, 2, 3))
+        if need_dw:
+            dW = conv_stem.wgrad(dz, x, stride, padding, dilation, dw_out=dw_out)
+        if need_dx:
+            dx = torch.ops.aten.convolution_backward(
+                dz.contiguous(memory_format=torch.channels_last), x, w, None, list(stride), list(padding), list(dilation), False,
+                [0, 0], 1, [True, False, False])[0]
+            if dx_accum is not None:
+                dx = dx_accum + dx
         return dx, dW, db
     if x.is_cuda and not dz.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last):
         dz = dz.contiguous(memory_format=torch.channels_last)
