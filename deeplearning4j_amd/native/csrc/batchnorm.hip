@@ -6,6 +6,7 @@
 // with a residual add — itself optionally batch-normalised — and ReLU), and a 2-pass backward.
 // Memory-bound: 16-byte vector accesses, fp32 accumulation, one float atomic per block/channel.
 #include "common.h"
+#include <stdlib.h>
 
 template <typename T> struct VecOf;
 template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
@@ -175,7 +176,14 @@ __global__ void __launch_bounds__(256) bn_sum_partials_kernel(const float* __res
   }
 }
 
-#define BN_MAX_ROWBLOCKS 512
+#define BN_MAX_ROWBLOCKS 2048                 // workspace bound
+// grid policy of the column reductions (tunable for tools/bn_microbench.py through the environment)
+static int bn_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+static int bn_rowblocks() { static int v = bn_env_int("DL4J_BN_ROWBLOCKS", 1024); return v < 1 ? 1 : (v > BN_MAX_ROWBLOCKS ? BN_MAX_ROWBLOCKS : v); }
+static int bn_min_iters() { static int v = bn_env_int("DL4J_BN_MIN_ITERS", 8); return v < 1 ? 1 : v; }
 // workspace floats needed for the partials of one call
 static inline int64_t colreduce_ws_floats(int C) { return (int64_t)BN_MAX_ROWBLOCKS * 2 * C; }
 
@@ -190,9 +198,10 @@ static int launch_colreduce(const void* x, const void* dy, const void* out, cons
   const int cpb = cv < 256 ? cv : 256;
   const int rpi = 256 / cpb;
   const int gx = (cv + cpb - 1) / cpb;
-  int64_t gy = (M + (int64_t)rpi * 16 - 1) / ((int64_t)rpi * 16);   // >= 16 row-iterations per block
+  const int64_t rows_pb = (int64_t)rpi * bn_min_iters();             // at least this many row-iterations per block
+  int64_t gy = (M + rows_pb - 1) / rows_pb;
   if (gy < 1) gy = 1;
-  int64_t cap = BN_MAX_ROWBLOCKS / gx; if (cap < 1) cap = 1;
+  int64_t cap = bn_rowblocks() / gx; if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   dim3 grid(gx, (unsigned)gy);
   if (vec_ok)
