@@ -156,6 +156,7 @@ struct __attribute__((packed, aligned(8))) CastSeg {
 };
 static_assert(sizeof(CastSeg) == 40, "CastSeg layout is part of the ctypes ABI");
 
+#define CAST_LDS_FLOATS 13312
 __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                          const CastSeg* __restrict__ segs,
                                                          const int32_t* __restrict__ blk_seg,
@@ -163,20 +164,58 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
   const CastSeg s = segs[blk_seg[blockIdx.x]];
   const int64_t start = (int64_t)blk_chunk[blockIdx.x] * UPD_CHUNK;
   const int64_t end = (start + UPD_CHUNK < s.len) ? start + UPD_CHUNK : s.len;
-  const int64_t IK = (int64_t)s.I * s.K;
-  for (int64_t d = start + threadIdx.x; d < end; d += 256) {
-    int64_t si = d;
-    if (s.mode == 1) {  // d indexes destination [i][k'][o], k' = K-1-k
-      const int64_t KO = (int64_t)s.K * s.O;
-      const int64_t i = d / KO, rem = d - i * KO;
-      const int64_t kf = rem / s.O, o = rem - kf * s.O;
-      si = o * IK + i * s.K + (s.K - 1 - kf);
-    } else if (s.K > 1) {  // d indexes destination [o][k][i]
-      const int64_t o = d / IK, rem = d - o * IK;
-      const int64_t k = rem / s.I, i = rem - k * s.I;
-      si = o * IK + i * s.K + k;
+  // one entry is one weight tensor (< 2^31 elements, checked on the host): 32-bit index math. The permuting modes stage
+  // the source through LDS: a destination chunk is contiguous and its sources form a few contiguous runs, so both the
+  // global reads and the global writes are coalesced (the first version gathered 4 bytes per 128-byte line).
+  __shared__ float lds[CAST_LDS_FLOATS];
+  const uint32_t I = (uint32_t)s.I, K = (uint32_t)s.K, O = (uint32_t)s.O;
+  const uint32_t IK = I * K, KO = K * O;
+  const float* sp = src + s.src_off;
+  bf16_t* dp = dst + s.dst_off;
+  const uint32_t d0 = (uint32_t)start, d1 = (uint32_t)end;
+  if (s.mode == 0 && K > 1) {                       // [o][i][k] -> [o][k][i]: the permutation stays inside each o block
+    const uint32_t o0 = d0 / IK, o1 = (d1 - 1) / IK;
+    const uint32_t base = o0 * IK, n_src = (o1 + 1 - o0) * IK;
+    if (n_src <= CAST_LDS_FLOATS) {
+      for (uint32_t j = threadIdx.x; j < n_src; j += 256) lds[j] = sp[base + j];
+      __syncthreads();
+      for (uint32_t d = d0 + threadIdx.x; d < d1; d += 256) {
+        const uint32_t o = d / IK, rem = d - o * IK;
+        const uint32_t k = rem / I, i = rem - k * I;
+        dp[d] = f2bf(lds[o * IK + i * K + k - base]);
+      }
+      return;
     }
-    dst[s.dst_off + d] = f2bf(src[s.src_off + si]);
+  } else if (s.mode == 1) {                          // dest [i][k'][o], k' = K-1-k  <-  src [o][i][k]
+    const uint32_t r0 = d0 / O, r1 = (d1 - 1) / O;   // destination rows r = i*K + k'
+    const uint32_t q0 = (r0 / K) * K, q1 = (r1 / K + 1) * K;   // covering range of source (i, k) indices
+    const uint32_t qlen = q1 - q0, pitch = qlen | 1;
+    if (O * pitch <= CAST_LDS_FLOATS) {
+      for (uint32_t idx = threadIdx.x; idx < O * qlen; idx += 256) {
+        const uint32_t o = idx / qlen, j = idx - o * qlen;
+        lds[o * pitch + j] = sp[o * IK + q0 + j];
+      }
+      __syncthreads();
+      for (uint32_t d = d0 + threadIdx.x; d < d1; d += 256) {
+        const uint32_t r = d / O, o = d - r * O;
+        const uint32_t i = r / K, kf = r - i * K;
+        dp[d] = f2bf(lds[o * pitch + i * K + (K - 1 - kf) - q0]);
+      }
+      return;
+    }
+  }
+  for (uint32_t d = d0 + threadIdx.x; d < d1; d += 256) {        // straight copies and oversize fallbacks
+    uint32_t si = d;
+    if (s.mode == 1) {
+      const uint32_t i = d / KO, rem = d - i * KO;
+      const uint32_t kf = rem / O, o = rem - kf * O;
+      si = o * IK + i * K + (K - 1 - kf);
+    } else if (K > 1) {
+      const uint32_t o = d / IK, rem = d - o * IK;
+      const uint32_t k = rem / I, i = rem - k * I;
+      si = o * IK + i * K + k;
+    }
+    dp[d] = f2bf(sp[si]);
   }
 }
 

@@ -201,6 +201,7 @@ class CastTable:
     def __init__(self, entries, device):
         # entries: list of (src_off, dst_off, len, I, K[, O, mode]); mode 1 = [O][I][K] -> [I][K flipped][O]
         self.entries = [tuple(e) + (0, 0) if len(e) == 5 else tuple(e) for e in entries]
+        assert all(e[2] < (1 << 31) for e in self.entries), "cast table entries are single weight tensors (< 2^31 elements)"
         self.device = torch.device(device)
         raw = b"".join(struct.pack("<qqqiiii", *e) for e in self.entries)
         self._seg = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device) if raw

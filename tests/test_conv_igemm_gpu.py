@@ -98,3 +98,20 @@ def test_cast_table_dgrad_layout():
     w = src.view(O, I, kh, kw)
     ref = torch.flip(w, dims=[2, 3]).permute(1, 2, 3, 0).contiguous().bfloat16()
     assert torch.equal(dst.view(I, kh, kw, O), ref)
+
+
+@pytest.mark.parametrize("O,I,K", [(64, 64, 9), (512, 512, 9), (256, 64, 1), (2048, 512, 1), (64, 3, 49), (128, 256, 1), (96, 40, 25)])
+def test_cast_table_lds_staged_permutes_at_network_sizes(O, I, K):
+    """Both permuting modes over many 2048-element chunks (LDS-staged path, and the direct fallback when a chunk's sources do
+    not fit), with odd destination offsets as in the real arena."""
+    from deeplearning4j_amd.ops import updater as U
+    n = O * I * K
+    torch.manual_seed(O + I + K)
+    src = torch.randn(7 + n, device="cuda")
+    ct = U.CastTable([(7, 3, n, I, K, 0, 0), (7, 3 + n + 5, n, I, K, O, 1)], "cuda")
+    dst = torch.zeros(3 + 2 * n + 5, dtype=torch.bfloat16, device="cuda")
+    ct.run(src, dst)
+    w = src[7:].view(O, I, K)
+    assert torch.equal(dst[3:3 + n].view(O, K, I), w.permute(0, 2, 1).contiguous().bfloat16())
+    assert torch.equal(dst[3 + n + 5:].view(I, K, O), torch.flip(w, dims=[2]).permute(1, 2, 0).contiguous().bfloat16())
+    assert float(dst[:3].abs().sum()) == 0 and float(dst[3 + n:3 + n + 5].abs().sum()) == 0
