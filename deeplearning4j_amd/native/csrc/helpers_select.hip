@@ -244,38 +244,49 @@ __global__ void sru_bwd_kernel(const float* __restrict__ x, const float* __restr
 }
 
 // ------------------------------------------------------------------ colour conversions on channel-last pixels [n, 3]
-// mode 0 rgb->hsv, 1 hsv->rgb, 2 3x3 matrix (rgb<->yuv / yiq; m row-major)
+// mode 0 rgb->hsv, 1 hsv->rgb, 2 3x3 matrix (rgb<->yuv / yiq; m row-major), 3 adjust_hue (delta = m[0]),
+// 4 adjust_saturation (factor = m[0])
 struct Mat3 {
   float m[9];
 };
+__device__ __forceinline__ void rgb2hsv(float a, float b, float c, float& h, float& s, float& v) {
+  const float mx = fmaxf(a, fmaxf(b, c)), mn = fminf(a, fminf(b, c)), dl = mx - mn;
+  s = mx > 0.f ? dl / fmaxf(mx, 1e-30f) : 0.f;
+  const float dz = fmaxf(dl, 1e-30f);
+  float hh = mx == a ? (b - c) / dz : (mx == b ? 2.f + (c - a) / dz : 4.f + (a - b) / dz);
+  hh = hh / 6.f;
+  hh = hh - floorf(hh);
+  h = dl == 0.f ? 0.f : hh;
+  v = mx;
+}
+__device__ __forceinline__ float hsv_chan(float n, float h6, float s, float v) {
+  float k = fmodf(n + h6, 6.f);
+  if (k < 0.f) k += 6.f;
+  return v - v * s * fminf(fmaxf(fminf(k, 4.f - k), 0.f), 1.f);
+}
 template <typename T>
 __global__ void color_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int mode, Mat3 M) {
   GRID_STRIDE(p, n) {
     const float a = Cvt<T>::ld(x, p * 3), b = Cvt<T>::ld(x, p * 3 + 1), c = Cvt<T>::ld(x, p * 3 + 2);
     float o0, o1, o2;
     if (mode == 0) {
-      const float mx = fmaxf(a, fmaxf(b, c)), mn = fminf(a, fminf(b, c)), dl = mx - mn;
-      const float s = mx > 0.f ? dl / fmaxf(mx, 1e-30f) : 0.f;
-      const float dz = fmaxf(dl, 1e-30f);
-      float h = mx == a ? (b - c) / dz : (mx == b ? 2.f + (c - a) / dz : 4.f + (a - b) / dz);
-      h = h / 6.f;
-      h = h - floorf(h);
-      o0 = dl == 0.f ? 0.f : h;
-      o1 = s;
-      o2 = mx;
+      rgb2hsv(a, b, c, o0, o1, o2);
     } else if (mode == 1) {
-      const float h6 = a * 6.f;
-      float k5 = fmodf(5.f + h6, 6.f), k3 = fmodf(3.f + h6, 6.f), k1 = fmodf(1.f + h6, 6.f);
-      if (k5 < 0.f) k5 += 6.f;
-      if (k3 < 0.f) k3 += 6.f;
-      if (k1 < 0.f) k1 += 6.f;
-      o0 = c - c * b * fminf(fmaxf(fminf(k5, 4.f - k5), 0.f), 1.f);
-      o1 = c - c * b * fminf(fmaxf(fminf(k3, 4.f - k3), 0.f), 1.f);
-      o2 = c - c * b * fminf(fmaxf(fminf(k1, 4.f - k1), 0.f), 1.f);
-    } else {
+      o0 = hsv_chan(5.f, a * 6.f, b, c);
+      o1 = hsv_chan(3.f, a * 6.f, b, c);
+      o2 = hsv_chan(1.f, a * 6.f, b, c);
+    } else if (mode == 2) {
       o0 = M.m[0] * a + M.m[1] * b + M.m[2] * c;
       o1 = M.m[3] * a + M.m[4] * b + M.m[5] * c;
       o2 = M.m[6] * a + M.m[7] * b + M.m[8] * c;
+    } else {
+      float h, s, v;
+      rgb2hsv(a, b, c, h, s, v);
+      if (mode == 3) { h += M.m[0]; h -= floorf(h); }
+      else s = fminf(fmaxf(s * M.m[0], 0.f), 1.f);
+      o0 = hsv_chan(5.f, h * 6.f, s, v);
+      o1 = hsv_chan(3.f, h * 6.f, s, v);
+      o2 = hsv_chan(1.f, h * 6.f, s, v);
     }
     Cvt<T>::st(y, p * 3, o0);
     Cvt<T>::st(y, p * 3 + 1, o1);
@@ -406,12 +417,13 @@ DL4J_API int dl4j_sru_bwd(const float* x, const float* z, const float* bias, con
   DL4J_RET_LAST();
 }
 
-// x, y: [n, 3] channel-last pixels; mode 0 rgb->hsv, 1 hsv->rgb, 2 matrix (m: 9 host floats, row-major)
+// x, y: [n, 3] channel-last pixels; mode 0 rgb->hsv, 1 hsv->rgb, 2 matrix (m: 9 host floats, row-major), 3 adjust_hue and
+// 4 adjust_saturation (m[0] = delta / factor)
 DL4J_API int dl4j_color_convert(const void* x, void* y, int64_t n, int mode, const float* m, int dtype, hipStream_t st) {
   if (n <= 0) return 0;
-  if (mode < 0 || mode > 2 || (mode == 2 && !m)) return 1;
+  if (mode < 0 || mode > 4 || (mode >= 2 && !m)) return 1;
   Mat3 M;
-  for (int j = 0; j < 9; ++j) M.m[j] = (mode == 2) ? m[j] : 0.f;
+  for (int j = 0; j < 9; ++j) M.m[j] = (mode == 2 || (mode > 2 && j == 0)) ? m[j] : 0.f;
   DISPATCH_T(hipLaunchKernelGGL(color_kernel<T>, dim3(grid_for(n, 512)), dim3(256), 0, st, (const T*)x, (T*)y, n, mode, M);)
   DL4J_RET_LAST();
 }

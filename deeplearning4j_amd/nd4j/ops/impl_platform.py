@@ -548,3 +548,94 @@ def _extract_patches(ins, i, t, b, d):
     kH, kW, sH, sW, rH, rW = [int(v) for v in i[:6]]
     p_lo, out = _nhwc_window(x, kH, kW, sH, sW, rH, rW, bool(i[6]) if len(i) > 6 else False)
     return H.extract_patches(x, kH, kW, (sH, sW), p_lo, (rH, rW), out)
+
+
+# ----------------------------------------------------------------------------- more colour / scatter / space-batch helpers
+platform("adjust_hue", lambda ins, i, t, b, d: _color_ok(ins, i, t, b, d) and (bool(t) or len(ins) > 1))(
+    lambda ins, i, t, b, d: H.color_convert(ins[0], "adjust_hue", param=t[0] if t else float(ins[1])))
+platform("adjust_saturation", lambda ins, i, t, b, d: _color_ok(ins, i, t, b, d) and (bool(t) or len(ins) > 1))(
+    lambda ins, i, t, b, d: H.color_convert(ins[0], "adjust_saturation", param=t[0] if t else float(ins[1])))
+
+
+def _scatter_red_ok(ins, i, t, b, d):
+    return (len(ins) >= 3 and _fx(ins[0]) and ins[0].dim() >= 1 and _idx(ins[1]) and isinstance(ins[2], torch.Tensor) and ins[2].is_cuda
+            and ins[2].is_floating_point() and ins[2].numel() == ins[1].numel() * (ins[0].numel() // ins[0].shape[0]))
+
+
+for _kind, _name in (("max", "scatter_max"), ("min", "scatter_min"), ("mul", "scatter_mul")):
+    platform(_name, _scatter_red_ok)(lambda ins, i, t, b, d, _k=_kind: H.scatter_reduce_rows(ins[0], ins[1].reshape(-1), ins[2], _k))
+
+
+def _perm_ok(x):
+    return L.use_hip(x) and x.is_contiguous() and x.numel() > 0 and x.element_size() in (1, 2, 4, 8)
+
+
+def _s2d_ok(ins, i, t, b, d):
+    x = ins[0]
+    if not (_perm_ok(x) and x.dim() == 4 and i and int(i[0]) > 0):
+        return False
+    bs, nhwc = int(i[0]), (len(i) > 1 and i[1] == 1)
+    h, w = (x.shape[1], x.shape[2]) if nhwc else (x.shape[2], x.shape[3])
+    return h % bs == 0 and w % bs == 0
+
+
+@platform("space_to_depth", _s2d_ok)
+def _space_to_depth(ins, i, t, b, d):
+    x, bs, nhwc = ins[0], int(i[0]), (len(i) > 1 and i[1] == 1)
+    if nhwc:
+        n, h, w, c = x.shape      # generic: NHWC -> NCHW -> [n, bs, bs, c, h/bs, w/bs] -> NHWC, composed into one permute
+        v = x.reshape(n, h // bs, bs, w // bs, bs, c)
+        return H.permute_copy(v, [0, 1, 3, 2, 4, 5]).reshape(n, h // bs, w // bs, bs * bs * c)
+    n, c, h, w = x.shape
+    return H.permute_copy(x.reshape(n, c, h // bs, bs, w // bs, bs), [0, 3, 5, 1, 2, 4]).reshape(n, c * bs * bs, h // bs, w // bs)
+
+
+def _d2s_ok(ins, i, t, b, d):
+    x = ins[0]
+    if not (_perm_ok(x) and x.dim() == 4 and i and int(i[0]) > 0):
+        return False
+    c = x.shape[3] if (len(i) > 1 and i[1] == 1) else x.shape[1]
+    return c % (int(i[0]) ** 2) == 0
+
+
+@platform("depth_to_space", _d2s_ok)
+def _depth_to_space(ins, i, t, b, d):
+    x, bs, nhwc = ins[0], int(i[0]), (len(i) > 1 and i[1] == 1)
+    if nhwc:
+        n, h, w, c = x.shape
+        v = x.reshape(n, h, w, bs, bs, c // (bs * bs))
+        return H.permute_copy(v, [0, 1, 3, 2, 4, 5]).reshape(n, h * bs, w * bs, c // (bs * bs))
+    n, c, h, w = x.shape
+    return H.permute_copy(x.reshape(n, bs, bs, c // (bs * bs), h, w), [0, 3, 4, 1, 5, 2]).reshape(n, c // (bs * bs), h * bs, w * bs)
+
+
+def _s2b_args(name, ins, i):
+    if name.endswith("_nd"):
+        return [int(v) for v in ins[1].tolist()], ins[2].long().reshape(-1, 2).tolist()
+    return [int(i[0])] * 2, ins[1].long().reshape(-1, 2).tolist()
+
+
+def _reg_space_batch(name, to_batch):
+    def ok(ins, i, t, b, d):
+        if not (_perm_ok(ins[0]) and len(ins) >= (3 if name.endswith("_nd") else 2) and (name.endswith("_nd") or i)):
+            return False
+        block, pads = _s2b_args(name, ins, i)
+        m = len(block)
+        x = ins[0]
+        if x.dim() < 1 + m or 2 * m + 1 + (x.dim() - 1 - m) > 8 or len(pads) != m or min(block) < 1:
+            return False
+        if to_batch:
+            return all((x.shape[1 + k] + pads[k][0] + pads[k][1]) % block[k] == 0 for k in range(m))
+        nb = 1
+        for bl in block:
+            nb *= bl
+        return x.shape[0] % nb == 0
+
+    def run(ins, i, t, b, d):
+        block, pads = _s2b_args(name, ins, i)
+        return (H.space_to_batch_nd if to_batch else H.batch_to_space_nd)(ins[0], block, pads)
+    platform(name, ok)(run)
+
+
+for _name, _tb in (("space_to_batch", True), ("space_to_batch_nd", True), ("batch_to_space", False), ("batch_to_space_nd", False)):
+    _reg_space_batch(_name, _tb)

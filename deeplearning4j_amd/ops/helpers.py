@@ -536,16 +536,68 @@ def sru_bwd(x, w, bias, c0, gh, gc_last=None, mask=None):
     return dx, dw, db, dc0
 
 
-def color_convert(x, mode, matrix=None):
-    """x [..., 3] channel-last; mode 'rgb_to_hsv' | 'hsv_to_rgb' | 'matrix' (3x3 nested list, out = M @ pixel)."""
+def color_convert(x, mode, matrix=None, param=0.0):
+    """x [..., 3] channel-last; mode 'rgb_to_hsv' | 'hsv_to_rgb' | 'matrix' (3x3 nested list, out = M @ pixel) |
+    'adjust_hue' (param = delta) | 'adjust_saturation' (param = factor)."""
     assert x.shape[-1] == 3
     y = torch.empty_like(x)
     m = None
     if mode == "matrix":
         m = (ctypes.c_float * 9)(*[float(v) for row in matrix for v in row])
-    L.check(L.hip().dl4j_color_convert(L.ptr(x), L.ptr(y), L.c_int64(x.numel() // 3), L.c_int({"rgb_to_hsv": 0, "hsv_to_rgb": 1, "matrix": 2}[mode]),
-                                       m, L.c_int(L.dtype_code(x)), L.stream()), "color_convert")
+    elif mode in ("adjust_hue", "adjust_saturation"):
+        m = (ctypes.c_float * 9)(float(param), *([0.0] * 8))
+    code = {"rgb_to_hsv": 0, "hsv_to_rgb": 1, "matrix": 2, "adjust_hue": 3, "adjust_saturation": 4}[mode]
+    L.check(L.hip().dl4j_color_convert(L.ptr(x), L.ptr(y), L.c_int64(x.numel() // 3), L.c_int(code), m, L.c_int(L.dtype_code(x)),
+                                       L.stream()), "color_convert")
     return y
+
+
+def scatter_reduce_rows(x, idx, upd, kind):
+    """x[idx[r], ...] = op(x[idx[r], ...], upd[r, ...]) for kind 'max' | 'min' | 'mul' (fp32 CAS atomics); returns a new tensor."""
+    rows = x.shape[0]
+    D = x.numel() // max(rows, 1)
+    acc = x.float().reshape(rows, D).contiguous()
+    if acc.data_ptr() == x.data_ptr():
+        acc = acc.clone()
+    u = upd.to(x.dtype).contiguous()
+    assert u.numel() == idx.numel() * D
+    L.check(L.hip().dl4j_segment_reduce(L.ptr(u), L.ptr(idx), L.ptr(acc), L.c_int64(idx.numel()), L.c_int(D), L.c_int64(rows),
+                                        L.c_int({"max": 1, "min": 2, "mul": 3}[kind]), L.c_int(L.dtype_code(u)),
+                                        L.c_int(1 if idx.dtype == torch.int64 else 0), L.stream()), "scatter_reduce_rows")
+    return acc.reshape(x.shape).to(x.dtype)
+
+
+def space_to_batch_nd(x, block, pads):
+    """x [N, spatial..., rest...]: zero-pad the spatial dims, then move the block offsets into the batch (one pad + one permute launch)."""
+    m = len(block)
+    full = [(0, 0)] + [(int(lo), int(hi)) for lo, hi in pads] + [(0, 0)] * (x.dim() - 1 - m)
+    xp = pad_nd(x, full) if any(lo or hi for lo, hi in full) else x
+    n, sp, rest = xp.shape[0], list(xp.shape[1:1 + m]), list(xp.shape[1 + m:])
+    shp = [n]
+    for s_, bl in zip(sp, block):
+        shp += [s_ // bl, bl]
+    v = xp.reshape(shp + rest)
+    perm = [2 + 2 * k for k in range(m)] + [0] + [1 + 2 * k for k in range(m)] + list(range(1 + 2 * m, 1 + 2 * m + len(rest)))
+    nb = 1
+    for bl in block:
+        nb *= int(bl)
+    return permute_copy(v, perm).reshape([n * nb] + [s_ // bl for s_, bl in zip(sp, block)] + rest)
+
+
+def batch_to_space_nd(x, block, crops):
+    m = len(block)
+    nb = 1
+    for bl in block:
+        nb *= int(bl)
+    n, sp, rest = x.shape[0] // nb, list(x.shape[1:1 + m]), list(x.shape[1 + m:])
+    v = x.reshape(list(block) + [n] + sp + rest)
+    perm = [m]
+    for k in range(m):
+        perm += [m + 1 + k, k]
+    perm += list(range(2 * m + 1, 2 * m + 1 + len(rest)))
+    y = permute_copy(v, perm).reshape([n] + [s_ * bl for s_, bl in zip(sp, block)] + rest)
+    key = [slice(None)] + [slice(int(lo), y.shape[1 + k] - int(hi)) for k, (lo, hi) in enumerate(crops)]
+    return y[tuple(key)]
 
 
 def nms(boxes, scores, max_out, iou_thr, score_thr=float("-inf"), overlaps=None):

@@ -225,3 +225,34 @@ def test_long_tail_layers_train_on_gpu_through_hip_kernels():
     gpu.fit(x.cuda(), y.cuda())
     pc, pg = cpu.params().reshape(-1).cpu(), gpu.params().reshape(-1).cpu()
     assert torch.allclose(pc, pg, atol=2e-4, rtol=1e-3), float((pc - pg).abs().max())
+
+
+def test_adjust_hue_saturation_scatter_reduce():
+    torch.manual_seed(14)
+    rgb = torch.rand(3, 6, 3)
+    _platform_vs_generic("adjust_hue", [rgb], [], [0.3])
+    _platform_vs_generic("adjust_hue", [rgb], [], [-0.45])
+    _platform_vs_generic("adjust_saturation", [rgb], [], [1.7])
+    _platform_vs_generic("adjust_saturation", [rgb], [], [0.4])
+    base = torch.randn(7, 5)
+    idx = torch.tensor([1, 3, 1, 6, 1, 0])
+    upd = torch.randn(6, 5)
+    for name in ("scatter_max", "scatter_min", "scatter_mul"):
+        _platform_vs_generic(name, [base, idx, upd])
+    _platform_vs_generic("scatter_max", [torch.randn(4, 2, 3), torch.tensor([[0, 2], [2, 3]]), torch.randn(2, 2, 2, 3)])
+
+
+def test_space_depth_batch_permutes():
+    torch.manual_seed(15)
+    x = torch.randn(2, 8, 6, 4)
+    for nhwc in (0, 1):
+        y = _platform_vs_generic("space_to_depth", [x], [2, nhwc])[0]
+        _platform_vs_generic("depth_to_space", [y.cpu()], [2, nhwc])
+    _platform_vs_generic("depth_to_space", [torch.randn(1, 18, 3, 5)], [3, 0])
+    nhwc = torch.randn(2, 5, 7, 3)
+    y = _platform_vs_generic("space_to_batch", [nhwc, torch.tensor([[1, 0], [0, 1]])], [2])[0]
+    assert tuple(y.shape) == (8, 3, 4, 3)
+    _platform_vs_generic("batch_to_space", [y.cpu(), torch.tensor([[1, 0], [0, 1]])], [2])
+    y = _platform_vs_generic("space_to_batch_nd", [torch.randn(3, 6, 9, 2, 2), torch.tensor([3, 3]), torch.tensor([[0, 0], [2, 1]])])[0]
+    _platform_vs_generic("batch_to_space_nd", [y.cpu(), torch.tensor([3, 3]), torch.tensor([[0, 0], [2, 1]])])
+    _platform_vs_generic("space_to_batch_nd", [torch.randn(2, 8, 3).bfloat16(), torch.tensor([4]), torch.tensor([[0, 0]])])
