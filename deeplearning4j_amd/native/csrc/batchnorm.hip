@@ -145,11 +145,13 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
 
 // Stage 2: sums[q*C + c] = sum over row-blocks of partial[(y*2+q)*C + c]; optional extra outputs
 // (gradient views for dbeta / dgamma) are written in the same pass.
-__global__ void __launch_bounds__(256) bn_sum_partials_kernel(const float* __restrict__ partial, int gy, int C,
-                                                              float* __restrict__ sums, float* __restrict__ out0,
-                                                              float* __restrict__ out1) {
-  __shared__ float red[256];
-  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;  // 32 columns x 8 row groups
+// 1024 threads = 32 columns x 32 row groups: the per-thread chain over the row blocks is the whole cost of this tiny kernel
+// (it ran ~7.6 us with 8 row groups), so it is kept short and four loads are in flight per thread.
+__global__ void __launch_bounds__(1024) bn_sum_partials_kernel(const float* __restrict__ partial, int gy, int C,
+                                                               float* __restrict__ sums, float* __restrict__ out0,
+                                                               float* __restrict__ out1) {
+  __shared__ float red[1024];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;  // 32 columns x 32 row groups
   const int col = blockIdx.x * 32 + cl;                     // column in [0, 2C)
   float a = 0.f;
   if (col < 2 * C) {
@@ -157,11 +159,11 @@ __global__ void __launch_bounds__(256) bn_sum_partials_kernel(const float* __res
     const float* p = partial + (int64_t)q * C + c;
     float a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int y = rg;
-    for (; y + 24 < gy; y += 32) {
-      a += p[(int64_t)y * 2 * C]; a1 += p[(int64_t)(y + 8) * 2 * C];
-      a2 += p[(int64_t)(y + 16) * 2 * C]; a3 += p[(int64_t)(y + 24) * 2 * C];
+    for (; y + 96 < gy; y += 128) {
+      a += p[(int64_t)y * 2 * C]; a1 += p[(int64_t)(y + 32) * 2 * C];
+      a2 += p[(int64_t)(y + 64) * 2 * C]; a3 += p[(int64_t)(y + 96) * 2 * C];
     }
-    for (; y < gy; y += 8) a += p[(int64_t)y * 2 * C];
+    for (; y < gy; y += 32) a += p[(int64_t)y * 2 * C];
     a += a1 + a2 + a3;
   }
   red[threadIdx.x] = a;
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(256) bn_sum_partials_kernel(const float* __res
   if (rg == 0 && col < 2 * C) {
     a = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a += red[k * 32 + cl];
+    for (int k = 0; k < 32; ++k) a += red[k * 32 + cl];
     sums[col] = a;
     if (col < C) { if (out0) out0[col] = a; }
     else if (out1) out1[col - C] = a;
@@ -210,7 +212,7 @@ static int launch_colreduce(const void* x, const void* dy, const void* out, cons
   else
     hipLaunchKernelGGL((bn_colreduce_kernel<T, 1, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
                        (const T*)out, mean, invstd, mscale, mshift, partial, M, C, cpb, rpi);
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, (int)gy, C, sums, out0,
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, st, partial, (int)gy, C, sums, out0,
                      out1);
   DL4J_RET_LAST();
 }
@@ -256,28 +258,34 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
 // One block owns 8 channels; its 32 row groups stride over the gy tiles (4 independent loads in flight per thread), an LDS
 // tree-less reduction (32 adds by 8 threads) finishes the sums and the same threads run the finalize math. Replaces two
 // latency-bound launches per BatchNorm (bn_sum_partials + bn_finalize) by one with 2-8x more blocks.
-__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(
+__global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(
     const float* __restrict__ partial, int gy, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ conv_bias, const float* __restrict__ gmean, const float* __restrict__ gvar, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ dgmean,
     float* __restrict__ dgvar, int C, float invM, float eps, float decay, int stat_mode) {
-  __shared__ float s0[32][9], s1[32][9];
+  // 1024 threads = 8 channels x 128 row groups (was 32): the serial chain over the M tiles was the whole cost (~7 us)
+  __shared__ float s0[128][9], s1[128][9];
   const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
   if (c < C) {
     const int64_t C2 = 2 * (int64_t)C;
     int r = rg;
-    for (; r + 32 < gy; r += 64) {
+    for (; r + 128 < gy; r += 256) {
       a0 += partial[r * C2 + c];
       b0 += partial[r * C2 + C + c];
-      a1 += partial[(r + 32) * C2 + c];
-      b1 += partial[(r + 32) * C2 + C + c];
+      a1 += partial[(r + 128) * C2 + c];
+      b1 += partial[(r + 128) * C2 + C + c];
     }
     if (r < gy) { a0 += partial[r * C2 + c]; b0 += partial[r * C2 + C + c]; }
   }
   s0[rg][cl] = a0 + a1;
   s1[rg][cl] = b0 + b1;
+  __syncthreads();
+  if (rg < 32) {
+    s0[rg][cl] += s0[rg + 32][cl] + s0[rg + 64][cl] + s0[rg + 96][cl];
+    s1[rg][cl] += s1[rg + 32][cl] + s1[rg + 64][cl] + s1[rg + 96][cl];
+  }
   __syncthreads();
   if (rg != 0 || c >= C) return;
   float su = 0.f, sq = 0.f;
@@ -488,7 +496,7 @@ DL4J_API int64_t dl4j_bn_ws_floats(int C) { return colreduce_ws_floats(C); }
 // Reduce [gy][2][C] partials (e.g. produced by the conv epilogue) to sums[2C].
 DL4J_API int dl4j_bn_sum_partials(const float* partial, int gy, int C, float* sums, float* out0, float* out1,
                                   hipStream_t st) {
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(256), 0, st, partial, gy, C, sums, out0,
+  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, st, partial, gy, C, sums, out0,
                      out1);
   DL4J_RET_LAST();
 }
@@ -516,7 +524,7 @@ DL4J_API int dl4j_bn_finalize_partials(const float* partial, int gy, const float
                                        float* dgmean, float* dgvar, int C, int64_t M, float eps, float decay, int stat_mode,
                                        hipStream_t st) {
   if (C <= 0 || gy <= 0) return 0;
-  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((C + 7) / 8), dim3(256), 0, st, partial, gy, gamma, beta, conv_bias, gmean,
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((C + 7) / 8), dim3(1024), 0, st, partial, gy, gamma, beta, conv_bias, gmean,
                      gvar, mean, invstd, scale, shift, dgmean, dgvar, C, 1.f / (float)M, eps, decay, stat_mode);
   DL4J_RET_LAST();
 }
