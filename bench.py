@@ -29,6 +29,12 @@ def main():
     ap.add_argument("--image", type=int, default=224)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON result of rank 0): RCCL prints a version banner to fd 1 when its first
+    # communicator comes up, so fd 1 is pointed at stderr for the duration of the run and the result goes to the saved fd.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from deeplearning4j_amd.parallel import comm
     from deeplearning4j_amd.models.resnet50 import ResNet50
     from deeplearning4j_amd.datasets.iterators import BenchmarkDataSetIterator
@@ -75,7 +81,7 @@ def main():
     if rank == 0:
         gb = args.batch * world
         ips = gb * args.steps / dt
-        print(json.dumps({
+        line = json.dumps({
             "metric": "images/sec (whole node) ResNet-50 ComputationGraph training",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -83,7 +89,9 @@ def main():
             "config": {"model": "ResNet-50 zoo ComputationGraph (DL4J ResNet50.java definition)", "global_batch": gb,
                        "per_gpu_batch": args.batch, "image": "3x%dx%d" % (args.image, args.image), "classes": args.classes,
                        "updater": "RmsProp(0.1,0.96,0.001)+l1 1e-7+l2 5e-5", "parallelism": "dp%d" % world,
-                       "hip_graph": not args.no_graph, "final_score": round(float(score), 4)}}))
+                       "hip_graph": not args.no_graph, "final_score": round(float(score), 4)}})
+        sys.stdout.flush()
+        os.write(result_fd, (line + "\n").encode())
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
