@@ -200,9 +200,14 @@ class SDNN(_NS):
     def dotProductAttention(self, q, k, v, mask=None, scaled=True, withWeights=False, name=None):
         return self._o("dot_product_attention", [q, k, v] + ([mask] if mask is not None else []), name, 2 if withWeights else 1,
                        iArgs=[int(scaled), int(withWeights)])
-    def dotProductAttentionV2(self, q, v, k=None, qMask=None, vMask=None, scale=1.0, dropout=0.0, causal=False, training=False, name=None):
+    def dotProductAttentionV2(self, q, v, k=None, qMask=None, vMask=None, scale=1.0, dropout=0.0, causal=False, training=False,
+                              withWeights=True, name=None):
+        """withWeights=False returns only the attention output (single SDVariable): nothing then needs the score matrices and the
+        op runs through the fused flash kernels on the GPU."""
         ins = [q, v] + ([k] if k is not None else []) + ([qMask] if qMask is not None else []) + ([vMask] if vMask is not None else [])
-        return self._o("dot_product_attention_v2", ins, name, 3, tArgs=[scale, dropout], bArgs=[causal, training])
+        key_only = int(qMask is None and vMask is not None)
+        return self._o("dot_product_attention_v2", ins, name, 3 if withWeights else 1, iArgs=[int(withWeights), key_only],
+                       tArgs=[scale, dropout], bArgs=[causal, training])
     def multiHeadDotProductAttention(self, q, k, v, Wq, Wk, Wv, Wo, mask=None, scaled=True, withWeights=False, name=None):
         return self._o("multi_head_dot_product_attention", [q, k, v, Wq, Wk, Wv, Wo] + ([mask] if mask is not None else []), name,
                        2 if withWeights else 1, iArgs=[int(scaled), int(withWeights)])

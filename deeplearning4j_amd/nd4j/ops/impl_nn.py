@@ -199,6 +199,16 @@ def _sdpa_v2(ins, i, t, b, d):
     dropout = t[1] if len(t) > 1 else 0.0
     causal = bool(b[0]) if b else False
     training = bool(b[1]) if len(b) > 1 else False
+    # iArgs (extension of this framework): [withWeights (default 1), singleMaskIsKeyMask (default 0)]. Without the weights
+    # outputs nothing forces the [.., Tq, Tk] matrices to exist, so the op goes through ops/attention.sdpa — on the GPU
+    # the fused flash kernels (forward and backward) for bf16, head size 64 / 128.
+    with_weights = bool(i[0]) if i else True
+    if len(masks) == 1 and len(i) > 1 and i[1]:
+        masks = [None, masks[0]]
+    if not with_weights and not (training and dropout > 0) and q.dim() == 4 and (not masks or masks[0] is None):
+        from ...ops import attention as ATT
+        vmask = masks[1] if len(masks) > 1 else None
+        return ATT.sdpa(q, k, v, None if vmask is None else vmask.to(torch.float32), scale, causal)
     logits = torch.matmul(q, k.transpose(-1, -2)) * scale
     Tq, Tv = logits.shape[-2], logits.shape[-1]
     neg = torch.finfo(logits.dtype).min if logits.is_floating_point() else -1e9
@@ -216,8 +226,8 @@ def _sdpa_v2(ins, i, t, b, d):
     if training and dropout > 0:
         mask = (torch.rand_like(scores) >= dropout).to(scores.dtype)
         scores = scores * mask / (1.0 - dropout)
-        return torch.matmul(scores, v), outs_scores, logits, mask
-    return torch.matmul(scores, v), outs_scores, logits
+        return (torch.matmul(scores, v), outs_scores, logits, mask) if with_weights else torch.matmul(scores, v)
+    return (torch.matmul(scores, v), outs_scores, logits) if with_weights else torch.matmul(scores, v)
 
 
 op("dot_product_attention_v2")(_sdpa_v2)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Secondary benchmark (SURVEY config 4): BERT-base sequence classification as a SameDiff graph, bf16 compute with fp32 master
+variables, batch 32 x sequence 128, synthetic tokens, Adam. Prints one JSON line (tokens/sec, ms/step)."""
+import argparse
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from deeplearning4j_amd.autodiff.samediff import SameDiff, TrainingConfig  # noqa: E402
+from deeplearning4j_amd.models.bert import BertConfig, build_bert_classifier  # noqa: E402
+from deeplearning4j_amd.nd4j.learning import Adam  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="BFLOAT16")
+    args = ap.parse_args()
+    sd = SameDiff.create("cuda")
+    cfg = BertConfig.base()
+    build_bert_classifier(sd, cfg, args.seq, 2, computeDataType=args.dtype)
+    sd.setTrainingConfig(TrainingConfig.builder().updater(Adam(2e-5)).build())
+    g = torch.Generator().manual_seed(0)
+    ph = {"tokenIdx": torch.randint(0, cfg.vocabSize, (args.batch, args.seq), generator=g).cuda(),
+          "mask": torch.ones(args.batch, args.seq).cuda(),
+          "label": torch.eye(2)[torch.randint(0, 2, (args.batch,), generator=g)].cuda()}
+    for _ in range(args.warmup):
+        sd.fit(ph)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sd.fit(ph)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    nparams = sum(int(v.getArr().tensor().numel()) for v in sd.variables.values() if v.variableType == "VARIABLE")
+    print(json.dumps({"metric": "tokens/sec BERT-base SameDiff fine-tuning step", "value": round(args.batch * args.seq / dt, 1),
+                      "ms_per_step": round(dt * 1e3, 2), "batch": args.batch, "seq_len": args.seq, "dtype": args.dtype,
+                      "params": nparams, "data": "synthetic", "final_loss": round(float(sd.output(ph, ["loss"])["loss"]), 4)}))
+
+
+if __name__ == "__main__":
+    main()
