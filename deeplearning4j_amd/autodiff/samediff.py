@@ -739,7 +739,7 @@ class SameDiff:
                     t0 = time.perf_counter_ns()
                     for l in listeners:
                         l.preOpExecution(self, at, o, ins)
-                    outs = self._exec_op(o, ins, allow_helpers=not training)
+                    outs = self._exec_op(o, ins, allow_helpers=True)
                     for l in listeners:
                         l.opExecution(self, at, o, ins, outs, time.perf_counter_ns() - t0)
             produced = []
@@ -833,7 +833,7 @@ class SameDiff:
     batchOutput = output
 
     # ------------------------------------------------------------------ gradients / training
-    def _loss_and_grads(self, placeholders, wrt: Sequence[str], extra_outputs=(), listeners=(), at=None):
+    def _loss_and_grads(self, placeholders, wrt: Sequence[str], extra_outputs=(), listeners=(), at=None, device_losses=False):
         if not self.lossVariables:
             raise RuntimeError("no loss variables set: call setLossVariables / markAsLoss")
         ph = self._prep_placeholders(placeholders)
@@ -858,6 +858,8 @@ class SameDiff:
             for n, a in saved.items():
                 self._arrays[n] = a
         gd = {n: (g if g is not None else torch.zeros_like(t)) for n, g, t in zip(wrt, grads, leaves)}
+        if device_losses:          # no host synchronisation (HIP-graph capture of the training step)
+            return [l.detach().sum() for l in losses], gd, {n: res[n].detach() for n in extra_outputs}
         return [float(l.detach().sum()) for l in losses], gd, {n: res[n].detach() for n in extra_outputs}
 
     def calculateGradients(self, placeholders, *variables) -> Dict[str, INDArray]:
@@ -930,9 +932,12 @@ class SameDiff:
                 ph = self._placeholders_from_dataset(ds)
                 for l in ls:
                     l.iterationStart(self, at, ds, 0)
-                losses, grads, extra = self._loss_and_grads(ph, trainable, sorted(required), ls, at)
-                self._apply_updates(grads, at)
-                self._last_grads.update(grads)
+                losses = self._captured_step(ph, trainable) if self._capture_eligible(ls, required) else None
+                extra = {}
+                if losses is None:
+                    losses, grads, extra = self._loss_and_grads(ph, trainable, sorted(required), ls, at)
+                    self._apply_updates(grads, at)
+                    self._last_grads.update(grads)
                 for k, v in enumerate(losses):
                     sums[k] += v
                 nb += 1
@@ -991,7 +996,7 @@ class SameDiff:
     # the .fb serialization is unchanged), and a training step applies updater + l1/l2/weight decay for every variable in a
     # single launch of the segmented updater kernel (native/csrc/updaters.hip) instead of ~6 launches and a table upload per
     # variable. Reference: TrainingSession.trainingIteration applies one GradientUpdater per variable.
-    def _fused_update(self, grads: Dict[str, torch.Tensor]) -> bool:
+    def _fused_update(self, grads: Dict[str, torch.Tensor], in_capture=False) -> bool:
         from ..native import lib as NL
         from ..ops import updater as U
         tc = self.trainingConfig
@@ -1052,9 +1057,77 @@ class SameDiff:
             flat_g = torch.cat([grads[n].detach().reshape(-1).to(torch.float32) for n in names])
             if not tc.minimize:
                 flat_g.neg_()
-            su.set_iteration(it)
+            if not in_capture:             # a captured step relies on the kernel's own device-side iteration increment
+                su.set_iteration(it)
             su.step(flat, flat_g, fu["state"], 1)
         return True
+
+    # -- HIP-graph capture of the whole SameDiff training iteration (forward interpreter + autograd backward + fused update).
+    # The session is a Python dataflow interpreter: a BERT-base step issues ~1.5k small launches and is host bound; replaying
+    # the captured iteration removes the interpreter and the launch overhead from the steady state. Shapes must be static
+    # (one capture per placeholder signature); graphs with random ops or listeners that need activations stay eager.
+    def enableGraphCapture(self, on=True):
+        self._capture_on = bool(on)
+        self._cap = None
+        return self
+
+    _RANDOM_OPS = ("dropout", "random", "alpha_dropout", "dropout_inverted", "randomuniform", "randomnormal", "random_bernoulli")
+
+    def _capture_eligible(self, ls, required):
+        if not getattr(self, "_capture_on", False) or self.device.type != "cuda" or required:
+            return False
+        if any(getattr(l, "needsPerOpCallbacks", False) for l in ls):
+            return False
+        if getattr(self, "_cap_static_ok", None) is None:
+            names = [getattr(o, "opName", "") or "" for o in self.ops.values()]
+            self._cap_static_ok = not any(any(r in n.lower() for r in self._RANDOM_OPS) for n in names)
+        return self._cap_static_ok
+
+    def _captured_step(self, ph, trainable):
+        """One training iteration through the captured graph; returns the loss values, or None when this signature cannot be
+        captured (the caller then runs the eager step)."""
+        tc = self.trainingConfig
+        ph = self._prep_placeholders(ph)
+        key = tuple(sorted((n, tuple(t.shape), str(t.dtype)) for n, t in ph.items())) + (tuple(trainable),)
+        cap = getattr(self, "_cap", None)
+        if cap is None or cap["key"] != key:
+            cap = self._cap = {"key": key, "warm": 0, "graph": None}
+        if cap["warm"] < 2:                       # eager warm-up: lazy allocations, flat variable vector, library handles
+            cap["warm"] += 1
+            return None
+        if cap["graph"] is None:
+            try:
+                static = {n: t.clone() for n, t in ph.items()}
+                self._fused["su"].set_iteration(tc.iterationCount)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    losses, grads, _ = self._loss_and_grads(static, trainable, device_losses=True)
+                    ok = self._fused_update(grads, in_capture=True)
+                if not ok:
+                    raise RuntimeError("fused update not available")
+                cap.update(graph=g, static=static, losses=losses, grads=grads, hp=self._fused["key"])
+            except Exception as e:            # a host synchronisation inside some op, unsupported updater, ...
+                import warnings
+                warnings.warn("SameDiff graph capture disabled for this graph: %s" % (e,))
+                self._capture_on = False
+                self._cap = None
+                torch.cuda.synchronize()
+                return None
+        for n, t in ph.items():
+            cap["static"][n].copy_(t)
+        it, ep = tc.iterationCount, tc.epochCount
+        fu = self._fused
+        lr, a_, b_, eps = tc.updater.segment_hparams(it, ep)
+        if (lr, a_, b_, eps) != fu["key"][:4]:                  # schedules: refresh the device table the captured kernel reads
+            for sg in fu["su"].segments:
+                sg.lr, sg.a, sg.b, sg.eps = lr, a_, b_, eps
+            fu["key"] = (lr, a_, b_, eps) + tuple(fu["key"][4:])
+            fu["su"]._upload()
+        cap["graph"].replay()
+        self._last_grads.update(cap["grads"])
+        return [float(l) for l in cap["losses"]]
 
     def _apply_updates(self, grads: Dict[str, torch.Tensor], at):
         tc = self.trainingConfig

@@ -34,9 +34,12 @@ def op(*names):
     return deco
 
 
-def platform(name, usable):
-    """Register a platform helper (hand-written HIP path) with its ``isUsable(ins, i, t, b, d)`` predicate."""
+def platform(name, usable, differentiable=False):
+    """Register a platform helper (hand-written HIP path) with its ``isUsable(ins, i, t, b, d)`` predicate.
+    ``differentiable``: the helper is an autograd-aware function (HIP kernels in both directions), so it may also run while a
+    SameDiff training session records the graph; other helpers are skipped as soon as an input requires grad."""
     def deco(fn):
+        fn._differentiable = bool(differentiable)
         _PLATFORM.setdefault(name, []).append((usable, fn))
         return fn
     return deco
@@ -307,10 +310,10 @@ class OpExecutioner:
 
     def _run(self, name, ins, i, t, b, d, allow_helpers=True):
         _load_impls()
-        if allow_helpers and self.env.helpersAllowed() and not any(
-                isinstance(x, torch.Tensor) and x.requires_grad for x in ins):
-            for usable, fn in _PLATFORM.get(name, ()):
-                if usable(ins, i, t, b, d):
+        if allow_helpers and self.env.helpersAllowed() and name in _PLATFORM:
+            tracked = torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in ins)
+            for usable, fn in _PLATFORM[name]:
+                if (not tracked or getattr(fn, "_differentiable", False)) and usable(ins, i, t, b, d):
                     return fn(ins, i, t, b, d)
         if name not in _IMPL:
             canon = name_by_hash(op_hash(name))         # DECLARE_SYN aliases resolve to the canonical op (mmul -> matmul)
@@ -320,8 +323,9 @@ class OpExecutioner:
             if canon in _PLATFORM:
                 _PLATFORM.setdefault(name, _PLATFORM[canon])
                 for usable, fn in _PLATFORM[name]:
-                    if allow_helpers and self.env.helpersAllowed() and not any(
-                            isinstance(x, torch.Tensor) and x.requires_grad for x in ins) and usable(ins, i, t, b, d):
+                    tracked = torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in ins)
+                    if allow_helpers and self.env.helpersAllowed() and (not tracked or getattr(fn, "_differentiable", False)) \
+                            and usable(ins, i, t, b, d):
                         return fn(ins, i, t, b, d)
         return _IMPL[name](ins, i, t, b, d)
 

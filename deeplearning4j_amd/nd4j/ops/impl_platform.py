@@ -58,9 +58,12 @@ def _ln_ok(ins, i, t, b, d):
     return axes == [x.dim() - 1] and ins[1].numel() == x.shape[-1] and (len(ins) < 3 or ins[2].numel() == x.shape[-1])
 
 
-@platform("layer_norm", _ln_ok)
+@platform("layer_norm", _ln_ok, differentiable=True)
 def _layer_norm(ins, i, t, b, d):
-    return H.layer_norm(ins[0], ins[1], ins[2] if len(ins) > 2 else None, float(t[0]) if t else 1e-5)
+    eps = float(t[0]) if t else 1e-5
+    if torch.is_grad_enabled() and any(isinstance(v, torch.Tensor) and v.requires_grad for v in ins):
+        return H.LayerNormFn.apply(ins[0], ins[1], ins[2] if len(ins) > 2 else None, eps)
+    return H.layer_norm(ins[0], ins[1], ins[2] if len(ins) > 2 else None, eps)
 
 
 def _ln_bp_ok(ins, i, t, b, d):

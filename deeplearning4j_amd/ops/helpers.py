@@ -407,6 +407,29 @@ def strided_slice_nd(x, begins, steps, counts):
     return index_map(x, out, maps)
 
 
+class LayerNormFn(torch.autograd.Function):
+    """Differentiable layer norm over the last axis: HIP kernels in both directions (one pass forward with saved mean / rstd,
+    dx pass + partial column reduction backward). Used by the layer_norm platform helper while SameDiff records a training graph."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xc = x.contiguous()
+        y, mean, rstd = layer_norm(xc, gamma, beta, eps, want_stats=True)
+        ctx.save_for_backward(xc, gamma, mean, rstd)
+        ctx.has_beta = beta is not None
+        ctx.bdt = None if beta is None else beta.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        need_p = ctx.needs_input_grad[1] or (ctx.has_beta and ctx.needs_input_grad[2])
+        dx, dg, db = layer_norm_bwd(x, g.to(x.dtype).contiguous(), gamma, mean, rstd, want_param_grads=need_p)
+        dgamma = dg.reshape(gamma.shape).to(gamma.dtype) if (dg is not None and ctx.needs_input_grad[1]) else None
+        dbeta = db.reshape(gamma.shape).to(ctx.bdt) if (db is not None and ctx.has_beta and ctx.needs_input_grad[2]) else None
+        return dx, dgamma, dbeta, None
+
+
 # ----------------------------------------------------------------------------- selection / indexed reductions (helpers_select.hip)
 def segment_reduce(x, seg, num_segments, kind):
     """kind: 'max' | 'min' | 'prod' | 'mean'. Empty segments keep the identity (-/+ finfo.max, 1) or 0 for mean."""

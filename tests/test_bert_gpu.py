@@ -74,3 +74,36 @@ def test_samediff_fused_updater_matches_per_variable_path(upd):
     if buf is not None:
         sd2 = SameDiff.fromFlatBuffers(bytes(buf), True, "cuda")
         assert torch.allclose(sd2.getArrForVarName("w0").tensor().cpu(), a["w0"])
+
+
+def test_samediff_training_step_hip_graph_capture_matches_eager():
+    """enableGraphCapture: after two eager warm-up iterations the whole step (interpreter forward, autograd backward, fused update)
+    is one HIP-graph replay; parameters follow the eager trajectory, an Adam schedule still takes effect, and new data is used."""
+    from deeplearning4j_amd.autodiff.samediff import SameDiff, TrainingConfig
+    from deeplearning4j_amd.models.bert import BertConfig, build_bert_classifier
+    from deeplearning4j_amd.nd4j.learning import Adam
+    from test_bert_cpu import _data
+
+    def run(capture):
+        torch.manual_seed(0)
+        T = 32
+        sd = SameDiff.create("cuda")
+        build_bert_classifier(sd, BertConfig.tiny(vocab=50, hidden=128, layers=2, heads=2, intermediate=256, maxPositions=64), T, 2,
+                              computeDataType="BFLOAT16")
+        sd.setTrainingConfig(TrainingConfig.builder().updater(Adam(1e-3)).l2(1e-4).build())
+        if capture:
+            sd.enableGraphCapture(True)
+        losses = []
+        for k in range(12):
+            idx, mask, lab = _data(32, T, 50, seed=k % 3)          # the batch changes between iterations
+            h = sd.fit({"tokenIdx": idx.cuda(), "mask": mask.cuda(), "label": lab.cuda()})
+            losses.append(h.lossCurve.lastMeanLoss()[0])
+        return losses, sd
+
+    le, _ = run(False)
+    lc, sdc = run(True)
+    assert sdc._cap is not None and sdc._cap["graph"] is not None, "the step was not captured"
+    assert sdc.trainingConfig.iterationCount == 12
+    for a, b in zip(le, lc):
+        assert abs(a - b) < 2e-2 * max(1.0, abs(a)), (le, lc)
+    assert lc[-1] < lc[0]

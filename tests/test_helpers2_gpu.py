@@ -256,3 +256,28 @@ def test_space_depth_batch_permutes():
     y = _platform_vs_generic("space_to_batch_nd", [torch.randn(3, 6, 9, 2, 2), torch.tensor([3, 3]), torch.tensor([[0, 0], [2, 1]])])[0]
     _platform_vs_generic("batch_to_space_nd", [y.cpu(), torch.tensor([3, 3]), torch.tensor([[0, 0], [2, 1]])])
     _platform_vs_generic("space_to_batch_nd", [torch.randn(2, 8, 3).bfloat16(), torch.tensor([4]), torch.tensor([[0, 0]])])
+
+
+def test_layer_norm_differentiable_platform_helper_under_autograd():
+    """The layer_norm helper stays on the HIP kernels while gradients are recorded (SameDiff training): grads equal the generic op's."""
+    import deeplearning4j_amd.nd4j.ops.custom as c
+    from deeplearning4j_amd.ops import helpers as H
+    c._load_impls()
+    torch.manual_seed(16)
+    x = torch.randn(37, 96)
+    gain, bias = torch.rand(96) + 0.5, torch.randn(96)
+    g = torch.randn(37, 96)
+    outs = []
+    for dev_ in ("cpu", "cuda"):
+        leaves = [t.clone().to(dev_).requires_grad_(True) for t in (x, gain, bias)]
+        usable, fn = c._PLATFORM["layer_norm"][0]
+        if dev_ == "cuda":
+            assert fn._differentiable and usable(leaves, [1], [1e-5], [], [])
+            y = fn(leaves, [1], [1e-5], [], [])
+            assert isinstance(y.grad_fn, H.LayerNormFn._backward_cls) or "LayerNormFn" in type(y.grad_fn).__name__
+        else:
+            y = c._IMPL["layer_norm"](leaves, [1], [1e-5], [], [])
+        y.backward(g.to(dev_))
+        outs.append([y.detach().cpu()] + [l.grad.cpu() for l in leaves])
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, atol=2e-4, rtol=1e-4), float((a - b).abs().max())

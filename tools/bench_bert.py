@@ -21,11 +21,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="BFLOAT16")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the training step into a HIP graph")
     args = ap.parse_args()
     sd = SameDiff.create("cuda")
     cfg = BertConfig.base()
     build_bert_classifier(sd, cfg, args.seq, 2, computeDataType=args.dtype)
     sd.setTrainingConfig(TrainingConfig.builder().updater(Adam(2e-5)).build())
+    if not args.no_graph:
+        sd.enableGraphCapture(True)
     g = torch.Generator().manual_seed(0)
     ph = {"tokenIdx": torch.randint(0, cfg.vocabSize, (args.batch, args.seq), generator=g).cuda(),
           "mask": torch.ones(args.batch, args.seq).cuda(),
@@ -41,7 +44,7 @@ def main():
     nparams = sum(int(v.getArr().tensor().numel()) for v in sd.variables.values() if v.variableType == "VARIABLE")
     print(json.dumps({"metric": "tokens/sec BERT-base SameDiff fine-tuning step", "value": round(args.batch * args.seq / dt, 1),
                       "ms_per_step": round(dt * 1e3, 2), "batch": args.batch, "seq_len": args.seq, "dtype": args.dtype,
-                      "params": nparams, "data": "synthetic", "final_loss": round(float(sd.output(ph, ["loss"])["loss"]), 4)}))
+                      "params": nparams, "hip_graph": bool(getattr(sd, "_cap", None) and sd._cap.get("graph") is not None), "data": "synthetic", "final_loss": round(float(sd.output(ph, ["loss"])["loss"]), 4)}))
 
 
 if __name__ == "__main__":
