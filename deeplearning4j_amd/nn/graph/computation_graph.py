@@ -393,7 +393,14 @@ class ComputationGraph(BaseNetwork):
                 res.append(self.output(*(f if isinstance(f, (list, tuple)) else [f])))
             return [torch.cat([r[i] for r in res], 0) for i in range(len(res[0]))]
         with torch.no_grad():
-            acts = self._forward(self._prep_inputs(list(xs)), train, fmasks=featureMasks)
+            ins = self._prep_inputs(list(xs))
+            cap = getattr(self, "_infer_cap", None)
+            if cap is not None and not train and featureMasks is None:
+                outs = cap.run(lambda z: [self._wrap(a) for a in (lambda acts: [acts[o] for o in self.conf.networkOutputs])(
+                    self._forward(z, False, fmasks=None))], ins)
+                if outs is not None:
+                    return outs
+            acts = self._forward(ins, train, fmasks=featureMasks)
         self.clearLayerMaskArrays()
         return [self._wrap(acts[o]) for o in self.conf.networkOutputs]
 
@@ -690,6 +697,12 @@ class ComputationGraph(BaseNetwork):
     def enableGraphCapture(self, enabled=True):
         from ..graph_capture import CapturedTrainStep
         self._graph_step = CapturedTrainStep(self) if enabled and self.ctx.device.type == "cuda" else None
+        return self
+
+    def enableInferenceCapture(self, enabled=True):
+        """Replay output() as a HIP graph per input signature (GPU only; calls with masks or train=True stay eager)."""
+        from ..graph_capture import CapturedInference
+        self._infer_cap = CapturedInference() if enabled and self.ctx.device.type == "cuda" else None
         return self
 
 

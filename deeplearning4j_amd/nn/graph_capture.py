@@ -130,3 +130,54 @@ class CapturedTrainStep:
             net._on_backward_progress, net._on_backward_begin = hook, begin_hook
         torch.cuda.current_stream().wait_stream(side)
         return segs
+
+
+class CapturedInference:
+    """HIP-graph replay of the inference forward pass, one graph per input signature (shapes + dtypes).
+
+    Small-batch inference is launch bound (the zoo ResNet-50 forward is ~220 launches: 2.8 ms at batch 32 and 3.0 ms at
+    batch 256 when issued eagerly), which is exactly the serving case of ParallelInference (reference:
+    parallelism/ParallelInference.java). The first ``warmup`` calls of a signature run eagerly (lazy allocations, library
+    handles); then the forward is captured once and later calls copy the inputs into the static buffers and replay.
+    """
+
+    def __init__(self, warmup=2, max_graphs=8):
+        self.warmup, self.max_graphs = warmup, max_graphs
+        self.entries = {}
+        self.disabled = False
+        self._stream = None
+
+    def run(self, fwd, xs):
+        """fwd(list of tensors) -> list of tensors. Returns the outputs (fresh tensors), or None when the caller should run eagerly."""
+        if self.disabled or not xs or not all(isinstance(x, torch.Tensor) and x.is_cuda for x in xs):
+            return None
+        key = tuple((tuple(x.shape), x.dtype) for x in xs)
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) >= self.max_graphs:
+                return None
+            e = self.entries[key] = {"seen": 0, "graph": None}
+        if e["graph"] is None:
+            e["seen"] += 1
+            if e["seen"] <= self.warmup:
+                return None
+            try:
+                if self._stream is None:
+                    self._stream = torch.cuda.Stream()
+                static_in = [x.clone() for x in xs]
+                self._stream.wait_stream(torch.cuda.current_stream())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self._stream, capture_error_mode="thread_local"):
+                    static_out = fwd(static_in)
+                e.update(graph=g, static_in=static_in, static_out=static_out)
+            except Exception as ex:           # an op that synchronises with the host: stay eager for this network
+                import warnings
+                warnings.warn("inference graph capture disabled: %s" % (ex,))
+                self.disabled = True
+                self.entries.clear()
+                torch.cuda.synchronize()
+                return None
+        for s, x in zip(e["static_in"], xs):
+            s.copy_(x)
+        e["graph"].replay()
+        return [o.clone() for o in e["static_out"]]

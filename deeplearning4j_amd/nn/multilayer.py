@@ -195,6 +195,11 @@ class MultiLayerNetwork(BaseNetwork):
         self._check_init()
         with torch.no_grad():
             x = self._prep_features(x)
+            cap = getattr(self, "_infer_cap", None)
+            if cap is not None and not train and featuresMask is None and labelsMask is None:
+                outs = cap.run(lambda z: [self._wrap_out(self._forward(z[0], False, fmask=None))], [x])
+                if outs is not None:
+                    return outs[0]
             y = self._forward(x, train, fmask=self._to_dev(featuresMask))
         self.clearLayerMaskArrays()
         return self._wrap_out(y)
@@ -542,6 +547,12 @@ class MultiLayerNetwork(BaseNetwork):
         """Capture the training iteration into a HIP graph (static shapes; GPU only)."""
         from .graph_capture import CapturedTrainStep
         self._graph_step = CapturedTrainStep(self) if enabled and self.ctx.device.type == "cuda" else None
+        return self
+
+    def enableInferenceCapture(self, enabled=True):
+        """Replay output() as a HIP graph per input signature (GPU only; calls with masks or train=True stay eager)."""
+        from .graph_capture import CapturedInference
+        self._infer_cap = CapturedInference() if enabled and self.ctx.device.type == "cuda" else None
         return self
 
 

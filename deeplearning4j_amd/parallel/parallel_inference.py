@@ -86,6 +86,8 @@ class _Worker(threading.Thread):
         v = self.pi._model_version
         if v != self._model_version:
             self.replica = _replicate(self.pi.model, self.device)
+            if self.pi.graphCapture and self.device.type == "cuda" and hasattr(self.replica, "enableInferenceCapture"):
+                self.replica.enableInferenceCapture(True)      # launch-bound small batches: replay the forward as a HIP graph
             self._model_version = v
 
     def run(self):
@@ -144,6 +146,13 @@ class _Worker(threading.Thread):
             ins = [x.to(dev, non_blocking=True) for x in ins]
             if masks:
                 masks = [None if m is None else m.to(dev, non_blocking=True) for m in masks]
+            n = int(ins[0].shape[0])
+            if self.pi.graphCapture and dev.type == "cuda" and masks is None and n > 0:
+                # pad the dynamic batch to the next power of two so that a handful of captured graphs serve every batch size
+                # (inference is per-example independent; the padded rows are dropped when the outputs are sliced below)
+                tgt = 1 << (n - 1).bit_length()
+                if tgt != n:
+                    ins = [torch.cat([x, x[-1:].expand(tgt - n, *x.shape[1:])], 0) for x in ins]
             outs = [_raw(y) for y in _forward(self.replica, ins, masks)]
             if self.stream is not None:
                 self.stream.synchronize()
@@ -166,7 +175,8 @@ class ParallelInference:
     DEFAULT_NUM_WORKERS, DEFAULT_BATCH_LIMIT, DEFAULT_QUEUE_LIMIT = None, 32, 64
 
     def __init__(self, model, workers=None, inferenceMode=InferenceMode.BATCHED, batchLimit=32, queueLimit=64,
-                 loadBalanceMode=LoadBalanceMode.FIFO, devices: Optional[Sequence] = None, maxWaitMs=0):
+                 loadBalanceMode=LoadBalanceMode.FIFO, devices: Optional[Sequence] = None, maxWaitMs=0, graphCapture=True):
+        self.graphCapture = bool(graphCapture)
         self.model = model
         self.inferenceMode, self.loadBalanceMode = inferenceMode, loadBalanceMode
         self.batchLimit, self.queueLimit, self.maxWaitMs = int(batchLimit), int(queueLimit), maxWaitMs

@@ -255,3 +255,45 @@ def test_two_captured_networks_in_one_process():
         assert abs(sa - s0) < 1e-3 * abs(s0) and abs(sb - s0) < 1e-3 * abs(s0), scores
     rel = (a._grads - b._grads).norm() / a._grads.norm()
     assert rel < 1e-3, float(rel)
+
+
+def test_inference_graph_capture_matches_eager_and_parallel_inference_pads_batches():
+    """enableInferenceCapture: output() replayed as a HIP graph equals the eager forward for several batch sizes, also after a
+    training step changed the weights; ParallelInference (BATCHED) serves odd batch sizes through power-of-two padded graphs."""
+    from deeplearning4j_amd.models.resnet50 import ResNet50
+    from deeplearning4j_amd.parallel.parallel_inference import ParallelInference, InferenceMode
+    torch.manual_seed(0)
+    net = ResNet50(numClasses=10, inputShape=(3, 160, 160), computeDataType="BFLOAT16").init(device=dev())
+    xs = {b: torch.randn(b, 3, 160, 160, device=dev()) for b in (4, 7)}
+    ref = {b: net.output(x)[0].clone() for b, x in xs.items()}
+    net.enableInferenceCapture(True)
+    for _ in range(4):
+        for b, x in xs.items():
+            y = net.output(x)[0]
+            assert torch.allclose(y, ref[b], atol=2e-3, rtol=2e-2), float((y - ref[b]).abs().max())
+    assert sum(e["graph"] is not None for e in net._infer_cap.entries.values()) == 2
+    # weights change between calls: the captured graph reads the refreshed parameters (LeNet, MultiLayerNetwork path)
+    from deeplearning4j_amd.models.lenet import LeNet
+    ln = LeNet(numClasses=10, inputShape=(1, 28, 28)).init(device=dev())
+    xl = torch.randn(16, 1, 28, 28, device=dev())
+    yl = torch.nn.functional.one_hot(torch.arange(16) % 10, 10).float().to(dev())
+    before = ln.output(xl).clone()
+    ln.enableInferenceCapture(True)
+    for _ in range(4):
+        assert torch.allclose(ln.output(xl), before, atol=1e-5)
+    for _ in range(3):
+        ln.fit(xl, yl)
+    got = ln.output(xl).clone()
+    ln.enableInferenceCapture(False)
+    after = ln.output(xl)
+    assert torch.allclose(got, after, atol=1e-5) and not torch.allclose(after, before, atol=1e-4)
+    net.enableInferenceCapture(False)
+    pi = ParallelInference(net, workers=1, inferenceMode=InferenceMode.BATCHED, batchLimit=8)
+    try:
+        for _ in range(5):
+            out = pi.output(xs[7].cpu())
+            out = out[0] if isinstance(out, (list, tuple)) else out
+            assert tuple(out.shape) == (7, 10)
+            assert torch.allclose(out.to(dev()).float(), net.output(xs[7])[0].float(), atol=2e-3, rtol=2e-2)
+    finally:
+        pi.shutdown()
