@@ -833,19 +833,55 @@ class SameDiff:
     batchOutput = output
 
     # ------------------------------------------------------------------ gradients / training
-    def _loss_and_grads(self, placeholders, wrt: Sequence[str], extra_outputs=(), listeners=(), at=None, device_losses=False):
+    def _bf16_shadowable(self):
+        """Trainable fp32 variables whose ONLY consumers are ``cast`` ops to BFLOAT16 (mixed-precision graphs: fp32 master
+        variable, bf16 at every use). During a training step their leaves can be views of one bf16 copy of the flat variable
+        vector: one cast launch instead of one per variable, and the per-variable cast ops become no-ops."""
+        key = (len(self.ops), len(self.variables))
+        c = getattr(self, "_shadow_cache", None)
+        if c is not None and c[0] == key:
+            return c[1]
+        users: Dict[str, list] = {}
+        for o in self.ops.values():
+            for i_ in o.inputs:
+                users.setdefault(i_, []).append(o)
+        ok = set()
+        for n in self.trainableVariables():
+            us = users.get(n, [])
+            if us and all(u.opName == "cast" and [str(a).upper() for a in (u.dArgs or [])] in (["BFLOAT16"], ["BF16"]) for u in us):
+                ok.add(n)
+        self._shadow_cache = (key, ok)
+        return ok
+
+    def _loss_and_grads(self, placeholders, wrt: Sequence[str], extra_outputs=(), listeners=(), at=None, device_losses=False,
+                        shadow_ok=False):
         if not self.lossVariables:
             raise RuntimeError("no loss variables set: call setLossVariables / markAsLoss")
         ph = self._prep_placeholders(placeholders)
         saved = {}
         leaves = []
+        fu = getattr(self, "_fused", None) if shadow_ok else None
+        shadow, offs, shadowable = None, {}, ()
+        if fu is not None:
+            shadowable = self._bf16_shadowable()
+            if shadowable:
+                off = 0
+                for n_, sz in zip(fu["names"], fu["sizes"]):
+                    offs[n_] = (off, sz)
+                    off += sz
         for n in wrt:
             if n in ph:
                 t = ph[n].detach().clone().requires_grad_(True)
                 ph[n] = t
             else:
                 saved[n] = self._arrays[n]
-                t = self._arrays[n].detach().requires_grad_(True)
+                a = self._arrays[n]
+                if n in shadowable and n in offs and a.data_ptr() == fu["flat"].data_ptr() + 4 * offs[n][0] and a.numel() == offs[n][1]:
+                    if shadow is None:
+                        shadow = fu["flat"].to(torch.bfloat16)
+                    t = shadow[offs[n][0]:offs[n][0] + offs[n][1]].view(a.shape).detach().requires_grad_(True)
+                else:
+                    t = a.detach().requires_grad_(True)
                 self._arrays[n] = t
             leaves.append(t)
         try:
@@ -935,7 +971,7 @@ class SameDiff:
                 losses = self._captured_step(ph, trainable) if self._capture_eligible(ls, required) else None
                 extra = {}
                 if losses is None:
-                    losses, grads, extra = self._loss_and_grads(ph, trainable, sorted(required), ls, at)
+                    losses, grads, extra = self._loss_and_grads(ph, trainable, sorted(required), ls, at, shadow_ok=True)
                     self._apply_updates(grads, at)
                     self._last_grads.update(grads)
                 for k, v in enumerate(losses):
@@ -1054,7 +1090,16 @@ class SameDiff:
             su._tables_dirty = True
             fu["key"] = key
         with torch.no_grad():
-            flat_g = torch.cat([grads[n].detach().reshape(-1).to(torch.float32) for n in names])
+            if fu.get("flat_g") is None:
+                fu["flat_g"] = torch.empty_like(flat)
+                offs, o_ = [], 0
+                for sz in sizes:
+                    offs.append(o_)
+                    o_ += sz
+                fu["g_views"] = [fu["flat_g"][o_:o_ + sz] for o_, sz in zip(offs, sizes)]
+            flat_g = fu["flat_g"]
+            # multi-tensor copy (with the bf16 -> fp32 conversion of shadow-leaf gradients) instead of one cast + cat per variable
+            torch._foreach_copy_(fu["g_views"], [grads[n].detach().reshape(-1) for n in names])
             if not tc.minimize:
                 flat_g.neg_()
             if not in_capture:             # a captured step relies on the kernel's own device-side iteration increment
@@ -1103,7 +1148,7 @@ class SameDiff:
                 side.wait_stream(torch.cuda.current_stream())
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                    losses, grads, _ = self._loss_and_grads(static, trainable, device_losses=True)
+                    losses, grads, _ = self._loss_and_grads(static, trainable, device_losses=True, shadow_ok=True)
                     ok = self._fused_update(grads, in_capture=True)
                 if not ok:
                     raise RuntimeError("fused update not available")
