@@ -294,6 +294,31 @@ __global__ void color_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t
   }
 }
 
+// ------------------------------------------------------------------ Barnes-Hut t-SNE attractive (edge) forces over a CSR graph
+// out[n, :] = sum_{k in row n} val[k] / (1 + |y_n - y_col[k]|^2) * (y_n - y_col[k]); one thread per row, D <= 8 in registers
+template <typename I>
+__global__ void barnes_edge_forces_kernel(const I* __restrict__ rowP, const I* __restrict__ colP, const float* __restrict__ val,
+                                          const float* __restrict__ y, float* __restrict__ out, int N, int D, int64_t nnz) {
+  GRID_STRIDE(n, (int64_t)N) {
+    float yn[8], acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { yn[j] = j < D ? y[n * D + j] : 0.f; acc[j] = 0.f; }
+    int64_t k0 = (int64_t)rowP[n], k1 = (int64_t)rowP[n + 1];
+    if (k1 > nnz) k1 = nnz;
+    for (int64_t k = k0; k < k1; ++k) {
+      const int64_t c = (int64_t)colP[k];
+      if (c < 0 || c >= N) continue;
+      float diff[8], d2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { diff[j] = j < D ? yn[j] - y[c * D + j] : 0.f; d2 += diff[j] * diff[j]; }
+      const float w = val[k] / (1.f + d2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += w * diff[j];
+    }
+    for (int j = 0; j < D; ++j) out[n * D + j] = acc[j];
+  }
+}
+
 // ------------------------------------------------------------------ greedy non-max suppression, one block
 // order: candidate indices by descending score; overlaps (optional) [N, N] replaces the box IoU
 __device__ __forceinline__ float box_iou(const float* a, const float* b) {
@@ -434,5 +459,15 @@ DL4J_API int dl4j_nms(const float* boxes, const float* overlaps, const float* sc
   if (N <= 0 || max_out <= 0) return 1;
   if (!boxes && !overlaps) return 1;
   hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(256), 0, st, boxes, overlaps, scores, order, keep, count, N, max_out, thr, score_thr);
+  DL4J_RET_LAST();
+}
+
+// rowP [N+1], colP / val [nnz] (CSR), y / out fp32 [N, D], D <= 8
+DL4J_API int dl4j_barnes_edge_forces(const void* rowP, const void* colP, const float* val, const float* y, float* out, int N, int D,
+                                     int64_t nnz, int idx64, hipStream_t st) {
+  if (N <= 0) return 0;
+  if (D < 1 || D > 8) return 1;
+  DISPATCH_I(hipLaunchKernelGGL(barnes_edge_forces_kernel<I>, dim3(grid_for(N, 256)), dim3(256), 0, st, (const I*)rowP, (const I*)colP,
+                                val, y, out, N, D, nnz);)
   DL4J_RET_LAST();
 }

@@ -642,3 +642,23 @@ def _reg_space_batch(name, to_batch):
 
 for _name, _tb in (("space_to_batch", True), ("space_to_batch_nd", True), ("batch_to_space", False), ("batch_to_space_nd", False)):
     _reg_space_batch(_name, _tb)
+
+
+def _sru_bi_ok(ins, i, t, b, d):
+    if len(ins) < 4 or not all(isinstance(v, torch.Tensor) and L.use_hip(v) and v.dtype == torch.float32 for v in ins[:4]) or len(ins) > 4:
+        return False
+    x, w, bias, c0 = ins[:4]
+    return (x.dim() == 3 and x.shape[2] % 2 == 0 and tuple(w.shape) == (x.shape[2], 3 * x.shape[2]) and bias.numel() == 2 * x.shape[2]
+            and tuple(c0.shape) == (x.shape[1], x.shape[2]))
+
+
+@platform("sru_bi", _sru_bi_ok)
+def _sru_bi(ins, i, t, b, d):
+    return H.sru_bi_fwd(ins[0], ins[1], ins[2].reshape(-1), ins[3])
+
+
+@platform("barnes_edge_forces", lambda ins, i, t, b, d: len(ins) >= 4 and _idx(ins[0]) and _idx(ins[1]) and ins[0].dtype == ins[1].dtype
+          and L.use_hip(ins[3]) and ins[3].dim() == 2 and 1 <= ins[3].shape[1] <= 8 and ins[3].dtype == torch.float32
+          and ins[2].is_cuda and (not i or int(i[0]) == ins[3].shape[0]) and ins[0].numel() >= ins[3].shape[0] + 1)
+def _barnes_edge_forces(ins, i, t, b, d):
+    return H.barnes_edge_forces(ins[0], ins[1], ins[2], ins[3])

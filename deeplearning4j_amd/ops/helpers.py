@@ -526,17 +526,57 @@ def lrn_bwd_last(x, g, depth, bias, alpha, beta):
     return dx
 
 
+def sru_recurrence(xm, z, bias, c0):
+    """The elementwise SRU recurrence given the projections: xm [B, K, T], z [B, 3K, T] fp32 contiguous, bias [2K], c0 [B, K] -> (h, c)."""
+    B, K, T = xm.shape
+    assert tuple(z.shape) == (B, 3 * K, T) and xm.is_contiguous() and z.is_contiguous() and xm.dtype == z.dtype == torch.float32
+    h = torch.empty_like(xm)
+    cs = torch.empty_like(xm)
+    L.check(L.hip().dl4j_sru_fwd(L.ptr(xm), L.ptr(z), L.ptr(_f32(bias)), L.ptr(c0.float().contiguous()), L.ptr(h), L.ptr(cs), L.c_int(B),
+                                 L.c_int(K), L.c_int(T), L.stream()), "sru_fwd")
+    return h, cs
+
+
 def sru_fwd(x, w, bias, c0, mask=None):
     """x [B, K, T] fp32, w [3K, K], bias [2K], c0 [B, K] -> (h, c) [B, K, T]; the projection is a library GEMM, the recurrence one kernel."""
     B, K, T = x.shape
     assert w.shape == (3 * K, K) and bias.numel() == 2 * K and c0.shape == (B, K)
     xm = (x * mask.unsqueeze(-1) if mask is not None else x).float().contiguous()
     z = torch.matmul(w.float(), xm).contiguous()                      # [B, 3K, T]
-    h = torch.empty_like(xm)
-    cs = torch.empty_like(xm)
-    L.check(L.hip().dl4j_sru_fwd(L.ptr(xm), L.ptr(z), L.ptr(_f32(bias)), L.ptr(c0.float().contiguous()), L.ptr(h), L.ptr(cs), L.c_int(B),
-                                 L.c_int(K), L.c_int(T), L.stream()), "sru_fwd")
+    h, cs = sru_recurrence(xm, z, bias, c0)
     return h, cs, z, xm
+
+
+def sru_bi_fwd(x, w, bias, c0):
+    """Bidirectional SRU: x [T, B, 2K], w [2K, 6K], bias [4K], c0 [B, 2K] -> (h, c) [T, B, 2K]; the backward direction runs the
+    same recurrence kernel on the time-reversed sequence."""
+    T, B, K2 = x.shape
+    K = K2 // 2
+    z = torch.matmul(x.float(), w.float()).reshape(T, B, 2, 3 * K)
+    hs, cs = [], []
+    for dirn in range(2):
+        zd = z[:, :, dirn].permute(1, 2, 0)                           # [B, 3K, T]
+        xd = x[:, :, dirn * K:(dirn + 1) * K].float().permute(1, 2, 0)
+        if dirn == 1:
+            zd, xd = zd.flip(-1), xd.flip(-1)
+        h, c = sru_recurrence(xd.contiguous(), zd.contiguous(), bias[dirn * 2 * K:(dirn + 1) * 2 * K], c0[:, dirn * K:(dirn + 1) * K])
+        if dirn == 1:
+            h, c = h.flip(-1), c.flip(-1)
+        hs.append(h.permute(2, 0, 1))
+        cs.append(c.permute(2, 0, 1))
+    return torch.cat(hs, -1).contiguous(), torch.cat(cs, -1).contiguous()
+
+
+def barnes_edge_forces(rowP, colP, val, y):
+    """Attractive forces of Barnes-Hut t-SNE over a CSR neighbour graph; y [N, D] (D <= 8) fp32."""
+    N, D = y.shape
+    assert 1 <= D <= 8 and rowP.numel() >= N + 1 and rowP.dtype == colP.dtype and _idx_ok(rowP) and _idx_ok(colP)
+    yc, vc = y.float().contiguous(), val.float().contiguous()
+    out = torch.empty_like(yc)
+    L.check(L.hip().dl4j_barnes_edge_forces(L.ptr(rowP), L.ptr(colP), L.ptr(vc), L.ptr(yc), L.ptr(out), L.c_int(N), L.c_int(D),
+                                            L.c_int64(min(colP.numel(), vc.numel())), L.c_int(1 if rowP.dtype == torch.int64 else 0),
+                                            L.stream()), "barnes_edge_forces")
+    return out.to(y.dtype)
 
 
 def sru_bwd(x, w, bias, c0, gh, gc_last=None, mask=None):

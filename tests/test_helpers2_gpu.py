@@ -281,3 +281,19 @@ def test_layer_norm_differentiable_platform_helper_under_autograd():
         outs.append([y.detach().cpu()] + [l.grad.cpu() for l in leaves])
     for a, b in zip(*outs):
         assert torch.allclose(a, b, atol=2e-4, rtol=1e-4), float((a - b).abs().max())
+
+
+def test_sru_bi_and_barnes_edge_forces():
+    torch.manual_seed(17)
+    T, B, K = 9, 5, 12
+    x, w = torch.randn(T, B, 2 * K), torch.randn(2 * K, 6 * K) * 0.3
+    bias, c0 = torch.randn(4 * K) * 0.3, torch.randn(B, 2 * K)
+    _platform_vs_generic("sru_bi", [x, w, bias, c0], atol=3e-5)
+    N, D = 40, 2
+    deg = torch.randint(1, 6, (N,))
+    rowP = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(deg, 0)])
+    colP = torch.randint(0, N, (int(rowP[-1]),))
+    val = torch.rand(int(rowP[-1]))
+    y = torch.randn(N, D)
+    _platform_vs_generic("barnes_edge_forces", [rowP, colP, val, y], [N], atol=1e-5)
+    _platform_vs_generic("barnes_edge_forces", [rowP.int(), colP.int(), val, torch.randn(N, 3)], [N], atol=1e-5)
