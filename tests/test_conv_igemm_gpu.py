@@ -115,3 +115,16 @@ def test_cast_table_lds_staged_permutes_at_network_sizes(O, I, K):
     assert torch.equal(dst[3:3 + n].view(O, K, I), w.permute(0, 2, 1).contiguous().bfloat16())
     assert torch.equal(dst[3 + n + 5:].view(I, K, O), torch.flip(w, dims=[2]).permute(1, 2, 0).contiguous().bfloat16())
     assert float(dst[:3].abs().sum()) == 0 and float(dst[3 + n:3 + n + 5].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 192, 320), (4096, 768, 768)])
+def test_hand_written_gemm_nt_matches_fp32(M, N, K):
+    from deeplearning4j_amd.ops import gemm as G
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = torch.randn(N, K, device="cuda").bfloat16()
+    b = torch.randn(N, device="cuda")
+    ref = x.float() @ w.float().t() + b
+    got = G.gemm_nt(x, w, b).float()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 2e-2 * float(ref.abs().max())
