@@ -502,7 +502,13 @@ def _confusion(ins, i, t, b, d):
     return torch.bincount(lab * n + pred, weights=w, minlength=n * n).reshape(n, n).to(dt)
 
 
-op("expose")(lambda ins, i, t, b, d: tuple(x for x in ins))
+op("expose", "Expose")(lambda ins, i, t, b, d: tuple(x for x in ins))
+# Eager forms of the dataflow control ops (generic/flow/flow_control_ops.cpp). Inside a graph they are interpreted by the frame
+# executors (autodiff/samediff.py _run_graph, native rt_graph.cpp); executed on their own they are the value-passing identities.
+op("Merge")(lambda ins, i, t, b, d: next(x for x in ins if x is not None))
+op("LoopCond")(lambda ins, i, t, b, d: ins[0])
+op("NextIteration")(lambda ins, i, t, b, d: ins[0])
+op("Exit")(lambda ins, i, t, b, d: ins[0])
 
 
 def _fake_quant(x, mn, mx, num_bits, narrow):
