@@ -651,3 +651,72 @@ class KerasModelImport:
                 w["kernel"] = _permute_dense_after_flatten(w["kernel"], pre_flat)
             _set_params(net, vname, m.weights(w, None))
         return net
+
+
+class KerasModel:
+    """Functional-API Keras model (reference: modelimport/keras/KerasModel.java): parsed configuration + weights, materialised as a
+    ComputationGraph. ``KerasModel.builder().modelJsonFilename(..).weightsHdf5Filename(..).enforceTrainingConfig(..).buildModel()``."""
+    SEQUENTIAL = False
+
+    def __init__(self, modelJson=None, weights=None, enforceTrainingConfig=False, loss=None):
+        self.modelJson, self.weights = modelJson, weights
+        self.enforceTrainingConfig, self.loss = enforceTrainingConfig, loss
+        self._config = KerasModelImport._read_config(modelJson) if modelJson is not None else None
+
+    class Builder:
+        def __init__(self, cls):
+            self._cls, self._kw = cls, {}
+
+        def modelJson(self, s):
+            self._kw["modelJson"] = s
+            return self
+
+        modelJsonFilename = modelJson
+        modelHdf5Filename = modelJson
+
+        def weightsHdf5Filename(self, p):
+            self._kw["weights"] = p
+            return self
+
+        weightsHdf5FilenameNoRoot = weightsHdf5Filename
+
+        def enforceTrainingConfig(self, b):
+            self._kw["enforceTrainingConfig"] = bool(b)
+            return self
+
+        def buildModel(self):
+            return KerasModel(**self._kw)
+
+        def buildSequential(self):
+            return KerasSequentialModel(**self._kw)
+
+    @classmethod
+    def builder(cls):
+        return KerasModel.Builder(cls)
+
+    def getClassName(self):
+        return (self._config or {}).get("class_name")
+
+    def getLayerNames(self):
+        cfg = (self._config or {}).get("config", {})
+        layers = cfg.get("layers", cfg) if isinstance(cfg, dict) else cfg
+        return [l.get("config", {}).get("name") or l.get("name") for l in layers]
+
+    def getComputationGraphConfiguration(self):
+        return KerasModelImport.importKerasModelConfiguration(self._config, self.enforceTrainingConfig, self.loss)
+
+    def getComputationGraph(self, importWeights=True, device=None):
+        return KerasModelImport.importKerasModelAndWeights(self._config, self.weights if importWeights else None,
+                                                           self.enforceTrainingConfig, self.loss, device=device)
+
+
+class KerasSequentialModel(KerasModel):
+    """Sequential Keras model -> MultiLayerNetwork (modelimport/keras/KerasSequentialModel.java)."""
+    SEQUENTIAL = True
+
+    def getMultiLayerConfiguration(self):
+        return KerasModelImport.importKerasSequentialConfiguration(self._config, self.enforceTrainingConfig, self.loss)
+
+    def getMultiLayerNetwork(self, importWeights=True, device=None):
+        return KerasModelImport.importKerasSequentialModelAndWeights(self._config, self.weights if importWeights else None,
+                                                                     self.enforceTrainingConfig, self.loss, device=device)

@@ -162,3 +162,15 @@ def memory_report_graph(conf, *inputTypes):
     return NetworkMemoryReport(reps, "ComputationGraph", "ComputationGraph", its,
                                str(conf.dataType),
                                conf.computeDataType)
+
+
+class MemoryReport:
+    """Common base name of the reports (nn/conf/memory/MemoryReport.java): static helpers shared by LayerMemoryReport / NetworkMemoryReport."""
+
+    @staticmethod
+    def fromLayer(conf, inputType=None):
+        return conf if isinstance(conf, LayerMemoryReport) else conf.getMemoryReport(inputType)
+
+    @staticmethod
+    def isReport(obj):
+        return isinstance(obj, (LayerMemoryReport, NetworkMemoryReport))

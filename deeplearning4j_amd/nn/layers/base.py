@@ -102,6 +102,11 @@ class LayerImpl:
     def setMaskArray(self, m):
         self.maskArray = m
 
+    def getHelper(self):
+        """The GPU helper object of this layer (reference: Layer.getHelper(); None when the layer has no HIP fast path here)."""
+        from .helpers import helper_for
+        return helper_for(self)
+
     def feedForwardMaskArray(self, mask, minibatch=None):
         self.maskArray = mask
         return mask

@@ -323,3 +323,9 @@ class InplaceParallelInference(ParallelInference):
 
     def __init__(self, model, workers=None, devices=None, **kw):
         super().__init__(model, workers=workers, inferenceMode=InferenceMode.INPLACE, devices=devices, **kw)
+
+
+# reference class names (parallelism/inference/observers/{BasicInferenceObservable,BatchedInferenceObservable}.java, InferenceWorker)
+InferenceWorker = _Worker
+BasicInferenceObservable = _Observable
+BatchedInferenceObservable = _Observable

@@ -1,0 +1,87 @@
+"""Reference-named API objects: Solver / StochasticGradientDescent, MultiLayerUpdater / UpdaterBlock, ParamInitializers, LayerHelper
+SPI, KerasModel / KerasSequentialModel."""
+import json
+
+import torch
+
+from deeplearning4j_amd.nd4j.learning import Adam, Sgd
+from deeplearning4j_amd.nn.conf.base import InputType
+from deeplearning4j_amd.nn.conf.configuration import NeuralNetConfiguration
+from deeplearning4j_amd.nn.conf.layers import DenseLayer, OutputLayer, BatchNormalization, ConvolutionLayer, LSTM, GravesLSTM
+from deeplearning4j_amd.nn.multilayer import MultiLayerNetwork
+
+
+def _net(updater):
+    conf = (NeuralNetConfiguration.Builder().seed(5).updater(updater).weightInit("XAVIER").list()
+            .layer(DenseLayer(nIn=4, nOut=8, activation="TANH", updater=Sgd(0.05)))
+            .layer(DenseLayer(nIn=8, nOut=8, activation="RELU"))
+            .layer(OutputLayer(nIn=8, nOut=3, activation="SOFTMAX", lossFunction="MCXENT")).build())
+    return MultiLayerNetwork(conf, device="cpu").init()
+
+
+def test_solver_matches_fit_and_updater_blocks():
+    from deeplearning4j_amd.optimize.solvers import Solver, StochasticGradientDescent
+    from deeplearning4j_amd.nn.updater import MultiLayerUpdater, UpdaterCreator
+    torch.manual_seed(0)
+    x, y = torch.randn(16, 4), torch.eye(3)[torch.randint(0, 3, (16,))]
+    a, b = _net(Adam(0.01)), _net(Adam(0.01))
+    solver = Solver.Builder().configure(b.conf).model(b).build()
+    assert isinstance(solver.getOptimizer(), StochasticGradientDescent)
+    for _ in range(5):
+        a.fit(x, y)
+        solver.optimize(x, y)
+    assert torch.allclose(a.params(), b.params(), atol=1e-6) and a.getIterationCount() == b.getIterationCount() == 5
+    assert abs(solver.getOptimizer().score() - float(b.score())) < 1e-9
+    up = UpdaterCreator.getUpdater(a)
+    assert isinstance(up, MultiLayerUpdater)
+    blocks = up.getUpdaterBlocks()
+    # layer 0 has its own Sgd -> its own block; the two Adam layers share one contiguous block (UpdaterBlock.java semantics)
+    assert len(blocks) == 2 and blocks[0].paramOffsetStart == 0 and blocks[0].paramOffsetEnd == 4 * 8 + 8
+    assert blocks[1].paramOffsetEnd == a.numParams() and type(blocks[1].gradientUpdater).__name__ == "Adam"
+    assert blocks[0].getUpdaterView().numel() == 0 and blocks[1].getUpdaterView().numel() == 2 * (blocks[1].paramOffsetEnd - blocks[1].paramOffsetStart)
+    st = up.getStateViewArray().clone()
+    up.setStateViewArray(st * 0)
+    assert float(a.getUpdaterState().abs().sum()) == 0.0
+    # MultiLayerUpdater.update == the update fit applies
+    c, d = _net(Adam(0.01)), _net(Adam(0.01))
+    c.fit(x, y)
+    d.computeGradientAndScore(x, y)
+    MultiLayerUpdater(d).update(None, 0, 0, 16)
+    assert torch.allclose(c.params(), d.params(), atol=1e-6)
+
+
+def test_param_initializers_layouts():
+    from deeplearning4j_amd.nn import params as P
+    d = DenseLayer(nIn=5, nOut=7)
+    pi = P.initializer_for(d)
+    assert isinstance(pi, P.DefaultParamInitializer) and pi.numParams(d) == 5 * 7 + 7 and pi.paramKeys(d) == ["W", "b"]
+    assert pi.weightKeys(d) == ["W"] and pi.biasKeys(d) == ["b"] and pi.isBiasParam(d, "b")
+    flat = torch.arange(42.0)
+    views = pi.init(d, flat)
+    assert tuple(views["W"].shape) == (5, 7) and float(views["W"][1, 0]) == 1.0 and float(views["W"][0, 1]) == 5.0     # 'f' order block
+    assert tuple(views["b"].shape) == (1, 7) and float(views["b"][0, 0]) == 35.0
+    views["W"][2, 3] = -1.0
+    assert float(flat[3 * 5 + 2]) == -1.0                                                                               # views, not copies
+    bn = BatchNormalization(nIn=6, nOut=6)
+    assert P.initializer_for(bn).paramKeys(bn)[:2] == ["gamma", "beta"] and P.initializer_for(bn).numParams(bn) == 24
+    l, g = LSTM(nIn=3, nOut=4), GravesLSTM(nIn=3, nOut=4)
+    assert P.initializer_for(l).paramShapes(l) == {"W": (3, 16), "RW": (4, 16), "b": (1, 16)}
+    assert P.initializer_for(g).paramShapes(g)["RW"] == (4, 19) and isinstance(P.initializer_for(g), P.GravesLSTMParamInitializer)
+    cv = ConvolutionLayer(nIn=2, nOut=3, kernelSize=(3, 3))
+    assert isinstance(P.initializer_for(cv), P.ConvolutionParamInitializer) and P.initializer_for(cv).numParams(cv) == 3 * 2 * 9 + 3
+
+
+def test_layer_helper_spi_and_keras_model_classes():
+    from deeplearning4j_amd.nn.layers.helpers import HelperUtils, ConvolutionHelper, helper_for
+    assert HelperUtils.createHelper("org.deeplearning4j.cuda.convolution.CudnnConvolutionHelper", "", ConvolutionHelper, "conv", device="cpu") is None
+    assert ConvolutionHelper("cpu").checkSupported() is False and "igemm_fwd_kernel" in ConvolutionHelper.KERNELS
+    net = _net(Sgd(0.1))
+    assert helper_for(net.layers[0]) is None
+    from deeplearning4j_amd.modelimport import KerasModel, KerasSequentialModel
+    cfg = {"class_name": "Sequential", "config": {"name": "s", "layers": [
+        {"class_name": "Dense", "config": {"name": "d1", "units": 6, "activation": "relu", "use_bias": True, "batch_input_shape": [None, 4]}},
+        {"class_name": "Dense", "config": {"name": "d2", "units": 3, "activation": "softmax", "use_bias": True}}]}}
+    km = KerasModel.builder().modelJson(json.dumps(cfg)).enforceTrainingConfig(False).buildSequential()
+    assert isinstance(km, KerasSequentialModel) and km.getClassName() == "Sequential" and km.getLayerNames() == ["d1", "d2"]
+    mln = km.getMultiLayerNetwork(importWeights=False, device="cpu")
+    assert tuple(mln.output(torch.randn(2, 4)).shape) == (2, 3)
