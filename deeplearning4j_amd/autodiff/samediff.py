@@ -422,6 +422,9 @@ class SameDiff:
     def _op(self, opName, inputs, iArgs=None, tArgs=None, bArgs=None, dArgs=None, nOut=1, name=None, opType=OpType.CUSTOM, opNum=None,
             dimensions=None, scalar=None, outNames=None):
         ins = [v if isinstance(v, SDVariable) else self.constant(None, v) for v in inputs]
+        icpt = getattr(self, "_arg_interceptor", None)
+        if icpt is not None:
+            ins = [icpt(v) for v in ins]
         oname = self._unique(name or opName)
         outs = outNames or ([oname] if nOut == 1 else [oname if k == 0 else "%s:%d" % (oname, k) for k in range(nOut)])
         o = SameDiffOp(oname, opName, [v.name for v in ins], outs, iArgs, tArgs, bArgs, dArgs, opType, opNum, dimensions, scalar)
@@ -1247,17 +1250,70 @@ class SameDiff:
     fromFlatFile = load
 
     # ------------------------------------------------------------------ control-flow builders (ControlFlow.java)
+    def addArgumentInterceptor(self, interceptor):
+        """Every SDVariable argument of ops created while the interceptor is installed passes through it (reference:
+        SameDiff.addArgumentInterceptor / ArgumentInterceptor.java). Interceptors nest; the newest runs first."""
+        prev = getattr(self, "_arg_interceptor", None)
+        self._icpt_stack = getattr(self, "_icpt_stack", []) + [prev]
+        self._arg_interceptor = (lambda v: prev(interceptor(v))) if prev is not None else interceptor
+
+    def removeArgumentInterceptor(self):
+        self._arg_interceptor = self._icpt_stack.pop() if getattr(self, "_icpt_stack", None) else None
+
+    def _paused_interceptor(self):
+        sd = self
+
+        class _P:
+            def __enter__(self_):
+                self_.saved = getattr(sd, "_arg_interceptor", None)
+                sd._arg_interceptor = None
+
+            def __exit__(self_, *exc):
+                sd._arg_interceptor = self_.saved
+                return False
+        return _P()
+
     def ifCond(self, cond: Callable, trueBody: Callable, falseBody: Callable, name=None):
-        """Builds Switch/Merge: both bodies are traced into the graph, only the live one executes."""
+        """Builds Switch/Merge: both bodies are traced into the graph, only the live one executes. Values from outside a
+        body are routed through a Switch on the predicate (an argument interceptor does this while the body is traced, as
+        the reference's ifCond does), so a body is gated even when it ignores its Switch-output argument."""
         name = self._unique(name or "cond")
         pred = cond(self)
         sw_f, sw_t = self._op("switch", [pred, pred], nOut=2, name=name + "/switch", opType=OpType.LOGIC, opNum=LOGIC_NUM["switch"])
+
+        def gate(branch, own):
+            outside, cache = set(self.variables), {}
+
+            def icpt(v):
+                if v.name not in outside or v.name == own:
+                    return v
+                if v.name not in cache:
+                    with self._paused_interceptor():
+                        cache[v.name] = self._op("switch", [v, pred], nOut=2, name="sw_" + v.name.replace("/", "_").replace(":", "_"),
+                                                 opType=OpType.LOGIC, opNum=LOGIC_NUM["switch"])[branch]
+                return cache[v.name]
+            return icpt
+
         with self.withNameScope(name + "/true"):
             t_in = self._op("identity", [sw_t])[0]
-            tv = trueBody(self, t_in)
+            self.addArgumentInterceptor(gate(1, t_in.name))
+            try:
+                before = set(self.variables)
+                tv = trueBody(self, t_in)
+                if tv.name in before:
+                    tv = self._op("identity", [tv])[0]          # a body returning an outer value as-is still gets gated
+            finally:
+                self.removeArgumentInterceptor()
         with self.withNameScope(name + "/false"):
             f_in = self._op("identity", [sw_f])[0]
-            fv = falseBody(self, f_in)
+            self.addArgumentInterceptor(gate(0, f_in.name))
+            try:
+                before = set(self.variables)
+                fv = falseBody(self, f_in)
+                if fv.name in before:
+                    fv = self._op("identity", [fv])[0]
+            finally:
+                self.removeArgumentInterceptor()
         return self._op("merge", [fv, tv], name=name + "/merge", opType=OpType.LOGIC, opNum=LOGIC_NUM["merge"])[0]
 
     def whileLoop(self, loopVars: Sequence[SDVariable], cond: Callable, body: Callable, name=None) -> List[SDVariable]:

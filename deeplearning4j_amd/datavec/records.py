@@ -385,6 +385,10 @@ class SVMLightRecordReader(LineRecordReader):
 LibSvmRecordReader = SVMLightRecordReader
 
 
+class LibSvmRecordReader(SVMLightRecordReader):
+    """LibSVM files share the SVMLight line format (reference: datavec-api records/reader/impl/misc/LibSvmRecordReader.java)."""
+
+
 class JacksonLineRecordReader(LineRecordReader):
     """One JSON object per line; ``fieldSelection`` = list of dotted paths (with optional default values)."""
 
