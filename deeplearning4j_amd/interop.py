@@ -6,6 +6,7 @@ MI355X design: a foreign graph is not handed to a second runtime (which would ru
 build); it is imported into SameDiff and executed by THIS framework's kernels, so ONNX / TensorFlow models get the
 same device residency, HIP-graph-friendly execution and op coverage as native models. If the foreign runtime happens
 to be importable (onnxruntime is not in this image) ``useForeignRuntime=True`` can select it for cross-checking.
+TensorFlow Lite files are decoded and executed operator by operator on device tensors (tflite.py).
 """
 from __future__ import annotations
 
@@ -134,12 +135,7 @@ class GraphRunner(_ImportedGraphRunner):
         super().__init__(TFGraphMapper.importGraph(graph, device=device), inputNames, outputNames)
 
 
-class TensorFlowLiteRunner:
-    """nd4j-tensorflow-lite runner. The .tflite FlatBuffer schema importer is not part of this round; a converter-side
-    export to a frozen GraphDef or ONNX runs through GraphRunner / OnnxRuntimeRunner."""
-
-    def __init__(self, modelUri):
-        raise NotImplementedError("TensorFlow Lite models: convert to ONNX or a frozen GraphDef and use OnnxRuntimeRunner / GraphRunner")
+from .tflite import TensorFlowLiteRunner  # noqa: E402,F401  (.tflite FlatBuffers decoded and executed on device tensors)
 
 
 class TvmRunner:
