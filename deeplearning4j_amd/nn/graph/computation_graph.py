@@ -437,6 +437,11 @@ class ComputationGraph(BaseNetwork):
         self._plan = self._build_plan()
 
     def _backward(self, mb):
+        from ...ops import streams
+        with streams.backward_scope():          # conv wgrads run on a side stream, joined when the scope closes
+            return self._backward_impl(mb)
+
+    def _backward_impl(self, mb):
         eps: Dict[str, torch.Tensor] = {}
         net_in = set(self.conf.networkInputs)
         prog = self._on_backward_progress

@@ -109,6 +109,8 @@ class CapturedTrainStep:
             # the head bucket is never worth a cut: nothing is left to overlap it with (finish() launches it)
             nb = min(buckets.count_ready(min_done_offset), len(buckets.ranges) - 1) - state["launched"]
             if nb > 0:
+                from ..ops import streams
+                streams.join()                  # side-stream wgrads belong to this segment: join before the cut
                 state["g"].capture_end()
                 segs.append((state["g"], nb))
                 state["launched"] += nb

@@ -249,6 +249,11 @@ class MultiLayerNetwork(BaseNetwork):
 
     # ------------------------------------------------------------------ backward
     def _backward(self, mb):
+        from ..ops import streams
+        with streams.backward_scope():          # conv wgrads run on a side stream, joined when the scope closes
+            return self._backward_impl(mb)
+
+    def _backward_impl(self, mb):
         pre = self.conf.inputPreProcessors
         eps = None
         steps = list(self._plan)

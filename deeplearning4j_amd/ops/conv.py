@@ -67,7 +67,14 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
         if need_db:
             db = dz.float().sum((0, 2, 3))
         if need_dw:
-            dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
+            from . import streams
+            if (streams.active() and dw_out is not None and dw_out.dtype == torch.float32 and dw_out.is_contiguous()
+                    and dz.is_contiguous(memory_format=torch.channels_last)):
+                # dW goes straight into the flat gradient view and is not read before the updater: side stream
+                with torch.cuda.stream(streams.fork(dz, x, dw_out)):
+                    IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
+            else:
+                dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
         if need_dx:
             if w_dgrad is not None and IG.dgrad_supported(w, stride, padding):
                 acc = dx_accum if IG.accum_ok(dx_accum, x.shape) else None

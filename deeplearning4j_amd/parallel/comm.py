@@ -138,6 +138,9 @@ class GradientBuckets:
     def ready(self, min_done_offset: int):
         """Launch every not-yet-launched bucket whose range is complete."""
         while self._next >= 0 and self.ranges[self._next][0] >= min_done_offset:
+            if self.flat.is_cuda:
+                from ..ops import streams
+                streams.join()                  # wgrads issued on the side stream are part of this bucket
             self._launch(self._next)
             self._next -= 1
 
