@@ -56,6 +56,13 @@ class ParallelWrapper:
         def gradientsAccumulator(self, a):
             self._kw["gradientsAccumulator"] = a; return self
 
+        def modelParamsSupplier(self, supplier):
+            """Callable returning the flat parameter vector every replica starts from (upstream ModelParamsSupplier)."""
+            self._kw["modelParamsSupplier"] = supplier; return self
+
+        def updaterParamsSupplier(self, supplier):
+            self._kw["updaterParamsSupplier"] = supplier; return self
+
         def bucketBytes(self, n):
             self._kw["bucketBytes"] = n; return self
 
@@ -67,7 +74,8 @@ class ParallelWrapper:
 
     def __init__(self, model, workers=None, prefetchBuffer=2, averagingFrequency=1, reportScoreAfterAveraging=True,
                  averageUpdaters=True, trainingMode=TrainingMode.SHARED_GRADIENTS, thresholdAlgorithm=None,
-                 residualPostProcessor=None, gradientsAccumulator=None, bucketBytes=32 << 20, overlap=True):
+                 residualPostProcessor=None, gradientsAccumulator=None, bucketBytes=32 << 20, overlap=True,
+                 modelParamsSupplier=None, updaterParamsSupplier=None):
         self.model = model
         self.averagingFrequency = max(1, int(averagingFrequency))
         self.averageUpdaters = averageUpdaters
@@ -83,6 +91,15 @@ class ParallelWrapper:
             print("ParallelWrapper: workers(%d) ignored, world size is %d (one process per GPU)" % (workers, self.world))
         if not model._initialized:
             model.init()
+        for supplier, target in ((modelParamsSupplier, "_params"), (updaterParamsSupplier, "_updater_state")):
+            if supplier is not None:
+                v = supplier() if callable(supplier) else supplier
+                if v is not None:
+                    v = getattr(v, "_t", v)
+                    dst = getattr(model, target)
+                    if v.numel() != dst.numel():
+                        raise ValueError("%s supplier returned %d values, the model has %d" % (target, v.numel(), dst.numel()))
+                    dst.copy_(torch.as_tensor(v).reshape(dst.shape).to(dst.device, dst.dtype))
         # replicas start identical: broadcast params + updater state from rank 0
         comm.broadcast_(model._params, 0)
         comm.broadcast_(model._updater_state, 0)

@@ -119,3 +119,57 @@ def test_gradient_buckets_cover_and_order():
     assert launched == [3, 2]
     gb.ready(0)
     assert launched == [3, 2, 1, 0]
+
+
+def _tm_worker(rank, world, port, kind, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(1)
+    from deeplearning4j_amd.parallel import comm
+    from deeplearning4j_amd.parallel.training_master import (ParameterAveragingTrainingMaster, SharedTrainingMaster,
+                                                             SparkDl4jMultiLayer)
+    from deeplearning4j_amd.nd4j.compression import AdaptiveThresholdAlgorithm
+    from deeplearning4j_amd.datasets.dataset import DataSet
+    comm.init_process_group("gloo")
+    if kind == "shared":
+        tm = (SharedTrainingMaster.Builder(AdaptiveThresholdAlgorithm(1e-3), 1).batchSizePerWorker(4).workersPerNode(world)
+              .collectTrainingStats(True).build())
+    else:
+        tm = ParameterAveragingTrainingMaster.Builder(1).averagingFrequency(2).batchSizePerWorker(4).saveUpdater(True).build()
+    net = _build(seed=7 + rank)
+    spark = SparkDl4jMultiLayer(None, net, tm)
+    rdd = [DataSet(*_data(s)) for s in range(8)]                 # the "RDD": ranks take batches rank, rank+world, ...
+    spark.fit(rdd, 1)
+    assert spark._wrapper.params_in_sync()
+    if kind == "shared":
+        assert tm.getTrainingStats() and tm.getTrainingStats()[0]["epochs"] == 1
+    torch.save({"params": net.params().clone()}, os.path.join(out_dir, "r%d.pt" % rank))
+    spark.close()
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["shared", "averaging"])
+def test_training_master_facades_gloo(tmp_path, kind):
+    world, port = 2, _free_port()
+    mp.spawn(_tm_worker, args=(world, port, kind, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
+    assert torch.equal(r0["params"], r1["params"])
+    assert not torch.equal(r0["params"], _build(seed=7).params())          # training happened
+
+
+def test_training_master_builders_and_param_suppliers():
+    from deeplearning4j_amd.parallel.parallel_wrapper import ParallelWrapper, TrainingMode
+    from deeplearning4j_amd.parallel.training_master import ParameterAveragingTrainingMaster, SharedTrainingMaster
+    tm = SharedTrainingMaster.Builder(1).batchSizePerWorker(32).workersPerNode(8).rddTrainingApproach("Export").build()
+    assert tm.trainingMode == TrainingMode.SHARED_GRADIENTS and tm.batchSizePerWorker == 32 and tm.workersPerNode == 8
+    pa = ParameterAveragingTrainingMaster.Builder(1).averagingFrequency(5).aggregationDepth(2).build()
+    assert pa.trainingMode == TrainingMode.AVERAGING and pa.averagingFrequency == 5
+    net = _build(seed=3)
+    src = _build(seed=11)
+    ParallelWrapper.Builder(net).modelParamsSupplier(lambda: src.params()).build().shutdown()
+    assert torch.equal(net.params(), src.params())
+    with pytest.raises(ValueError, match="supplier"):
+        ParallelWrapper.Builder(net).modelParamsSupplier(lambda: torch.zeros(3)).build()
