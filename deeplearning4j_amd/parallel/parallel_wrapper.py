@@ -8,7 +8,8 @@ One process per GPU (launched by torchrun / torch.distributed.run). ``trainingMo
   gradient vector (BatchNormalization.java:170-186,321-353) and are averaged for free.
 * AVERAGING: each rank trains ``averagingFrequency`` iterations locally, then parameters (and
   updater state if ``averageUpdaters``) are all-reduced — upstream's periodic parameter averaging.
-Threshold-encoding knobs are accepted for source compatibility; on xGMI dense all-reduce wins.
+Threshold-encoding knobs are accepted for source compatibility; on xGMI the dense all-reduce wins, so they only take
+effect with ``compatEncoding(True)`` (sparse ±threshold messages with residuals, all-gathered and decoded by every rank).
 """
 from __future__ import annotations
 
@@ -63,6 +64,12 @@ class ParallelWrapper:
         def updaterParamsSupplier(self, supplier):
             self._kw["updaterParamsSupplier"] = supplier; return self
 
+        def compatEncoding(self, b=True):
+            """Exchange threshold-encoded sparse updates with residuals (upstream SHARED_GRADIENTS wire behaviour) instead
+            of the dense all-reduce. Uses ``gradientsAccumulator`` or builds an EncodedGradientsAccumulator from
+            ``thresholdAlgorithm`` / ``residualPostProcessor``."""
+            self._kw["compatEncoding"] = bool(b); return self
+
         def bucketBytes(self, n):
             self._kw["bucketBytes"] = n; return self
 
@@ -75,7 +82,7 @@ class ParallelWrapper:
     def __init__(self, model, workers=None, prefetchBuffer=2, averagingFrequency=1, reportScoreAfterAveraging=True,
                  averageUpdaters=True, trainingMode=TrainingMode.SHARED_GRADIENTS, thresholdAlgorithm=None,
                  residualPostProcessor=None, gradientsAccumulator=None, bucketBytes=32 << 20, overlap=True,
-                 modelParamsSupplier=None, updaterParamsSupplier=None):
+                 modelParamsSupplier=None, updaterParamsSupplier=None, compatEncoding=False):
         self.model = model
         self.averagingFrequency = max(1, int(averagingFrequency))
         self.averageUpdaters = averageUpdaters
@@ -106,15 +113,25 @@ class ParallelWrapper:
         model._refresh_replicas()
         self.buckets = comm.GradientBuckets(model._grads, bucketBytes)
         self._local_iters = 0
+        self.accumulator = None
+        if compatEncoding or gradientsAccumulator is not None:
+            from ..nd4j.compression import EncodedGradientsAccumulator
+            self.accumulator = gradientsAccumulator or EncodedGradientsAccumulator(thresholdAlgorithm, residualPostProcessor)
         if trainingMode == TrainingMode.SHARED_GRADIENTS:
             model._grad_sync = self._sync_gradients
-            if overlap and (self.world > 1 or comm._forced()):
+            # encoded exchange: variable-length messages whose sizes are read on the host, so no bucket overlap; with HIP-graph
+            # training it runs eagerly between the captured forward/backward graph and the captured update graph
+            if self.accumulator is None and overlap and (self.world > 1 or comm._forced()):
                 model._on_backward_progress = self.buckets.ready
                 model._on_backward_begin = self.buckets.begin
                 model._dp_buckets = self.buckets      # lets the HIP-graph step cut its capture at bucket boundaries
 
     # gradient sharing
     def _sync_gradients(self):
+        if self.accumulator is not None:
+            g = self.model._grads
+            self.accumulator.applyUpdate(self.accumulator.storeUpdate(g), g)
+            return
         if self.world == 1 and not comm._forced():
             return
         if (self.overlap and getattr(self.model, "_on_backward_progress", None) is not None
