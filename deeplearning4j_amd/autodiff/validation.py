@@ -79,13 +79,72 @@ class TestCase:
         return self
 
 
+class OpTestCase:
+    """Single-op test: a DynamicCustomOp plus expected output arrays (values or a predicate) and, optionally, the expected
+    output shapes — checked against ``calculateOutputShape`` before execution (reference:
+    org/nd4j/autodiff/validation/OpTestCase.java)."""
+
+    def __init__(self, op):
+        self.op = op
+        self.expected: Dict[int, object] = {}
+        self.expShapes: Dict[int, list] = {}
+        self.rtol, self.atol = 1e-5, 1e-6
+
+    def expectedOutput(self, outputNum: int, expected):
+        """``expected``: array-like, or a callable ``fn(actual_tensor) -> None | error string``."""
+        if callable(expected):
+            self.expected[outputNum] = expected
+        else:
+            self.expected[outputNum] = expected.tensor() if hasattr(expected, "tensor") else torch.as_tensor(expected)
+            self.expShapes.setdefault(outputNum, list(self.expected[outputNum].shape))
+        return self
+
+    def expectedShape(self, outputNum: int, shape):
+        self.expShapes[outputNum] = [int(s) for s in shape]
+        return self
+
+    def tolerance(self, rtol, atol):
+        self.rtol, self.atol = rtol, atol
+        return self
+
+
 class OpValidation:
     """Runs TestCases and keeps per-op coverage counts (forward validated / gradient validated)."""
     fwdPassed: Dict[str, int] = {}
     gradPassed: Dict[str, int] = {}
 
     @staticmethod
-    def validate(tc: TestCase) -> Optional[str]:
+    def validateOp(tc: OpTestCase) -> Optional[str]:
+        op = tc.op
+        if tc.expShapes:
+            shapes = [list(s) for s in op.calculateOutputShape()]
+            for k, want in tc.expShapes.items():
+                if k >= len(shapes):
+                    return "%s: calculateOutputShape returned %d shapes, expected output %d" % (op.opName, len(shapes), k)
+                if shapes[k] != list(want):
+                    return "%s: calculateOutputShape[%d] = %s, expected %s" % (op.opName, k, shapes[k], list(want))
+        outs = op.exec()
+        outs = outs if isinstance(outs, (list, tuple)) else [outs]
+        for k, e in tc.expected.items():
+            if k >= len(outs):
+                return "%s: op produced %d outputs, expected output %d" % (op.opName, len(outs), k)
+            a = outs[k].tensor() if hasattr(outs[k], "tensor") else outs[k]
+            if callable(e):
+                err = e(a)
+                if err:
+                    return "%s: output %d: %s" % (op.opName, k, err)
+                continue
+            if list(a.shape) != list(e.shape):
+                return "%s: output %d shape %s != expected %s" % (op.opName, k, list(a.shape), list(e.shape))
+            if not torch.allclose(a.double().cpu(), e.double().cpu(), rtol=tc.rtol, atol=tc.atol, equal_nan=True):
+                return "%s: output %d values differ (max abs err %.3g)" % (op.opName, k, float((a.double().cpu() - e.double().cpu()).abs().max()))
+        OpValidation.fwdPassed[op.opName] = OpValidation.fwdPassed.get(op.opName, 0) + 1
+        return None
+
+    @staticmethod
+    def validate(tc) -> Optional[str]:
+        if isinstance(tc, OpTestCase):
+            return OpValidation.validateOp(tc)
         sd = tc.sd
         if tc.expected:
             res = sd.output(tc.placeholders, list(tc.expected))

@@ -208,3 +208,19 @@ def test_ifcond_gates_outer_values_and_passthrough_bodies():
     assert float(sd.output({"x": torch.tensor(-2.0)}, [r.name])[r.name]) == -3.0
     sd2 = SameDiff.fromFlatBuffers(sd.asFlatBuffers())           # the gated graph survives serialization
     assert float(sd2.output({"x": torch.tensor(-2.0)}, [r.name])[r.name]) == -3.0
+
+
+def test_op_test_case_validation():
+    from deeplearning4j_amd.autodiff.validation import OpTestCase, OpValidation
+    from deeplearning4j_amd.nd4j.ops.custom import DynamicCustomOp
+    a, b = torch.arange(6.0).reshape(2, 3), torch.ones(3, 4)
+    op = DynamicCustomOp.builder("matmul").addInputs(a, b).build()
+    assert OpValidation.validate(OpTestCase(op).expectedOutput(0, a @ b)) is None
+    assert OpValidation.fwdPassed.get("matmul", 0) >= 1
+    bad = OpValidation.validate(OpTestCase(DynamicCustomOp.builder("matmul").addInputs(a, b).build()).expectedOutput(0, a @ b + 1))
+    assert bad and "values differ" in bad
+    shp = OpValidation.validate(OpTestCase(DynamicCustomOp.builder("matmul").addInputs(a, b).build()).expectedShape(0, [2, 5]))
+    assert shp and "calculateOutputShape" in shp
+    pred = OpTestCase(DynamicCustomOp.builder("softmax").addInputs(a).build()).expectedOutput(
+        0, lambda t: None if torch.allclose(t.sum(-1), torch.ones(2)) else "rows do not sum to 1")
+    assert OpValidation.validate(pred) is None
