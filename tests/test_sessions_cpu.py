@@ -251,3 +251,24 @@ def test_transforms_static_helpers():
     n = INDArray(torch.tensor([[1.0, 10.0], [3.0, 30.0], [5.0, 50.0]]))
     Transforms.normalizeZeroMeanAndUnitVariance(n)
     assert torch.allclose(n.tensor().mean(0), torch.zeros(2), atol=1e-6) and torch.allclose(n.tensor().std(0), torch.ones(2), atol=1e-6)
+
+
+def test_runtime_handles():
+    from deeplearning4j_amd.nd4j.ndarray import INDArray
+    from deeplearning4j_amd.nd4j.runtime_handles import AtomicAllocator, LaunchContext, NativeOpsHolder, TadPack
+    lc = LaunchContext.defaultContext()
+    assert lc is LaunchContext.defaultContext() and lc.getDeviceId() == 0 and lc.isInitialized()
+    lc.syncStream()
+    t = torch.arange(24.0).reshape(2, 3, 4)
+    p = TadPack(INDArray(t), [2])
+    assert p.numberOfTads() == 6 and p.tadShape() == [4] and p.tadStrides() == [1] and p.tadLength() == 4
+    assert p.tadOffsets() == [0, 4, 8, 12, 16, 20]
+    assert torch.equal(p.tad(4).tensor(), t[1, 1]) and p.tad(4).tensor().data_ptr() == t[1, 1].data_ptr()      # a view
+    q = TadPack(t, [0, 2])
+    assert q.numberOfTads() == 3 and q.tadShape() == [2, 4] and q.tadOffsets() == [0, 4, 8] and torch.equal(q.tad(1).tensor(), t[:, 1, :])
+    with pytest.raises(IndexError):
+        p.tad(6)
+    a = AtomicAllocator.getInstance()
+    assert a.getPointer(t) == t.data_ptr() and set(a.getMemoryStats()) >= {"allocated", "reserved", "free", "total"}
+    a.synchronizeHostData(t)
+    assert NativeOpsHolder.getInstance().getRuntimeNativeOps() is not None
