@@ -297,3 +297,41 @@ def test_inference_graph_capture_matches_eager_and_parallel_inference_pads_batch
             assert torch.allclose(out.to(dev()).float(), net.output(xs[7])[0].float(), atol=2e-3, rtol=2e-2)
     finally:
         pi.shutdown()
+
+
+def test_wgrad_side_stream_matches_main_stream_eager_and_captured():
+    """ops/streams.py (opt-in): conv wgrads on a second HIP stream — forked per layer, joined when backward ends — give the same
+    gradients as the single-stream path, eagerly and as a parallel branch inside a captured HIP graph."""
+    from tests.test_networks_cpu import _onehot
+    from deeplearning4j_amd.models.resnet50 import ResNet50
+    from deeplearning4j_amd.nd4j.learning import Sgd
+    from deeplearning4j_amd.ops import streams
+    m = ResNet50(numClasses=5, inputShape=(3, 160, 160), computeDataType="BFLOAT16", updater=Sgd(0.0))
+    x = torch.rand(8, 3, 160, 160, device=dev())
+    y = _onehot(8, 5).float().to(dev())
+    ref = m.init(device=dev())
+    ref.computeGradientAndScore([x], [y])
+    torch.cuda.synchronize()
+    g_ref = ref._grads.clone()
+    wmask = torch.zeros_like(g_ref, dtype=torch.bool)
+    for e in ref._entries:
+        if e.spec.role != "stat":
+            wmask[e.off:e.off + e.spec.numel] = True
+    streams.set_enabled(True)
+    try:
+        a = m.init(device=dev())
+        a.computeGradientAndScore([x], [y])
+        assert streams._side is not None and not streams._pending and not streams._held      # forked, and joined at scope exit
+        torch.cuda.synchronize()
+        rel = ((a._grads - g_ref)[wmask]).norm() / g_ref[wmask].norm()
+        assert rel < 1e-3, float(rel)
+        b = m.init(device=dev())
+        b.enableGraphCapture(True)
+        for it in range(6):
+            b.fit(x, y)
+        assert b._graph_step.graph_a is not None
+        torch.cuda.synchronize()
+        rel = ((b._grads - g_ref)[wmask]).norm() / g_ref[wmask].norm()
+        assert rel < 1e-3, float(rel)
+    finally:
+        streams.set_enabled(False)
