@@ -65,6 +65,69 @@ class DataSetIterator:
 MultiDataSetIterator = DataSetIterator
 
 
+class ShardedDataSetIterator(DataSetIterator):
+    """This rank's share of a base iterator for data-parallel training: batch k of every COMPLETE round of ``world``
+    consecutive batches goes to rank ``k % world``; a ragged tail (fewer than ``world`` batches left) is dropped on every
+    rank so all ranks run the same number of iterations and every collective has all its peers.
+
+    Iterators that can address batches (``numBatches()`` + ``skip(n)``, e.g. list / benchmark iterators) never materialise
+    a foreign batch; for plain streams the foreign batches of a round are pulled and discarded before preprocessing."""
+
+    def __init__(self, base, rank, world):
+        self.base, self.rank, self.world = base, int(rank), max(1, int(world))
+        self._held = None
+
+    def _fill(self):
+        if self._held is not None or self.world == 1:
+            return
+        b = self.base
+        if hasattr(b, "numBatches") and hasattr(b, "skip"):
+            left = b.numBatches() - b.position()
+            if left < self.world:
+                b.skip(left)
+                return
+            b.skip(self.rank)
+            self._held = b.next()
+            b.skip(self.world - self.rank - 1)
+            return
+        mine, got = None, 0
+        while got < self.world and b.hasNext():
+            d = b.next()
+            if got == self.rank:
+                mine = d
+            got += 1
+        if got == self.world:
+            self._held = mine
+
+    def hasNext(self):
+        if self.world == 1:
+            return self.base.hasNext()
+        self._fill()
+        return self._held is not None
+
+    def next(self, num=None):
+        if self.world == 1:
+            return self.base.next()
+        self._fill()
+        d, self._held = self._held, None
+        if d is None:
+            raise StopIteration
+        return d
+
+    def reset(self):
+        self._held = None
+        self.base.reset()
+
+    def resetSupported(self):
+        return self.base.resetSupported()
+
+    def asyncSupported(self):
+        return False
+
+    def batch(self):
+        return self.base.batch()
+
+
 class ListDataSetIterator(DataSetIterator):
     def __init__(self, data, batchSize=None):
         if isinstance(data, DataSet):
@@ -84,6 +147,16 @@ class ListDataSetIterator(DataSetIterator):
 
     def reset(self):
         self._i = 0
+
+    # random access (lets ShardedDataSetIterator skip foreign batches without touching them)
+    def numBatches(self):
+        return len(self._data)
+
+    def position(self):
+        return self._i
+
+    def skip(self, n):
+        self._i = min(len(self._data), self._i + int(n))
 
     def batch(self):
         return self._bs

@@ -86,3 +86,20 @@ static inline int grid_for(int64_t work_items, int per_block) {
 }
 
 #define DL4J_RET_LAST() return (int)hipGetLastError()
+
+// hipFuncSetAttribute is PER DEVICE: a process that drives several GPUs from worker threads (ParallelInference replicas)
+// must raise the dynamic-LDS limit on each of them. One flag per (call site, device), set under a mutex so two threads
+// that race on the first launch both see the attribute applied before they launch.
+#include <mutex>
+struct DeviceOnceLds {
+  std::mutex mu;
+  int bytes[64] = {0};
+  void ensure(const void* fn, int want) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> g(mu);
+    if (bytes[dev] >= want) return;
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    bytes[dev] = want;
+  }
+};

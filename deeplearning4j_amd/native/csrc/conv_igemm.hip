@@ -216,12 +216,8 @@ static int launch_fwd(IGemmP& p, hipStream_t st) {
   constexpr int epi = ((BM * PITCH_C + 255) & ~255) + 4 * BN * (int)sizeof(float);   // epilogue staging (C tile + stat partials)
   int smem = p.nbuf * (BM + BN) * 128;
   if (smem < epi) smem = epi;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * 128 > epi ? 2 * (BM + BN) * 128 : epi);
-    attr_set = true;
-  }
+  static DeviceOnceLds lds_attr;
+  lds_attr.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN>), 2 * (BM + BN) * 128 > epi ? 2 * (BM + BN) * 128 : epi);
   hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
   DL4J_RET_LAST();
 }
@@ -467,12 +463,8 @@ static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t
   }
   const int smem = 2 * 2 * 64 * (BK_ + BC_) * 2;      // two groups x double buffer
   static_assert(BK_ * BC_ * 4 <= 2 * 2 * 64 * (BK_ + BC_) * 2, "exchange tile must fit the operand buffers");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BK_, BC_>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  static DeviceOnceLds lds_attr;
+  lds_attr.ensure(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BK_, BC_>), smem);
   hipLaunchKernelGGL((igemm_wgrad_kernel<BK_, BC_>), dim3(tiles * splits), dim3(512), smem, st, p);
   DL4J_RET_LAST();
 }

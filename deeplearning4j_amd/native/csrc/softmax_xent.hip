@@ -5,8 +5,8 @@
 // One workgroup (256 threads = 4 waves) per row; wave64 shuffles + one LDS hop for block reductions.
 #include "common.h"
 
-template <typename T>
-__global__ void __launch_bounds__(256) softmax_xent_kernel(const T* __restrict__ z, const T* __restrict__ y,
+template <typename T, typename YT>
+__global__ void __launch_bounds__(256) softmax_xent_kernel(const T* __restrict__ z, const YT* __restrict__ y,
                                                            const int64_t* __restrict__ ylab,
                                                            T* __restrict__ probs, T* __restrict__ grad,
                                                            float* __restrict__ row_loss, float* __restrict__ score,
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) softmax_xent_kernel(const T* __restrict__
   const int64_t lab = ylab ? ylab[row] : -1;
   for (int i = threadIdx.x; i < N; i += 256) {
     const float p = __expf(Cvt<T>::ld(zr, i) - mx) * inv;
-    const float yv = ylab ? (i == lab ? 1.f : 0.f) : Cvt<T>::ld(y + row * N, i);
+    const float yv = ylab ? (i == lab ? 1.f : 0.f) : Cvt<YT>::ld(y + row * N, i);
     if (probs) Cvt<T>::st(probs + row * N, i, p);
     if (grad) Cvt<T>::st(grad + row * N, i, p - yv);
     if (yv != 0.f) loss -= yv * __logf(fminf(fmaxf(p, 1e-10f), 1.f));
@@ -84,12 +84,19 @@ DL4J_API int dl4j_softmax_xent(const void* z, const void* y, const int64_t* ylab
                                float* row_loss, float* score, int64_t M, int N, int dtype, hipStream_t st) {
   if (score) hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(64), 0, st, score, 1);
   if (M <= 0) return 0;
-  if (dtype == 1)
-    hipLaunchKernelGGL(softmax_xent_kernel<bf16_t>, dim3((unsigned)M), dim3(256), 0, st, (const bf16_t*)z,
+  // dtype: low byte = logits / probs / grad type, second byte = label type (0 fp32, 1 bf16); labels keep the network dtype
+  const int zt = dtype & 0xff, yt = (dtype >> 8) & 0xff;
+  if (zt == 1 && yt == 1)
+    hipLaunchKernelGGL((softmax_xent_kernel<bf16_t, bf16_t>), dim3((unsigned)M), dim3(256), 0, st, (const bf16_t*)z,
                        (const bf16_t*)y, ylab, (bf16_t*)probs, (bf16_t*)grad, row_loss, score, N);
-  else
-    hipLaunchKernelGGL(softmax_xent_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (const float*)z,
+  else if (zt == 1)
+    hipLaunchKernelGGL((softmax_xent_kernel<bf16_t, float>), dim3((unsigned)M), dim3(256), 0, st, (const bf16_t*)z,
+                       (const float*)y, ylab, (bf16_t*)probs, (bf16_t*)grad, row_loss, score, N);
+  else if (yt == 0)
+    hipLaunchKernelGGL((softmax_xent_kernel<float, float>), dim3((unsigned)M), dim3(256), 0, st, (const float*)z,
                        (const float*)y, ylab, (float*)probs, (float*)grad, row_loss, score, N);
+  else
+    return -2;
   DL4J_RET_LAST();
 }
 

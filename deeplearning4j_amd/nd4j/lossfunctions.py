@@ -25,6 +25,11 @@ def _apply_mask(arr, mask):
     return arr * mask.to(arr.dtype)
 
 
+def _loss_dtype(t):
+    """Loss math runs in fp32 when the network computes in bf16 / fp16."""
+    return t.float() if t.dtype in (torch.bfloat16, torch.float16) else t
+
+
 class ILossFunction:
     JAVA_CLASS = None
     NAME = None
@@ -45,7 +50,7 @@ class ILossFunction:
         return arr * w.reshape(1, -1)
 
     def computeScoreArray(self, labels, preOutput, activationFn, mask=None):
-        out = get_activation(activationFn).forward(preOutput)
+        out = get_activation(activationFn).forward(_loss_dtype(preOutput))
         return _apply_mask(self._w(self._score_elems(labels.to(out.dtype), out)), mask).sum(1)
 
     def computeScore(self, labels, preOutput, activationFn, mask=None, average=True):
@@ -60,7 +65,9 @@ class ILossFunction:
     def computeGradientAndScore(self, labels, preOutput, activationFn, mask=None, average=True):
         """Returns (score tensor (0-d), dL/dpreOutput). Gradient is the SUM over examples (DL4J)."""
         act = get_activation(activationFn)
-        z = preOutput.detach().requires_grad_(True)
+        # reduced-precision pre-outputs (bf16 / fp16 compute) are scored in fp32 against the un-rounded labels; only the
+        # gradient handed back to the layer is cast to the compute type
+        z = _loss_dtype(preOutput.detach()).requires_grad_(True)
         with torch.enable_grad():
             out = act.forward(z, True)
             s = _apply_mask(self._w(self._score_elems(labels.to(out.dtype), out)), mask).sum()
@@ -68,7 +75,7 @@ class ILossFunction:
         s = s.detach()
         if average:
             s = s / preOutput.shape[0]
-        return s, g
+        return s, g.to(preOutput.dtype)
 
     def to_json(self):
         d = {"@class": self.JAVA_CLASS}
@@ -100,7 +107,7 @@ class LossMCXENT(ILossFunction):
                 and preOutput.dim() == 2 and labels.shape == preOutput.shape):
             from ..ops.softmax import softmax_xent
             z = preOutput.contiguous()
-            score, grad, _ = softmax_xent(z, labels.to(z.dtype).contiguous())
+            score, grad, _ = softmax_xent(z, labels.contiguous())
             s = score[0]
             if average:
                 s = s / preOutput.shape[0]
@@ -153,9 +160,9 @@ class LossMSE(ILossFunction):
     def computeGradientAndScore(self, labels, preOutput, activationFn, mask=None, average=True):
         act = get_activation(activationFn)
         if isinstance(act, ActivationIdentity) and self.weights is None and mask is None:
-            d = preOutput - labels.to(preOutput.dtype)
-            s = (d.float() ** 2).sum() / labels.shape[1]
-            return (s / preOutput.shape[0] if average else s), d * (2.0 / labels.shape[1])
+            d = _loss_dtype(preOutput) - labels.to(_loss_dtype(preOutput).dtype)
+            s = (d ** 2).sum() / labels.shape[1]
+            return (s / preOutput.shape[0] if average else s), (d * (2.0 / labels.shape[1])).to(preOutput.dtype)
         return super().computeGradientAndScore(labels, preOutput, activationFn, mask, average)
 
 

@@ -487,21 +487,39 @@ class ComputationGraph(BaseNetwork):
         return eps
 
     def _node_min_offsets(self):
-        """offs[k] = lowest flat-gradient offset owned by plan nodes k..end (all finished once node k ran backward)."""
+        """offs[k] = smallest T such that NO unfinished plan node (0..k-1) owns a flat-gradient offset >= T, i.e. every
+        gradient at offset >= offs[k] is final once plan nodes k..end have run backward. Fused nodes own parameters that
+        sit earlier in the flat vector than parameters of nodes that run later in backward (a fused BN node at the trailing
+        ReLU owns the shortcut BN while the shortcut conv is still pending), so the bound is the highest END offset among
+        the unfinished nodes, not the lowest start offset among the finished ones."""
         if getattr(self, "_node_offs", None) is not None and len(self._node_offs) == len(self._plan) + 1:
             return self._node_offs
         by_impl = {}
         for e in self._entries:
-            by_impl.setdefault(id(e.layer), []).append(e.off)
-        offs = [self._num_params] * (len(self._plan) + 1)
-        for k in range(len(self._plan) - 1, -1, -1):
-            nd = self._plan[k]
-            cand = [offs[k + 1]]
-            for impl in ([nd.impl] + ([nd.bn2] if getattr(nd, "bn2", None) is not None else [])):
-                cand += by_impl.get(id(impl), [])
-            offs[k] = min(cand)
+            by_impl.setdefault(id(e.layer), []).append(e.off + e.spec.numel)
+        offs = [0] * (len(self._plan) + 1)
+        hi = 0                                    # highest end offset owned by plan nodes 0..k-1
+        for k, nd in enumerate(self._plan):
+            offs[k] = hi
+            for impl in self._node_impls(nd):
+                for end in by_impl.get(id(impl), []):
+                    hi = max(hi, end)
+        offs[len(self._plan)] = hi
         self._node_offs = offs
         return offs
+
+    @staticmethod
+    def _node_impls(nd):
+        """Every layer implementation whose parameters a plan node's backward writes (fused nodes own several)."""
+        out = []
+        for attr in ("impl", "bn", "bn2", "conv", "act"):
+            v = getattr(nd, attr, None)
+            if v is not None and not any(v is o for o in out):
+                out.append(v)
+        for v in getattr(nd, "impls", None) or []:
+            if not any(v is o for o in out):
+                out.append(v)
+        return out
 
     def computeGradientAndScore(self, inputs=None, labels=None, fmasks=None, lmasks=None, mode=None):
         self._check_init()

@@ -362,9 +362,9 @@ class MultiLayerNetwork(BaseNetwork):
         if (self.conf.backpropType == BackpropType.TruncatedBPTT and torch.as_tensor(x).dim() == 3
                 and torch.as_tensor(x).shape[2] > self.conf.tbpttFwdLength):
             return self._fit_tbptt(x, y, fmask, lmask)
-        if self._graph_step is not None:
+        if self._graph_step is not None and fmask is None and lmask is None:
             self._graph_step.run(x, y)
-        else:
+        else:       # masked / variable-length batches are not part of the captured signature: run them eagerly
             self.computeGradientAndScore(x, y, fmask, lmask)
             self._apply_update(self._last_batch)
         self.clearLayerMaskArrays()

@@ -432,9 +432,11 @@ class BaseNetwork:
         return x
 
     def _prep_labels(self, y):
+        # labels stay in the NETWORK dtype (fp32 master): only activations / weights are rounded to the bf16 / fp16 compute
+        # type; the fused softmax-xent kernel casts where it needs matching operands (ops/softmax.py)
         y = self._to_dev(y)
-        if y is not None and y.is_floating_point() and y.dtype != self.ctx.cdtype:
-            y = y.to(self.ctx.cdtype)
+        if y is not None and y.is_floating_point() and y.dtype != self.ctx.dtype:
+            y = y.to(self.ctx.dtype)
         return y
 
     def close(self):

@@ -21,13 +21,15 @@ def softmax_xent(z, y=None, labels_idx=None, want_probs=False):
     Score is the SUM over rows (caller divides by minibatch, as DL4J does).
     """
     M, N = z.shape
-    if _ok(z) and (y is None or (y.dtype == z.dtype and y.is_contiguous())):
+    if _ok(z) and (y is None or (y.dtype in (z.dtype, torch.float32) and y.is_contiguous())):
+        # labels may stay fp32 (network dtype) while the logits are bf16: the kernel reads each operand in its own type
         grad = torch.empty_like(z)
         probs = torch.empty_like(z) if want_probs else None
         score = torch.empty(1, device=z.device, dtype=torch.float32)
+        ycode = L.dtype_code(y) if y is not None else L.dtype_code(z)
         L.check(L.hip().dl4j_softmax_xent(L.ptr(z), L.ptr(y), L.ptr(labels_idx), L.ptr(probs), L.ptr(grad),
                                           L.ptr(None), L.ptr(score), L.c_int64(M), L.c_int(N),
-                                          L.c_int(L.dtype_code(z)), L.stream()), "softmax_xent")
+                                          L.c_int(L.dtype_code(z) | (ycode << 8)), L.stream()), "softmax_xent")
         return score, grad, probs
     cd = torch.float32 if z.dtype == torch.bfloat16 else z.dtype
     p = torch.softmax(z.to(cd), dim=1)

@@ -151,20 +151,17 @@ class ParallelWrapper:
         m._refresh_replicas()
 
     def fit(self, iterator, numEpochs=1):
-        """Each rank consumes its own shard: batches rank, rank+world, ... of the iterator."""
+        """Each rank consumes its own shard: batch k of every complete round of ``world`` batches goes to rank k % world.
+        A ragged tail is dropped on every rank (ShardedDataSetIterator), so the iteration count is uniform and no
+        all-reduce is ever left without its peers."""
+        from ..datasets.iterators import ShardedDataSetIterator
         m = self.model
-        r = comm.rank()
+        src = iterator if self.world == 1 else ShardedDataSetIterator(iterator, comm.rank(), self.world)
         for _ in range(numEpochs):
-            if iterator.resetSupported():
-                iterator.reset()
-            k = 0
-            while iterator.hasNext() and not self._stop:
-                ds = iterator.next()
-                if self.world > 1 and (k % self.world) != r:
-                    k += 1
-                    continue
-                k += 1
-                m.fit(ds)
+            if src.resetSupported():
+                src.reset()
+            while src.hasNext() and not self._stop:
+                m.fit(src.next())
                 self._maybe_average_params()
             m.incrementEpochCount()
         return self

@@ -35,6 +35,7 @@ class TrainingMaster:
         self.workerPrefetchNumBatches = kw.get("workerPrefetchNumBatches", 2)
         self.encodingDebugMode = kw.get("encodingDebugMode", False)
         self.rddDataSetNumExamples = kw.get("rddDataSetNumExamples", 1)
+        self.ignoredOptions = dict(kw.get("ignoredOptions", {}))
         self._stats = []
 
     def wrapper(self, model) -> ParallelWrapper:
@@ -67,12 +68,31 @@ class _MasterBuilder:
             elif hasattr(a, "calculateThreshold"):
                 self._kw["thresholdAlgorithm"] = a
 
+    # options that change behaviour here
+    _APPLIED = ("batchSizePerWorker", "workersPerNode", "averagingFrequency", "thresholdAlgorithm", "residualPostProcessor",
+                "collectTrainingStats", "saveUpdater", "workerPrefetchNumBatches", "encodingDebugMode",
+                "rddDataSetNumExamples")
+    # upstream options that are meaningless without Spark / Aeron (storage levels, repartitioning, mesh transport):
+    # accepted so upstream code builds unchanged, recorded in ``ignoredOptions`` and otherwise without effect
+    _ACCEPTED = ("rddTrainingApproach", "exportDirectory", "storageLevel", "storageLevelStreams", "repartionData",
+                 "repartitionStrategy", "repartitioner", "aggregationDepth", "rngSeed", "unicastPort", "networkMask",
+                 "controllerAddress", "transport", "meshBuildMode", "workerTogglePeriodicGC", "workerPeriodicGCFrequency",
+                 "maxChunkSize", "debugLongerIterations", "shakeFrequency", "voidConfiguration", "trainingHooks",
+                 "updatesThreshold", "thresholdStep", "minThreshold", "stepTrigger", "stepDelay", "numWorkers")
+
     def __getattr__(self, name):
         if name.startswith("_"):
             raise AttributeError(name)
+        if name not in self._APPLIED and name not in self._ACCEPTED:
+            raise AttributeError("%s.Builder has no option '%s' (applied: %s; accepted without effect: %s)"
+                                 % (self._cls.__name__, name, ", ".join(self._APPLIED), ", ".join(self._ACCEPTED)))
 
         def setter(*v):
-            self._kw[name] = v[0] if len(v) == 1 else (v or True)
+            val = v[0] if len(v) == 1 else (v or True)
+            if name in self._APPLIED:
+                self._kw[name] = val
+            else:
+                self._kw.setdefault("ignoredOptions", {})[name] = val
             return self
         return setter
 

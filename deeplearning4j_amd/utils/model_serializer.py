@@ -61,7 +61,10 @@ class ModelSerializer:
         conf_json, params, upd, _ = ModelSerializer._read(path)
         d = json.loads(conf_json)
         if "confs" not in d:
-            raise ValueError("Model is not a MultiLayerNetwork (use restoreComputationGraph)")
+            # ModelSerializer.java:251-330 tries the other configuration type before giving up
+            if "vertices" in d:
+                return ModelSerializer.restoreComputationGraph(path, loadUpdater, device=device)
+            raise ValueError("configuration.json holds neither a MultiLayerConfiguration nor a ComputationGraphConfiguration")
         conf = MultiLayerConfiguration.fromJson(d)
         net = MultiLayerNetwork(conf, device=device)
         net.init(params, True)
@@ -76,7 +79,9 @@ class ModelSerializer:
         conf_json, params, upd, _ = ModelSerializer._read(path)
         d = json.loads(conf_json)
         if "vertices" not in d:
-            raise ValueError("Model is not a ComputationGraph (use restoreMultiLayerNetwork)")
+            if "confs" in d:
+                return ModelSerializer.restoreMultiLayerNetwork(path, loadUpdater, device=device)
+            raise ValueError("configuration.json holds neither a MultiLayerConfiguration nor a ComputationGraphConfiguration")
         conf = ComputationGraphConfiguration.fromJson(conf_json)
         net = ComputationGraph(conf, device=device)
         net.init(params, True)

@@ -208,3 +208,116 @@ def test_parallel_wrapper_threshold_encoded_exchange_gloo(tmp_path):
     r0 = torch.load(tmp_path / "r0.pt", weights_only=True)
     r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
     assert torch.equal(r0["params"], r1["params"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: uneven tails, fused-node bucket readiness
+def _tail_worker(rank, world, port, n_batches, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(1)
+    from deeplearning4j_amd.parallel import comm
+    from deeplearning4j_amd.parallel.parallel_wrapper import ParallelWrapper
+    from deeplearning4j_amd.datasets.dataset import DataSet
+    from deeplearning4j_amd.datasets.iterators import ListDataSetIterator, ExistingDataSetIterator
+    comm.init_process_group("gloo", timeout_s=60)
+    for stream_like in (False, True):
+        net = _build(seed=7 + rank)
+        pw = ParallelWrapper.Builder(net).bucketBytes(64).build()
+        data = [DataSet(*_data(s)) for s in range(n_batches)]
+        it = ExistingDataSetIterator(iter(data)) if stream_like else ListDataSetIterator(data)
+        if stream_like:
+            it.resetSupported = lambda: False
+        pw.fit(it, 1)
+        assert net.iterationCount == n_batches // world, (net.iterationCount, n_batches, world)
+        assert pw.params_in_sync()
+        pw.shutdown()
+    torch.save({"params": net.params().clone()}, os.path.join(out_dir, "r%d.pt" % rank))
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_batches", [(2, 5), (2, 7), (3, 7), (3, 5)])
+def test_parallel_wrapper_uneven_tail_does_not_hang(tmp_path, world, n_batches):
+    """5 or 7 batches over 2 or 3 ranks: the ragged tail is dropped on every rank, nobody waits for a missing peer."""
+    port = _free_port()
+    mp.spawn(_tail_worker, args=(world, port, n_batches, str(tmp_path)), nprocs=world, join=True)
+    ps = [torch.load(tmp_path / ("r%d.pt" % r), weights_only=True)["params"] for r in range(world)]
+    assert all(torch.equal(ps[0], p) for p in ps[1:])
+
+
+def _build_res_cg(seed=7):
+    """conv block with a projection shortcut: main = conv2c -> bn2c, shortcut = conv1 -> bn1, add, relu (ResNet 'conv block')."""
+    from deeplearning4j_amd.nn.conf.configuration import NeuralNetConfiguration
+    from deeplearning4j_amd.nn.conf.layers import (ConvolutionLayer, BatchNormalization, ActivationLayer, OutputLayer,
+                                                   GlobalPoolingLayer)
+    from deeplearning4j_amd.nn.conf.graph import ElementWiseVertex
+    from deeplearning4j_amd.nn.conf.base import InputType
+    from deeplearning4j_amd.nn.graph.computation_graph import ComputationGraph
+    from deeplearning4j_amd.nd4j.learning import Sgd
+    g = (NeuralNetConfiguration.Builder().seed(seed).updater(Sgd(1e-2)).graphBuilder().addInputs("in"))
+    g.addLayer("stem", ConvolutionLayer.Builder(1, 1).nIn(3).nOut(4).activation("relu").build(), "in")
+    g.addLayer("c2c", ConvolutionLayer.Builder(1, 1).nIn(4).nOut(8).activation("identity").build(), "stem")
+    g.addLayer("bn2c", BatchNormalization.Builder().nOut(8).build(), "c2c")
+    g.addLayer("c1", ConvolutionLayer.Builder(3, 3).nIn(4).nOut(8).padding(1, 1).activation("identity").build(), "stem")
+    g.addLayer("bn1", BatchNormalization.Builder().nOut(8).build(), "c1")
+    g.addVertex("add", ElementWiseVertex("Add"), "bn2c", "bn1")
+    g.addLayer("relu", ActivationLayer.Builder().activation("relu").build(), "add")
+    g.addLayer("gp", GlobalPoolingLayer.Builder().poolingType("AVG").build(), "relu")
+    g.addLayer("out", OutputLayer.Builder().nIn(8).nOut(3).activation("softmax").lossFunction("MCXENT").build(), "gp")
+    g.setOutputs("out").setInputTypes(InputType.convolutional(5, 5, 3))
+    net = ComputationGraph(g.build())
+    net.init()
+    return net
+
+
+def test_backward_progress_offsets_hold_for_fused_nodes():
+    """offs[k] must bound every offset still to be written: no plan node 0..k-1 owns a gradient at or above offs[k]."""
+    net = _build_res_cg()
+    offs = net._node_min_offsets()
+    assert any(type(nd).__name__ == "_FusedBNNode" for nd in net._plan), "fusion planner did not fuse the block"
+    ends = {}
+    for e in net._entries:
+        ends.setdefault(id(e.layer), []).append(e.off + e.spec.numel)
+    for k in range(len(net._plan) + 1):
+        for nd in net._plan[:k]:
+            for impl in net._node_impls(nd):
+                for end in ends.get(id(impl), []):
+                    assert end <= offs[k], (k, nd.out, end, offs[k])
+    assert offs[0] == 0 and offs[-1] == net.numParams()
+
+
+def _res_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(1)
+    from deeplearning4j_amd.parallel import comm
+    from deeplearning4j_amd.parallel.parallel_wrapper import ParallelWrapper
+    comm.init_process_group("gloo", timeout_s=60)
+    res = {}
+    for overlap in (True, False):
+        net = _build_res_cg(seed=7)
+        # 16-float buckets: boundaries fall inside the shortcut conv (288 weights) and between the fused node's BNs
+        pw = ParallelWrapper.Builder(net).bucketBytes(64).overlap(overlap).build()
+        g = torch.Generator().manual_seed(5 + rank)
+        for step in range(3):
+            x = torch.randn(4, 3, 5, 5, generator=g)
+            y = torch.eye(3)[torch.randint(0, 3, (4,), generator=g)]
+            net.fit(x, y)
+        assert pw.params_in_sync()
+        res[overlap] = net.params().clone()
+        pw.shutdown()
+    assert torch.equal(res[True], res[False]), (res[True] - res[False]).abs().max()
+    torch.save({"params": res[True]}, os.path.join(out_dir, "r%d.pt" % rank))
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_overlapped_buckets_match_non_overlapped_on_projection_shortcut_block(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_res_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
+    assert torch.equal(r0["params"], r1["params"])
