@@ -15,7 +15,7 @@ struct GemmP {
   int M, N, K;
   int64_t lda, ldb, ldc;
   int64_t sA, sB, sC;         // batch strides (elements)
-  int mtiles, ntiles;
+  int mtiles, ntiles, gm;
   int act;
   int out_f32;                // 1: C is fp32
   float alpha;
@@ -47,11 +47,12 @@ template <class C> struct PlainSrc {
   }
 };
 
-template <class C>
+template <class C, bool PP = false>
 __global__ void __launch_bounds__(C::NT) gemm_nt_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = lid / p.ntiles, nt = lid - mt * p.ntiles;
+  int mt, nt;
+  tile_coords(lid, p.mtiles, p.ntiles, p.gm, mt, nt);
   const int m0 = mt * C::BM, n0 = nt * C::BN;
   const bf16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
   const bf16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
@@ -74,24 +75,25 @@ __global__ void __launch_bounds__(C::NT) gemm_nt_kernel(const GemmP p) {
     if (n > p.N - 1) n = p.N - 1;
     src.bp[i] = B + (int64_t)n * p.ldb;
   }
-  f32x16 acc[C::TM][C::TN];
-  mainloop<C>(smem, src, (p.K + 63) >> 6, acc);
+  typename C::acc_t acc[C::TM][C::TN];
+  if constexpr (PP) mainloop_pingpong<C>(smem, src, (p.K + 63) >> 6, acc);
+  else mainloop<C>(smem, src, (p.K + 63) >> 6, acc);
 
   // ---- epilogue: alpha, bias, activation, residual, rounding; LDS transpose so every row leaves as whole 16-byte chunks
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / C::WN, wn = wid - wm * C::WN;
-  const int l31 = lane & 31, lh = lane >> 5;
+  const int lc = C::acc_col(lane);
   if (p.out_f32) {
     float* Cf = (float*)p.C + (int64_t)blockIdx.y * p.sC;
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) {
-      const int n = n0 + wn * (C::BN / C::WN) + j * 32 + l31;
+      const int n = n0 + wn * (C::BN / C::WN) + j * C::MF + lc;
       const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
       for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm * (C::BM / C::WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        for (int e = 0; e < C::ACC; ++e) {
+          const int m = m0 + wm * (C::BM / C::WM) + i * C::MF + C::acc_row(e, lane);
           if (m < p.M && n < p.N) {
             float v = apply_act(acc[i][j][e] * p.alpha + bv, p.act);
             if (p.residual) v += bf2f(p.residual[(int64_t)blockIdx.y * p.sC + (int64_t)m * p.ldc + n]);
@@ -104,13 +106,13 @@ __global__ void __launch_bounds__(C::NT) gemm_nt_kernel(const GemmP p) {
   char* sC = smem;
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) {
-    const int col = wn * (C::BN / C::WN) + j * 32 + l31;
+    const int col = wn * (C::BN / C::WN) + j * C::MF + lc;
     const float bv = (p.bias && n0 + col < p.N) ? p.bias[n0 + col] : 0.f;
 #pragma unroll
     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * (C::BM / C::WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      for (int e = 0; e < C::ACC; ++e) {
+        const int row = wm * (C::BM / C::WM) + i * C::MF + C::acc_row(e, lane);
         *reinterpret_cast<bf16_t*>(sC + row * C::PITCH_C + col * 2) = f2bf(apply_act(acc[i][j][e] * p.alpha + bv, p.act));
       }
   }
@@ -141,13 +143,14 @@ __global__ void __launch_bounds__(C::NT) gemm_nt_kernel(const GemmP p) {
   }
 }
 
-template <class C>
+template <class C, bool PP = false>
 static int launch_gemm(GemmP& p, int batch, hipStream_t st) {
   p.mtiles = (p.M + C::BM - 1) / C::BM;
   p.ntiles = (p.N + C::BN - 1) / C::BN;
+  if (p.gm <= 0) p.gm = 4;
   static DeviceOnceLds lds_attr;
-  lds_attr.ensure(reinterpret_cast<const void*>(&gemm_nt_kernel<C>), C::LDS_BYTES);
-  hipLaunchKernelGGL((gemm_nt_kernel<C>), dim3(p.mtiles * p.ntiles, batch), dim3(C::NT), C::LDS_BYTES, st, p);
+  lds_attr.ensure(reinterpret_cast<const void*>(&gemm_nt_kernel<C, PP>), C::LDS_BYTES);
+  hipLaunchKernelGGL((gemm_nt_kernel<C, PP>), dim3(p.mtiles * p.ntiles, batch), dim3(C::NT), C::LDS_BYTES, st, p);
   return (int)hipGetLastError();
 }
 

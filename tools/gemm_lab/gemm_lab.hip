@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deeplearning4j_amd/native/csrc tools/gemm_lab/gemm_lab.hip -o tools/gemm_lab/gemm_lab
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cmath>
 #include <vector>
 #include <algorithm>
@@ -31,11 +32,16 @@ __global__ void cmp_kernel(const bf16_t* C, const float* R, int64_t n, float* ma
   atomicMax((int*)maxerr, __float_as_int(e)); atomicMax((int*)maxref, __float_as_int(r));
 }
 
-struct Variant { const char* name; int (*launch)(GemmP&, int, hipStream_t); int bm, bn; };
-#define V(bm, bn, wm, wn, st) {#bm "x" #bn "_w" #wm "x" #wn "_s" #st, &launch_gemm<Cfg<bm, bn, wm, wn, st>>, bm, bn}
+struct Variant { const char* name; int (*launch)(GemmP&, int, hipStream_t); int bm, bn, gm; };
+#define V(bm, bn, wm, wn, st, mf, gm) {#bm "x" #bn "_w" #wm "x" #wn "_s" #st "_mf" #mf "_g" #gm, &launch_gemm<Cfg<bm, bn, wm, wn, st, mf>>, bm, bn, gm}
 static Variant variants[] = {
-  V(256, 256, 2, 4, 2), V(256, 128, 2, 2, 2), V(256, 128, 2, 2, 3), V(256, 128, 4, 2, 3), V(128, 128, 2, 2, 2), V(128, 128, 2, 2, 3),
-  V(128, 128, 2, 2, 4), V(128, 64, 2, 2, 3), V(128, 64, 2, 2, 4), V(64, 64, 2, 2, 4), V(128, 256, 2, 4, 3),
+  {"256x256_pingpong_g4", &launch_gemm<Cfg<256, 256, 2, 4, 2, 16>, true>, 256, 256, 4},
+  {"256x256_pingpong_g8", &launch_gemm<Cfg<256, 256, 2, 4, 2, 16>, true>, 256, 256, 8},
+  V(256, 256, 2, 4, 2, 32, 1), V(256, 256, 2, 4, 2, 32, 4), V(256, 256, 2, 4, 2, 16, 4), V(256, 256, 2, 4, 2, 16, 8),
+  V(256, 128, 4, 2, 3, 32, 4), V(256, 128, 4, 2, 3, 16, 4), V(256, 128, 4, 2, 2, 16, 4), V(128, 256, 2, 4, 3, 16, 4),
+  V(128, 128, 2, 2, 2, 32, 4), V(128, 128, 2, 2, 2, 16, 4), V(128, 128, 2, 2, 2, 16, 8),
+  V(128, 64, 2, 2, 3, 32, 4), V(128, 64, 2, 2, 3, 16, 4), V(128, 64, 2, 2, 2, 16, 4), V(128, 64, 2, 2, 2, 16, 8), V(128, 64, 2, 2, 1, 16, 8),
+  V(64, 64, 2, 2, 4, 16, 4), V(64, 64, 2, 2, 2, 16, 8), V(64, 64, 2, 2, 1, 16, 8), V(64, 128, 2, 2, 2, 16, 8),
 };
 
 int main(int argc, char** argv) {
@@ -44,6 +50,8 @@ int main(int argc, char** argv) {
                                {65536, 256, 64}, {200704, 256, 64}, {1024, 1024, 1024}, {12544, 256, 1024}, {50176, 128, 512},
                                {1000, 520, 264}};
   const int iters = argc > 1 ? atoi(argv[1]) : 20;
+  const char* vfilter = argc > 2 ? argv[2] : "";          // substring of the variant name ("" = all)
+  if (argc > 5) shapes = {{atoi(argv[3]), atoi(argv[4]), atoi(argv[5])}};
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float* d_err; CK(hipMalloc(&d_err, 8));
@@ -57,7 +65,10 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
     printf("shape M=%d N=%d K=%d  (%.2f GFLOP)\n", s.M, s.N, s.K, 2.0 * s.M * s.N * s.K / 1e9);
     for (auto& v : variants) {
-      GemmP p{}; p.A = A; p.B = B; p.C = C; p.M = s.M; p.N = s.N; p.K = s.K; p.lda = s.K; p.ldb = s.K; p.ldc = s.N; p.alpha = 1.f;
+      if (vfilter[0] && !strstr(v.name, vfilter)) continue;
+      if (v.launch == nullptr) continue;
+      if ((s.K + 63) / 64 > 1 && strstr(v.name, "_s1_")) continue;     // single-stage build is for one k-tile only
+      GemmP p{}; p.gm = v.gm; p.A = A; p.B = B; p.C = C; p.M = s.M; p.N = s.N; p.K = s.K; p.lda = s.K; p.ldb = s.K; p.ldc = s.N; p.alpha = 1.f;
       CK(hipMemsetAsync(C, 0, nc * 2, st));
       int rc = v.launch(p, 1, st);
       if (rc) { printf("  %-18s launch rc=%d\n", v.name, rc); continue; }
