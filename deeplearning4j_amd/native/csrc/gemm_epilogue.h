@@ -1,0 +1,150 @@
+// Shared epilogue of the LDS-DMA GEMM / implicit-GEMM kernels: alpha, bias, activation, rounding to the output type, LDS transpose
+// so every output row leaves as whole 16-byte chunks, optional residual add / in-place accumulation, optional per-column
+// (sum, sum of squares) partials of the ROUNDED values for a following BatchNorm (one pass over y saved; reference computes the
+// statistics in a separate pass, nn/layers/normalization/BatchNormalization.java:270-360).
+#pragma once
+#include "gemm_core.h"
+
+namespace gemmcore {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_TANH = 2, ACT_GELU_ERF = 3, ACT_TANH = 4, ACT_SIGMOID = 5 };
+enum { OT_BF16 = 0, OT_F16 = 1, OT_F32 = 2 };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_GELU_TANH: { const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v); return 0.5f * v * (1.f + tanhf(u)); }
+    case ACT_GELU_ERF: return 0.5f * v * (1.f + erff(v * 0.7071067811865476f));
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+template <int OT> struct Out;
+template <> struct Out<OT_BF16> {
+  typedef bf16_t T; static constexpr int SZ = 2;
+  static __device__ __forceinline__ T cv(float f) { return f2bf(f); }
+  static __device__ __forceinline__ float fl(T v) { return bf2f(v); }
+};
+template <> struct Out<OT_F16> {
+  typedef uint16_t T; static constexpr int SZ = 2;
+  static __device__ __forceinline__ T cv(float f) { _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }
+  static __device__ __forceinline__ float fl(T v) { return (float)__builtin_bit_cast(_Float16, v); }
+};
+template <> struct Out<OT_F32> {
+  typedef float T; static constexpr int SZ = 4;
+  static __device__ __forceinline__ T cv(float f) { return f; }
+  static __device__ __forceinline__ float fl(T v) { return v; }
+};
+
+struct EpiP {
+  void* out;                 // output tensor
+  const void* residual;      // same addressing as out, added after the activation (or null)
+  const float* bias;         // [N] or null
+  float* stats;              // [mtiles][2][N] partial column sums of the rounded outputs (or null)
+  const float* stat_shift;   // [N] per-column shift subtracted before summing (running mean; null = 0): keeps E[x^2]-E[x]^2 stable
+  float alpha;
+  int act;
+  int accum;                 // out += result
+};
+
+// RowOff: int64 element offset of tile row r's first column (n0) in `out`, or -1 when the row is out of range.
+template <class C, int OT, class RowOff>
+__device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C::TM][C::TN], int mt, int n0, int N,
+                                         const EpiP& e, RowOff rowoff) {
+  typedef Out<OT> O;
+  typedef typename O::T OTy;
+  constexpr int PITCH = C::pitch_c(O::SZ);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / C::WN, wn = wid - wm * C::WN;
+  const int lc = C::acc_col(lane);
+  char* sC = smem;
+  int64_t* sRow = reinterpret_cast<int64_t*>(smem + C::BM * PITCH);
+  float* sS = reinterpret_cast<float*>(smem + C::BM * PITCH + C::BM * 8);
+#pragma unroll
+  for (int j = 0; j < C::TN; ++j) {
+    const int col = wn * (C::BN / C::WN) + j * C::MF + lc;
+    const float bv = (e.bias && n0 + col < N) ? e.bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int q = 0; q < C::ACC; ++q) {
+        const int row = wm * (C::BM / C::WM) + i * C::MF + C::acc_row(q, lane);
+        *reinterpret_cast<OTy*>(sC + row * PITCH + col * O::SZ) = O::cv(apply_act(acc[i][j][q] * e.alpha + bv, e.act));
+      }
+  }
+  for (int r = tid; r < C::BM; r += C::NT) sRow[r] = rowoff(r);
+  __syncthreads();
+  if (e.stats != nullptr) {
+    // thread -> (column, row slice); partial sums over the slice's valid rows, slices combined through LDS
+    constexpr bool WIDE = C::NT >= C::BN;                 // enough threads for several row slices per column
+    constexpr int NSL = WIDE ? C::NT / C::BN : 1;
+    constexpr int RPS = C::BM / NSL;
+    static_assert(!WIDE || C::NT % C::BN == 0, "thread count is a multiple of the tile width");
+    const int sl = WIDE ? tid / C::BN : 0;
+    for (int c = WIDE ? tid % C::BN : tid; c < C::BN; c += WIDE ? C::BN : C::NT) {
+      const float sh = (e.stat_shift && n0 + c < N) ? e.stat_shift[n0 + c] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+      for (int r = sl * RPS; r < (sl + 1) * RPS; ++r)
+        if (sRow[r] >= 0) {
+          const float v = O::fl(*reinterpret_cast<const OTy*>(sC + r * PITCH + c * O::SZ)) - sh;
+          s1 += v; s2 += v * v;
+        }
+      sS[(sl * 2 + 0) * C::BN + c] = s1;
+      sS[(sl * 2 + 1) * C::BN + c] = s2;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * C::BN; idx += C::NT) {
+      const int qs = idx / C::BN, c = idx - qs * C::BN;
+      if (n0 + c < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) s += sS[(sl * 2 + qs) * C::BN + c];
+        e.stats[((int64_t)mt * 2 + qs) * N + n0 + c] = s;
+      }
+    }
+  }
+  constexpr int EPC = 16 / O::SZ;               // elements per 16-byte chunk
+  constexpr int CPR = C::BN / EPC;
+  OTy* out = reinterpret_cast<OTy*>(e.out);
+  const OTy* res = reinterpret_cast<const OTy*>(e.residual);
+  const bool full_cols = n0 + C::BN <= N;
+  for (int idx = tid; idx < C::BM * CPR; idx += C::NT) {
+    const int row = idx / CPR, ch = idx - row * CPR;
+    const int64_t ro = sRow[row];
+    const int n = n0 + ch * EPC;
+    if (ro < 0 || n >= N) continue;
+    const int64_t o = ro + ch * EPC;
+    const char* sp = sC + row * PITCH + ch * 16;
+    if ((full_cols || n + EPC <= N) && ((reinterpret_cast<uintptr_t>(out + o) & 15) == 0)) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+      if (res != nullptr || e.accum) {
+        OTy* ve = reinterpret_cast<OTy*>(&v);
+        if (res != nullptr) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(res + o);
+          const OTy* re = reinterpret_cast<const OTy*>(&rv);
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) ve[j] = O::cv(O::fl(ve[j]) + O::fl(re[j]));
+        }
+        if (e.accum) {
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(out + o);
+          const OTy* pe = reinterpret_cast<const OTy*>(&pv);
+#pragma unroll
+          for (int j = 0; j < EPC; ++j) ve[j] = O::cv(O::fl(ve[j]) + O::fl(pe[j]));
+        }
+      }
+      *reinterpret_cast<f32x4*>(out + o) = v;
+    } else {
+      const OTy* se = reinterpret_cast<const OTy*>(sp);
+      for (int j = 0; j < EPC && n + j < N; ++j) {
+        float f = O::fl(se[j]);
+        if (res != nullptr) f += O::fl(res[o + j]);
+        if (e.accum) f += O::fl(out[o + j]);
+        out[o + j] = O::cv(f);
+      }
+    }
+  }
+}
+
+}  // namespace gemmcore

@@ -24,6 +24,15 @@ import torch.nn.functional as F
 from ..native import lib as L
 
 _FORCE = os.environ.get("DL4J_AMD_CONV", "auto")  # auto | hip | library
+_CORE = os.environ.get("DL4J_AMD_CONV_CORE", "mfma2")  # mfma2: round-2 LDS-DMA core (conv_mfma.hip) | igemm: round-1 kernels
+
+
+def _mfma_eligible(x, w):
+    """Round-2 core: bf16 / fp16 / fp32, any stride / padding / dilation, channels a multiple of 8 (fp32: 4)."""
+    if _FORCE == "library" or _CORE != "mfma2" or not L.use_hip(x, w):
+        return False
+    from . import conv_mfma
+    return conv_mfma.supported(x, w)
 
 
 def _hip_eligible(x, w, stride, padding, dilation):
@@ -48,6 +57,12 @@ def _stem_eligible(x, w, stride, padding, dilation):
 def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False):
     """x: [N,C,H,W] logical (channels_last memory on GPU). Returns (z, sums): ``sums`` is the [2K] fp32
     per-channel (sum, sum of squares) of z when the HIP path fused it into its epilogue, else None."""
+    if _stem_eligible(x, w, stride, padding, dilation) and x.shape[1] < 8:
+        from . import conv_stem
+        return conv_stem.forward(x, w, b, stride, padding, dilation, want_stats)
+    if _mfma_eligible(x, w):
+        from . import conv_mfma
+        return conv_mfma.forward(x, w, b, stride, padding, dilation, want_stats)
     if _hip_eligible(x, w, stride, padding, dilation):
         from . import conv_igemm
         return conv_igemm.forward(x, w, b, stride, padding, dilation, want_stats)
@@ -61,6 +76,9 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
                     dw_out=None, dx_accum=None, dw_prezeroed=False):
     """Returns (dx, dW, db); dW has logical shape [nOut, nIn, kH, kW] — or None when it was written
     straight into ``dw_out`` (fp32 gradient view) by the HIP wgrad kernel."""
+    if _mfma_eligible(x, w) and dz.dtype == x.dtype and not (_stem_eligible(x, w, stride, padding, dilation) and x.shape[1] < 8):
+        return _backward_mfma(dz, x, w, stride, padding, dilation, need_dx, need_dw, need_db, w_dgrad, dw_out, dx_accum,
+                              dw_prezeroed)
     if _hip_eligible(x, w, stride, padding, dilation) and dz.dtype == torch.bfloat16:
         from . import conv_igemm as IG
         dx = dW = db = None
@@ -110,3 +128,34 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
     if dx_accum is not None and dx is not None:
         dx = dx_accum + dx
     return dx, dw, db
+
+
+def _backward_mfma(dz, x, w, stride, padding, dilation, need_dx, need_dw, need_db, w_dgrad, dw_out, dx_accum, dw_prezeroed):
+    """Backward on the round-2 core: data gradient for any stride by residue classes (ops/conv_mfma.dgrad); weight gradient on the
+    split-K transposing-read kernel (bf16, 64-multiple channels) or the library for the shapes it does not cover yet."""
+    from . import conv_mfma as CM
+    from . import conv_igemm as IG
+    dx = dW = db = None
+    if not dz.is_contiguous(memory_format=torch.channels_last):
+        dz = dz.contiguous(memory_format=torch.channels_last)
+    if need_db:
+        db = dz.float().sum((0, 2, 3))
+    if need_dw:
+        if IG.supported(x, w, stride, padding, dilation):
+            from . import streams
+            if (streams.active() and dw_out is not None and dw_out.dtype == torch.float32 and dw_out.is_contiguous()):
+                with torch.cuda.stream(streams.fork(dz, x, dw_out)):
+                    IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
+            else:
+                dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
+        else:
+            dW = torch.ops.aten.convolution_backward(dz, x, w, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
+                                                     [False, True, False])[1]
+    if need_dx:
+        wd = w_dgrad if w_dgrad is not None else CM.flip_filters(w)
+        acc = dx_accum if (dx_accum is not None and dx_accum.dtype == dz.dtype and tuple(dx_accum.shape) == tuple(x.shape)
+                           and dx_accum.is_contiguous(memory_format=torch.channels_last)) else None
+        dx = CM.dgrad(dz, x.shape, wd, stride, padding, dilation, accum_into=acc)
+        if dx_accum is not None and acc is None:
+            dx = dx_accum + dx
+    return dx, dW, db

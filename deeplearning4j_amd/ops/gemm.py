@@ -1,29 +1,96 @@
-"""Hand-written MFMA GEMM entry point: y[M, N] = x[M, K] . w[N, K]^T (+ bias), bf16 in / fp32 accumulate / bf16 out.
+"""Hand-written MFMA GEMM on the LDS-DMA core (native/csrc/gemm_core.h, conv_mfma.hip):
 
-It is the implicit-GEMM convolution kernel of native/csrc/conv_igemm.hip (32x32x16 bf16 MFMA, LDS double buffering,
-XCD-aware tile order, bias epilogue) run as a 1x1 convolution over M "pixels" — the reference's MmulHelper falls back to a naive
-one-thread-per-element kernel for bf16 (helpers/cuda_off/MmulHelper.cu:41-106). Plain library GEMMs stay on hipBLASLt
-(tools/gemm_microbench.py compares the two); this entry point exists for fused uses and as the hand-written baseline.
+    y[M, N] = act(alpha * x[M, K] . w[N, K]^T + bias) (+ residual)      bf16 / fp16 / fp32 operands, fp32 accumulation
+
+``w`` is in the transposed-B ("NT") layout, i.e. exactly a dense layer's [nOut, nIn] weight. Fused epilogues (bias, ReLU / GELU / tanh /
+sigmoid, residual add, fp32 output) replace the separate elementwise launches of the reference, whose MmulHelper has no fast bf16
+path at all (helpers/cuda_off/MmulHelper.cu:255-280 -> naive kernel :41-106) and synchronises the stream after every GEMM (:347).
+Batched form ``bgemm_nt`` = helpers/cuda/batched_gemm.cu:145-193 (cublasGemmBatchedEx) for strided batches.
+Measured against hipBLASLt: profiles/r2_gemm_microbench.md.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
-from . import conv_igemm as IG
+from ..native import lib as L
+
+TILES = ((128, 128), (128, 64), (64, 64), (64, 128), (256, 256))
+_DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+ACTS = {None: 0, "identity": 0, "relu": 1, "gelu": 2, "gelu_tanh": 2, "gelu_erf": 3, "tanh": 4, "sigmoid": 5}
+
+
+def chunk(dtype):
+    return 4 if dtype == torch.float32 else 8
 
 
 def supported(x, w):
-    return (x.is_cuda and w.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
-            and x.shape[1] == w.shape[1] and x.shape[1] % 64 == 0 and w.shape[0] % 64 == 0 and x.is_contiguous() and w.is_contiguous()
-            and x.numel() < (1 << 31))
+    """2-D operands, same dtype, K-contiguous rows with 16-byte aligned starts."""
+    if not (x.is_cuda and w.is_cuda and x.dtype == w.dtype and x.dtype in _DT and x.dim() == 2 and w.dim() == 2):
+        return False
+    if x.shape[1] != w.shape[1] or x.shape[0] == 0 or w.shape[0] == 0:
+        return False
+    ch = chunk(x.dtype)
+    return (x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] % ch == 0 and x.stride(0) % ch == 0 and w.stride(0) % ch == 0
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
-def gemm_nt(x, w, bias=None):
-    """x [M, K], w [N, K] (row-major, i.e. the transposed-B layout of a dense layer's weight) -> [M, N]."""
-    assert supported(x, w), "gemm_nt: bf16 contiguous operands with K and N multiples of 64 are required"
+def pick_tile(M, N, K, dtype):
+    """Measured on MI355X with tools/gemm_lab (profiles/r2_gemm_lab_v2.txt, r2_gemm_lab_v4_pingpong.txt)."""
+    def blocks(t):
+        bm, bn = TILES[t]
+        return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+    if dtype == torch.bfloat16 and blocks(4) >= 448 and K >= 2048:
+        return 4                                  # 256x256 ping-pong: only when it fills the chip ~2x with a deep K loop
+    if blocks(0) >= 1536 and K >= 1024:
+        return 0
+    if blocks(1) >= 640:
+        return 1
+    if N >= 128 and M < 128:
+        return 3
+    return 2
+
+
+def _launch(x, w, y, bias, residual, alpha, act, M, N, K, lda, ldb, ldc, sA, sB, sC, batch, tile, out_f32):
+    d = (ctypes.c_int64 * 14)(M, N, K, lda, ldb, ldc, sA, sB, sC, batch, tile, _DT[x.dtype], 1 if out_f32 else 0, ACTS[act])
+    L.check(L.hip().dl4j_gemm_nt(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(bias), L.ptr(residual), ctypes.c_float(alpha), d, L.stream()),
+            "gemm_nt")
+
+
+def gemm_nt(x, w, bias=None, act=None, residual=None, alpha=1.0, out_dtype=None, tile=None):
+    """x [M, K], w [N, K] -> [M, N]."""
+    assert supported(x, w), "gemm_nt: same-dtype 2-D operands with K-contiguous, 16-byte aligned rows are required"
     M, K = x.shape
     N = w.shape[0]
-    x4 = x.view(M, 1, 1, K).permute(0, 3, 1, 2)           # logical [M, K, 1, 1], channels-last memory == [M, K]
-    w4 = w.view(N, 1, 1, K).permute(0, 3, 1, 2)
-    y, _ = IG.forward(x4, w4, bias, (1, 1), (0, 0), (1, 1), want_stats=False)
-    return y.permute(0, 2, 3, 1).reshape(M, N)
+    out_dtype = out_dtype or x.dtype
+    assert out_dtype in (x.dtype, torch.float32)
+    y = torch.empty(M, N, device=x.device, dtype=out_dtype)
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        bias = bias.float().contiguous()
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == out_dtype and residual.is_contiguous()
+    t = pick_tile(M, N, K, x.dtype) if tile is None else tile
+    if t == 4 and (x.dtype != torch.bfloat16 or out_dtype != torch.bfloat16):
+        t = 0
+    _launch(x, w, y, bias, residual, alpha, act, M, N, K, x.stride(0), w.stride(0), N, 0, 0, 0, 1, t, out_dtype == torch.float32
+            and x.dtype != torch.float32)
+    return y
+
+
+def bgemm_nt(a, b, alpha=1.0, out_dtype=None):
+    """a [B, M, K], b [B, N, K] (K-contiguous, uniform batch strides) -> [B, M, N]."""
+    assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.shape[2] == b.shape[2] and a.dtype == b.dtype
+    B, M, K = a.shape
+    N = b.shape[1]
+    ch = chunk(a.dtype)
+    assert a.stride(2) == 1 and b.stride(2) == 1 and K % ch == 0
+    assert all(s % ch == 0 for s in (a.stride(0), a.stride(1), b.stride(0), b.stride(1)))
+    out_dtype = out_dtype or a.dtype
+    y = torch.empty(B, M, N, device=a.device, dtype=out_dtype)
+    t = pick_tile(M, N, K, a.dtype)
+    if t == 4:
+        t = 0
+    _launch(a, b, y, None, None, alpha, None, M, N, K, a.stride(1), b.stride(1), N, a.stride(0), b.stride(0), M * N, B, t,
+            out_dtype == torch.float32 and a.dtype != torch.float32)
+    return y
