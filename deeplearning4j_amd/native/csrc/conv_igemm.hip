@@ -289,7 +289,16 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int cb, int ks, in
 // tools/wgrad_sweep.py), so a workgroup is TWO 4-wave groups: each group runs the pipelined loop over its own half of the
 // workgroup's pixel range with its own LDS buffers, the halves are summed through LDS and only one group issues the
 // atomics — half the atomic traffic for the same number of waves in flight.
-template <int BK_, int BC_>   // BK_: out-channel tile (dy), BC_: in-channel tile (x)
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <int F16>
+__device__ __forceinline__ f32x16 wg_mfma(const bf16x8_t& a, const bf16x8_t& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// F16: operands are IEEE half instead of bfloat16 (same bytes, same lane maps, the f16 MFMA). Channel counts need only be multiples
+// of 8: 16-byte chunks past K / C are fed zeros and the stores are masked.
+template <int BK_, int BC_, int F16>   // BK_: out-channel tile (dy), BC_: in-channel tile (x)
 __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
   constexpr int PA = BK_ * 2, PB = BC_ * 2;          // row pitches in bytes
   constexpr int CPA = BK_ / 8, CPB = BC_ / 8;        // 16-byte chunks per pixel row
@@ -327,14 +336,14 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
     for (int i = 0; i < NA; ++i) {
       const int pp = pb + prA + i * RPA;
       s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (pp < pend) v = *reinterpret_cast<const s16x8*>(p.dy + (int64_t)pp * p.K + k0 + chA * 8);
+      if (pp < pend && k0 + chA * 8 < p.K) v = *reinterpret_cast<const s16x8*>(p.dy + (int64_t)pp * p.K + k0 + chA * 8);
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int pp = pb + prB + i * RPB;
       s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (pp < pend) {
+      if (pp < pend && c0 + chB * 8 < p.C) {
         const int n = pp / OHW, rem = pp - n * OHW;
         const int oh = rem / p.OW, ow = rem - oh * p.OW;
         const int ih = oh * p.sh - p.ph + r * p.dh, iw = ow * p.sw - p.pw + s * p.dw_;
@@ -386,7 +395,7 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = wg_mfma<F16>(af[i], bfr[j], acc[i][j]);
     }
     if (t + 1 < nsteps) swrite(cur ^ 1);
     __syncthreads();
@@ -414,9 +423,11 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
         const int k = k0 + wm * (BK_ / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         const int c = c0 + wn * (BC_ / 2) + j * 32 + l31;
         const float v = acc[i][j][e] + xch[(((i * TN + j) * 16 + e) * 4 + wid) * 64 + lane];
-        float* dst = p.dw + ((int64_t)k * RS + rs) * p.C + c;
-        if (p.use_atomic) atomicAdd(dst, v);
-        else *dst = v;
+        if (k < p.K && c < p.C) {
+          float* dst = p.dw + ((int64_t)k * RS + rs) * p.C + c;
+          if (p.use_atomic) atomicAdd(dst, v);
+          else *dst = v;
+        }
       }
 }
 
@@ -432,10 +443,10 @@ __global__ void __launch_bounds__(256) zero_f32_scalar_kernel(float* __restrict_
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
 }
 
-template <int BK_, int BC_>
+template <int BK_, int BC_, int F16>
 static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t st) {
-  p.ktiles = p.K / BK_;
-  p.ctiles = p.C / BC_;
+  p.ktiles = (p.K + BK_ - 1) / BK_;
+  p.ctiles = (p.C + BC_ - 1) / BC_;
   const int tiles = p.ktiles * p.ctiles * p.R * p.S;
   int splits;
   if (target_blocks > 0) {
@@ -464,27 +475,44 @@ static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t
   const int smem = 2 * 2 * 64 * (BK_ + BC_) * 2;      // two groups x double buffer
   static_assert(BK_ * BC_ * 4 <= 2 * 2 * 64 * (BK_ + BC_) * 2, "exchange tile must fit the operand buffers");
   static DeviceOnceLds lds_attr;
-  lds_attr.ensure(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BK_, BC_>), smem);
-  hipLaunchKernelGGL((igemm_wgrad_kernel<BK_, BC_>), dim3(tiles * splits), dim3(512), smem, st, p);
+  lds_attr.ensure(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BK_, BC_, F16>), smem);
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BK_, BC_, F16>), dim3(tiles * splits), dim3(512), smem, st, p);
   DL4J_RET_LAST();
 }
 
 // geom = [N,H,W,C, OH,OW,K, R,S, sh,sw, ph,pw, dh,dw]; dw_out fp32 [K][R*S][C]
 // prezeroed: the caller guarantees dw_out is all zeros (flat gradient vector cleared once per iteration, or the
 // self-cleaning scratch of the 3x3 path), so the per-layer memset in front of the split-K atomics is skipped.
-DL4J_API int dl4j_igemm_wgrad(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks, int prezeroed,
-                              hipStream_t st) {
+template <int F16>
+static int dispatch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t st) {
+  const bool k128 = p.K >= 128 && (p.K % 128 == 0 || p.K > 256), c128 = p.C >= 128 && (p.C % 128 == 0 || p.C > 256);
+  if (k128 && c128) return launch_wgrad<128, 128, F16>(p, target_blocks, prezeroed, st);
+  if (k128) return launch_wgrad<128, 64, F16>(p, target_blocks, prezeroed, st);
+  if (c128) return launch_wgrad<64, 128, F16>(p, target_blocks, prezeroed, st);
+  return launch_wgrad<64, 64, F16>(p, target_blocks, prezeroed, st);
+}
+
+static int wgrad_entry(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks, int prezeroed, int f16,
+                       hipStream_t st) {
   WGradP p;
   p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw_out;
   p.N = g[0]; p.H = g[1]; p.W = g[2]; p.C = g[3]; p.OH = g[4]; p.OW = g[5]; p.K = g[6]; p.R = g[7]; p.S = g[8];
   p.sh = g[9]; p.sw = g[10]; p.ph = g[11]; p.pw = g[12]; p.dh = g[13]; p.dw_ = g[14];
-  p.P = p.N * p.OH * p.OW;
-  if (p.C % 64 != 0 || p.K % 64 != 0) return -2;
-  const bool k128 = (p.K % 128) == 0, c128 = (p.C % 128) == 0;
-  if (k128 && c128) return launch_wgrad<128, 128>(p, target_blocks, prezeroed, st);
-  if (k128) return launch_wgrad<128, 64>(p, target_blocks, prezeroed, st);
-  if (c128) return launch_wgrad<64, 128>(p, target_blocks, prezeroed, st);
-  return launch_wgrad<64, 64>(p, target_blocks, prezeroed, st);
+  const int64_t P = (int64_t)p.N * p.OH * p.OW;
+  if (p.C % 8 != 0 || p.K % 8 != 0 || P <= 0 || P > 0x7fffffff) return -2;     // 16-byte chunks inside a pixel's channel run
+  p.P = (int)P;
+  return f16 ? dispatch_wgrad<1>(p, target_blocks, prezeroed, st) : dispatch_wgrad<0>(p, target_blocks, prezeroed, st);
+}
+
+DL4J_API int dl4j_igemm_wgrad(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks, int prezeroed,
+                              hipStream_t st) {
+  return wgrad_entry(dy, x, dw_out, g, target_blocks, prezeroed, 0, st);
+}
+// same with a dtype code: 0 bf16, 1 fp16
+DL4J_API int dl4j_igemm_wgrad_dt(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks, int prezeroed,
+                                 int dtype, hipStream_t st) {
+  if (dtype != 0 && dtype != 1) return -2;
+  return wgrad_entry(dy, x, dw_out, g, target_blocks, prezeroed, dtype, st);
 }
 
 // fp32 [K][RS][C] -> [K][C][RS]  (OHWI -> DL4J OIHW gradient view)

@@ -38,20 +38,28 @@ template <class C> struct ConvSrc {
   int bd[C::PA], bh[C::PA], bw[C::PA];
   const char* bp[C::PB];
   int kchunk;
+  int CT, Cc, D, H, W;
   const ConvP* p;
-  __device__ __forceinline__ const void* a(int i, int t) const {
-    const int tap = t / p->CT;
-    const int c = (t - tap * p->CT) * C::BK + kchunk;
-    const int dd = p->tap_d[tap], dh = p->tap_h[tap], dw = p->tap_w[tap];
-    const int id = bd[i] + dd, ih = bh[i] + dh, iw = bw[i] + dw;
-    const bool ok = ((unsigned)id < (unsigned)p->D) && ((unsigned)ih < (unsigned)p->H) && ((unsigned)iw < (unsigned)p->W) && c < p->C;
-    const int64_t off = ((((int64_t)dd * p->H + dh) * p->W + dw) * p->C + c) * C::ESZ;
-    return ok ? (const void*)(ap[i] + off) : (const void*)g_zero_page;
+  struct Tile { int dd, dh, dw, c0; int64_t aoff, boff; };
+  // wave-uniform scalars of k-tile t: its tap (one kernarg table lookup) and channel offset
+  __device__ __forceinline__ Tile tile(int t) const {
+    Tile ts;
+    const int tap = (CT == 1) ? t : t / CT;
+    ts.c0 = (t - tap * CT) * C::BK;
+    ts.dd = p->tap_d[tap]; ts.dh = p->tap_h[tap]; ts.dw = p->tap_w[tap];
+    ts.aoff = ((((int64_t)ts.dd * H + ts.dh) * W + ts.dw) * Cc + ts.c0) * C::ESZ;
+    ts.boff = ((int64_t)p->tap_off[tap] + ts.c0) * C::ESZ;
+    return ts;
   }
-  __device__ __forceinline__ const void* b(int i, int t) const {
-    const int tap = t / p->CT;
-    const int c = (t - tap * p->CT) * C::BK + kchunk;
-    return c < p->C ? (const void*)(bp[i] + ((int64_t)p->tap_off[tap] + c) * C::ESZ) : (const void*)g_zero_page;
+  __device__ __forceinline__ const void* a(int i, const Tile& ts) const {
+    const int id = bd[i] + ts.dd, ih = bh[i] + ts.dh, iw = bw[i] + ts.dw;
+    // bitwise, not short-circuit: a branch per staged row would split the DMA issue stream
+    const bool ok = (int)((unsigned)id < (unsigned)D) & (int)((unsigned)ih < (unsigned)H) & (int)((unsigned)iw < (unsigned)W) &
+                    (int)(ts.c0 + kchunk < Cc);
+    return ok ? (const void*)(ap[i] + ts.aoff) : (const void*)g_zero_page;
+  }
+  __device__ __forceinline__ const void* b(int i, const Tile& ts) const {
+    return ts.c0 + kchunk < Cc ? (const void*)(bp[i] + ts.boff) : (const void*)g_zero_page;
   }
 };
 
@@ -66,6 +74,7 @@ __global__ void __launch_bounds__(C::NT) conv_igemm_kernel(const ConvP p) {
 
   ConvSrc<C> src;
   src.p = &p;
+  src.CT = p.CT; src.Cc = p.C; src.D = p.D; src.H = p.H; src.W = p.W;
   src.kchunk = stage_chunk(stage_row<C>(0)) * C::CH;
 #pragma unroll
   for (int i = 0; i < C::PA; ++i) {
@@ -75,7 +84,7 @@ __global__ void __launch_bounds__(C::NT) conv_igemm_kernel(const ConvP p) {
       const int od = rem / OHW; rem -= od * OHW;
       const int oh = rem / p.OW, ow = rem - oh * p.OW;
       src.bd[i] = od * p.sd - p.pd; src.bh[i] = oh * p.sh - p.ph; src.bw[i] = ow * p.sw - p.pw;
-      src.ap[i] = (const char*)p.x + ((((int64_t)n * p.D + src.bd[i]) * p.H + src.bh[i]) * p.W + src.bw[i]) * p.C * C::ESZ;
+      src.ap[i] = (const char*)p.x + (((((int64_t)n * p.D + src.bd[i]) * p.H + src.bh[i]) * p.W + src.bw[i]) * p.C + src.kchunk) * C::ESZ;
     } else {
       src.bd[i] = src.bh[i] = src.bw[i] = -(1 << 24);     // every tap out of range: the row is fed zeros and never stored
       src.ap[i] = (const char*)p.x;
@@ -85,12 +94,12 @@ __global__ void __launch_bounds__(C::NT) conv_igemm_kernel(const ConvP p) {
   for (int i = 0; i < C::PB; ++i) {
     int n = n0 + stage_row<C>(i);
     if (n > p.K - 1) n = p.K - 1;
-    src.bp[i] = (const char*)p.w + (int64_t)n * p.wrow * C::ESZ;
+    src.bp[i] = (const char*)p.w + ((int64_t)n * p.wrow + src.kchunk) * C::ESZ;
   }
   typename C::acc_t acc[C::TM][C::TN];
   mainloop<C>(smem, src, p.ntaps * p.CT, acc);
 
-  epilogue<C, OT>(smem, acc, mt, n0, p.K, p.epi, [&](int r) -> int64_t {
+  epilogue<C, OT>(smem, acc, mt, n0, p.K, p.M - m0, p.epi, [&](int r) -> int64_t {
     const int m = m0 + r;
     if (m >= p.M) return (int64_t)-1;
     const int n = m / ODHW; int rem = m - n * ODHW;
@@ -119,6 +128,16 @@ static const int kTiles[][2] = {{128, 128}, {128, 64}, {64, 64}, {64, 128}, {256
 
 template <int DT, int OT>
 static int dispatch_conv(ConvP& p, int tile, hipStream_t st) {
+  // a single k-tile (1x1 conv with C <= BK): one LDS stage, so more workgroups are resident to overlap their load and store phases
+  if (p.ntaps * ((p.C + (DT == DT_F32 ? 32 : 64) - 1) / (DT == DT_F32 ? 32 : 64)) == 1) {
+    switch (tile) {
+      case 0: return launch_conv<Cfg<128, 128, 2, 2, 1, 16, DT>, OT>(p, st);
+      case 1: return launch_conv<Cfg<128, 64, 2, 2, 1, 16, DT>, OT>(p, st);
+      case 2: return launch_conv<Cfg<64, 64, 2, 2, 1, 16, DT>, OT>(p, st);
+      case 3: return launch_conv<Cfg<64, 128, 2, 2, 1, 16, DT>, OT>(p, st);
+      default: return -2;
+    }
+  }
   switch (tile) {
     case 0: return launch_conv<Cfg<128, 128, 2, 2, 2, 16, DT>, OT>(p, st);
     case 1: return launch_conv<Cfg<128, 64, 2, 2, 2, 16, DT>, OT>(p, st);
@@ -175,6 +194,15 @@ DL4J_API int dl4j_mfma_tile_dims(int tile, int* bm, int* bn) {
 // ------------------------------------------------------------------------------------------------------------------ GEMM
 template <int DT, int OT>
 static int dispatch_gemm(GemmP& p, int tile, int batch, hipStream_t st) {
+  if (p.K <= (DT == DT_F32 ? 32 : 64)) {
+    switch (tile) {
+      case 0: return launch_gemm<Cfg<128, 128, 2, 2, 1, 16, DT>, OT>(p, batch, st);
+      case 1: return launch_gemm<Cfg<128, 64, 2, 2, 1, 16, DT>, OT>(p, batch, st);
+      case 2: return launch_gemm<Cfg<64, 64, 2, 2, 1, 16, DT>, OT>(p, batch, st);
+      case 3: return launch_gemm<Cfg<64, 128, 2, 2, 1, 16, DT>, OT>(p, batch, st);
+      default: break;
+    }
+  }
   switch (tile) {
     case 0: return launch_gemm<Cfg<128, 128, 2, 2, 2, 16, DT>, OT>(p, batch, st);
     case 1: return launch_gemm<Cfg<128, 64, 2, 2, 2, 16, DT>, OT>(p, batch, st);
@@ -188,12 +216,27 @@ static int dispatch_gemm(GemmP& p, int tile, int batch, hipStream_t st) {
 }
 
 // C[b] = act(alpha * A[b] . B[b]^T + bias) (+ residual[b]);  dims (int64): M N K lda ldb ldc sA sB sC batch tile dtype out_f32 act
+static int gemm_entry(const void* A, const void* B, void* Cout, const float* bias, const void* residual, float alpha, float* stats,
+                      const float* stat_shift, int accum, const int64_t* d, hipStream_t st);
+
 DL4J_API int dl4j_gemm_nt(const void* A, const void* B, void* Cout, const float* bias, const void* residual, float alpha,
                           const int64_t* d, hipStream_t st) {
+  return gemm_entry(A, B, Cout, bias, residual, alpha, nullptr, nullptr, 0, d, st);
+}
+
+// + per-M-tile column statistics of the rounded output ([mtiles][2][N], optionally of out - stat_shift) and in-place accumulation:
+// the 1x1 / stride 1 convolution (x channels-last IS an [N*H*W, C] matrix) with its BatchNorm-statistics epilogue
+DL4J_API int dl4j_gemm_nt_ex(const void* A, const void* B, void* Cout, const float* bias, const void* residual, float alpha,
+                             float* stats, const float* stat_shift, int accum, const int64_t* d, hipStream_t st) {
+  return gemm_entry(A, B, Cout, bias, residual, alpha, stats, stat_shift, accum, d, st);
+}
+
+static int gemm_entry(const void* A, const void* B, void* Cout, const float* bias, const void* residual, float alpha, float* stats,
+                      const float* stat_shift, int accum, const int64_t* d, hipStream_t st) {
   GemmP p;
   p.A = A; p.B = B;
-  p.epi.out = Cout; p.epi.residual = residual; p.epi.bias = bias; p.epi.stats = nullptr; p.epi.stat_shift = nullptr;
-  p.epi.alpha = alpha; p.epi.act = (int)d[13]; p.epi.accum = 0;
+  p.epi.out = Cout; p.epi.residual = residual; p.epi.bias = bias; p.epi.stats = stats; p.epi.stat_shift = stat_shift;
+  p.epi.alpha = alpha; p.epi.act = (int)d[13]; p.epi.accum = accum;
   p.M = (int)d[0]; p.N = (int)d[1]; p.K = (int)d[2];
   p.lda = d[3]; p.ldb = d[4]; p.ldc = d[5]; p.sA = d[6]; p.sB = d[7]; p.sC = d[8];
   p.gm = 0;

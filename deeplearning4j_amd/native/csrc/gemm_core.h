@@ -66,7 +66,7 @@ struct Cfg {
   // epilogue staging: output tile in the OUTPUT element size (row pitch padded by 16 bytes), one int64 row address per tile row,
   // and the per-slice column sums of the fused BatchNorm statistics
   static constexpr int pitch_c(int osz) { return BN * osz + 16; }
-  static constexpr int epi_bytes(int osz) { return BM * pitch_c(osz) + BM * 8 + 2 * NT * 4; }
+  static constexpr int epi_bytes(int osz) { return BM * pitch_c(osz) + BM * 8 + WM * 2 * BN * 4; }
   static constexpr int lds_bytes(int osz) {
     return STAGES * STAGE_BYTES > epi_bytes(osz) ? STAGES * STAGE_BYTES : epi_bytes(osz);
   }
@@ -102,7 +102,7 @@ __device__ __forceinline__ void mma(const bf16x8_t& a, const bf16x8_t& b, typena
 }
 
 // Main loop shared by GEMM and implicit-GEMM convolution. `Src` provides, per k-tile t, the source address of this lane's 16-byte
-// chunk for staged row i of A / B:  const void* a(int i, int t),  const void* b(int i, int t).
+// chunk for staged row i of A / B:  auto ts = tile(t) (wave-uniform scalars of the tile), const void* a(int i, ts), const void* b(int i, ts).
 template <class C, class Src>
 __device__ __forceinline__ void mainloop(char* smem, const Src& src, int KT, typename C::acc_t (&acc)[C::TM][C::TN]) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -118,10 +118,11 @@ __device__ __forceinline__ void mainloop(char* smem, const Src& src, int KT, typ
 
   auto stage = [&](int t) {
     char* sb = smem + (t % C::STAGES) * C::STAGE_BYTES;
+    const auto ts = src.tile(t);          // wave-uniform per-tile scalars (tap, channel offset ...) computed ONCE per k-tile
 #pragma unroll
-    for (int i = 0; i < C::PA; ++i) glds16(src.a(i, t), sb + (wid + i * C::NW) * 1024);
+    for (int i = 0; i < C::PA; ++i) glds16(src.a(i, ts), sb + (wid + i * C::NW) * 1024);
 #pragma unroll
-    for (int i = 0; i < C::PB; ++i) glds16(src.b(i, t), sb + C::A_BYTES + (wid + i * C::NW) * 1024);
+    for (int i = 0; i < C::PB; ++i) glds16(src.b(i, ts), sb + C::A_BYTES + (wid + i * C::NW) * 1024);
   };
 
   // per-lane fragment read offsets inside an MF-row block: row lr, 16-byte chunk q, swizzled by (row >> 1) & 7.
@@ -199,13 +200,15 @@ __device__ __forceinline__ void mainloop_pingpong(char* smem, const Src& src, in
 
   auto stage_a = [&](int t) {
     char* sb = smem + (t & 1) * C::STAGE_BYTES;
+    const auto ts = src.tile(t);
 #pragma unroll
-    for (int i = 0; i < C::PA; ++i) glds16(src.a(i, t), sb + (wid + i * C::NW) * 1024);
+    for (int i = 0; i < C::PA; ++i) glds16(src.a(i, ts), sb + (wid + i * C::NW) * 1024);
   };
   auto stage_b = [&](int t) {
     char* sb = smem + (t & 1) * C::STAGE_BYTES + C::A_BYTES;
+    const auto ts = src.tile(t);
 #pragma unroll
-    for (int i = 0; i < C::PB; ++i) glds16(src.b(i, t), sb + (wid + i * C::NW) * 1024);
+    for (int i = 0; i < C::PB; ++i) glds16(src.b(i, ts), sb + (wid + i * C::NW) * 1024);
   };
   const int lr = lane & 15, lq = lane >> 4, sw = (lr >> 1) & 7;
   int foff[2];

@@ -50,8 +50,9 @@ struct EpiP {
 };
 
 // RowOff: int64 element offset of tile row r's first column (n0) in `out`, or -1 when the row is out of range.
+// vrows: number of valid rows of this tile (rows >= vrows are padding: excluded from the statistics, never stored).
 template <class C, int OT, class RowOff>
-__device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C::TM][C::TN], int mt, int n0, int N,
+__device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C::TM][C::TN], int mt, int n0, int N, int vrows,
                                          const EpiP& e, RowOff rowoff) {
   typedef Out<OT> O;
   typedef typename O::T OTy;
@@ -62,45 +63,46 @@ __device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C:
   char* sC = smem;
   int64_t* sRow = reinterpret_cast<int64_t*>(smem + C::BM * PITCH);
   float* sS = reinterpret_cast<float*>(smem + C::BM * PITCH + C::BM * 8);
+  // statistics straight from the accumulator registers: a lane owns one column of every block, so the column sums are a sum over
+  // its registers and row blocks, then over the lanes that share the column (xor 16 / 32), then over the wave rows through LDS
+  const bool want_stats = e.stats != nullptr;
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) {
     const int col = wn * (C::BN / C::WN) + j * C::MF + lc;
-    const float bv = (e.bias && n0 + col < N) ? e.bias[n0 + col] : 0.f;
+    const bool cok = n0 + col < N;
+    const float bv = (e.bias && cok) ? e.bias[n0 + col] : 0.f;
+    const float sh = (want_stats && e.stat_shift && cok) ? e.stat_shift[n0 + col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
       for (int q = 0; q < C::ACC; ++q) {
         const int row = wm * (C::BM / C::WM) + i * C::MF + C::acc_row(q, lane);
-        *reinterpret_cast<OTy*>(sC + row * PITCH + col * O::SZ) = O::cv(apply_act(acc[i][j][q] * e.alpha + bv, e.act));
+        const OTy o = O::cv(apply_act(acc[i][j][q] * e.alpha + bv, e.act));
+        *reinterpret_cast<OTy*>(sC + row * PITCH + col * O::SZ) = o;
+        if (want_stats) {
+          const float v = row < vrows ? O::fl(o) - sh : 0.f;
+          s1 += v; s2 += v * v;
+        }
       }
+    if (want_stats) {
+      if (C::MF == 16) { s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); }
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (lane < C::MF) {
+        sS[(wm * 2 + 0) * C::BN + col] = s1;
+        sS[(wm * 2 + 1) * C::BN + col] = s2;
+      }
+    }
   }
   for (int r = tid; r < C::BM; r += C::NT) sRow[r] = rowoff(r);
   __syncthreads();
-  if (e.stats != nullptr) {
-    // thread -> (column, row slice); partial sums over the slice's valid rows, slices combined through LDS
-    constexpr bool WIDE = C::NT >= C::BN;                 // enough threads for several row slices per column
-    constexpr int NSL = WIDE ? C::NT / C::BN : 1;
-    constexpr int RPS = C::BM / NSL;
-    static_assert(!WIDE || C::NT % C::BN == 0, "thread count is a multiple of the tile width");
-    const int sl = WIDE ? tid / C::BN : 0;
-    for (int c = WIDE ? tid % C::BN : tid; c < C::BN; c += WIDE ? C::BN : C::NT) {
-      const float sh = (e.stat_shift && n0 + c < N) ? e.stat_shift[n0 + c] : 0.f;
-      float s1 = 0.f, s2 = 0.f;
-      for (int r = sl * RPS; r < (sl + 1) * RPS; ++r)
-        if (sRow[r] >= 0) {
-          const float v = O::fl(*reinterpret_cast<const OTy*>(sC + r * PITCH + c * O::SZ)) - sh;
-          s1 += v; s2 += v * v;
-        }
-      sS[(sl * 2 + 0) * C::BN + c] = s1;
-      sS[(sl * 2 + 1) * C::BN + c] = s2;
-    }
-    __syncthreads();
+  if (want_stats) {
     for (int idx = tid; idx < 2 * C::BN; idx += C::NT) {
       const int qs = idx / C::BN, c = idx - qs * C::BN;
       if (n0 + c < N) {
         float s = 0.f;
 #pragma unroll
-        for (int sl = 0; sl < NSL; ++sl) s += sS[(sl * 2 + qs) * C::BN + c];
+        for (int w_ = 0; w_ < C::WM; ++w_) s += sS[(w_ * 2 + qs) * C::BN + c];
         e.stats[((int64_t)mt * 2 + qs) * N + n0 + c] = s;
       }
     }

@@ -20,12 +20,13 @@ template <class C> struct PlainSrc {
   const char* bp[C::PB];
   int kchunk;      // first k of this lane's 16-byte chunk inside a k-tile
   int K;
-  __device__ __forceinline__ const void* a(int i, int t) const {
-    const int k = t * C::BK + kchunk;
+  __device__ __forceinline__ int tile(int t) const { return t * C::BK; }
+  __device__ __forceinline__ const void* a(int i, int k0) const {
+    const int k = k0 + kchunk;
     return k < K ? (const void*)(ap[i] + (int64_t)k * C::ESZ) : (const void*)g_zero_page;
   }
-  __device__ __forceinline__ const void* b(int i, int t) const {
-    const int k = t * C::BK + kchunk;
+  __device__ __forceinline__ const void* b(int i, int k0) const {
+    const int k = k0 + kchunk;
     return k < K ? (const void*)(bp[i] + (int64_t)k * C::ESZ) : (const void*)g_zero_page;
   }
 };
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(C::NT) gemm_nt_kernel(const GemmP p) {
   if (e.residual) e.residual = (const char*)e.residual + boff * Out<OT>::SZ;
   const int M = p.M;
   const int64_t ldc = p.ldc;
-  epilogue<C, OT>(smem, acc, mt, n0, p.N, e, [=](int r) -> int64_t {
+  epilogue<C, OT>(smem, acc, mt, n0, p.N, M - m0, e, [=](int r) -> int64_t {
     const int m = m0 + r;
     return m < M ? (int64_t)m * ldc + n0 : (int64_t)-1;
   });

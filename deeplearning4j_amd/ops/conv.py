@@ -24,15 +24,31 @@ import torch.nn.functional as F
 from ..native import lib as L
 
 _FORCE = os.environ.get("DL4J_AMD_CONV", "auto")  # auto | hip | library
-_CORE = os.environ.get("DL4J_AMD_CONV_CORE", "mfma2")  # mfma2: round-2 LDS-DMA core (conv_mfma.hip) | igemm: round-1 kernels
+# auto: per shape the faster of the two hand-written families (tools/conv_core_compare.py, profiles/r2_conv_core_compare.md): the
+#       round-1 register-staged kernels for bf16 layers with 64-multiple channels (stride 1, or strided 1x1), the round-2 LDS-DMA
+#       core for everything round 1 cannot run (fp16 / fp32, other channel counts, strided KxK data gradients, 1-D / 3-D);
+#       mfma2 / igemm force one family
+_CORE = os.environ.get("DL4J_AMD_CONV_CORE", "auto")
 
 
 def _mfma_eligible(x, w):
     """Round-2 core: bf16 / fp16 / fp32, any stride / padding / dilation, channels a multiple of 8 (fp32: 4)."""
-    if _FORCE == "library" or _CORE != "mfma2" or not L.use_hip(x, w):
+    if _FORCE == "library" or _CORE == "igemm" or not L.use_hip(x, w):
         return False
     from . import conv_mfma
     return conv_mfma.supported(x, w)
+
+
+def _prefer_r1(x, w, stride, padding, dilation):
+    """auto mode: shapes where the round-1 kernels measured faster."""
+    if _CORE != "auto" or not _hip_eligible(x, w, stride, padding, dilation):
+        return False
+    from . import conv_igemm
+    if not conv_igemm.dgrad_supported(w, stride, padding):
+        return False
+    # measured in the full training step (profiles/r2_conv_core_compare.md): 10.26 ms with the round-1 kernels on every eligible
+    # layer, 10.64 ms with the 1x1 stride-1 layers on the GEMM form of the new core, 11.98 ms with every layer on the new core
+    return True
 
 
 def _hip_eligible(x, w, stride, padding, dilation):
@@ -60,7 +76,7 @@ def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False):
     if _stem_eligible(x, w, stride, padding, dilation) and x.shape[1] < 8:
         from . import conv_stem
         return conv_stem.forward(x, w, b, stride, padding, dilation, want_stats)
-    if _mfma_eligible(x, w):
+    if _mfma_eligible(x, w) and not _prefer_r1(x, w, stride, padding, dilation):
         from . import conv_mfma
         return conv_mfma.forward(x, w, b, stride, padding, dilation, want_stats)
     if _hip_eligible(x, w, stride, padding, dilation):
@@ -76,7 +92,8 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
                     dw_out=None, dx_accum=None, dw_prezeroed=False):
     """Returns (dx, dW, db); dW has logical shape [nOut, nIn, kH, kW] — or None when it was written
     straight into ``dw_out`` (fp32 gradient view) by the HIP wgrad kernel."""
-    if _mfma_eligible(x, w) and dz.dtype == x.dtype and not (_stem_eligible(x, w, stride, padding, dilation) and x.shape[1] < 8):
+    if _mfma_eligible(x, w) and dz.dtype == x.dtype and not _prefer_r1(x, w, stride, padding, dilation) \
+            and not (_stem_eligible(x, w, stride, padding, dilation) and x.shape[1] < 8):
         return _backward_mfma(dz, x, w, stride, padding, dilation, need_dx, need_dw, need_db, w_dgrad, dw_out, dx_accum,
                               dw_prezeroed)
     if _hip_eligible(x, w, stride, padding, dilation) and dz.dtype == torch.bfloat16:
@@ -141,7 +158,7 @@ def _backward_mfma(dz, x, w, stride, padding, dilation, need_dx, need_dw, need_d
     if need_db:
         db = dz.float().sum((0, 2, 3))
     if need_dw:
-        if IG.supported(x, w, stride, padding, dilation):
+        if IG.wgrad_supported(x, w):
             from . import streams
             if (streams.active() and dw_out is not None and dw_out.dtype == torch.float32 and dw_out.is_contiguous()):
                 with torch.cuda.stream(streams.fork(dz, x, dw_out)):

@@ -117,6 +117,17 @@ def forward(x, w, b, stride, padding, dilation, want_stats=False):
     return y, sums
 
 
+def wgrad_supported(x, w):
+    """Split-K weight gradient kernels: bf16 / fp16 (transposing-read MFMA kernel) or fp32 (exact fp32 MFMA kernel) channels-last
+    activations; channel counts multiples of 8 (fp32: 4)."""
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and w.dtype == x.dtype and x.dim() == 4):
+        return False
+    K, C = w.shape[0], w.shape[1]
+    ch = 4 if x.dtype == torch.float32 else 8
+    return (C % ch == 0 and K % ch == 0 and x.shape[1] == C and x.is_contiguous(memory_format=torch.channels_last)
+            and x.numel() <= _MAX_ELEMS and x.data_ptr() % 16 == 0)
+
+
 def dgrad_supported(w, stride, padding):
     R, S = w.shape[2], w.shape[3]
     if tuple(stride) == (1, 1):
@@ -172,14 +183,27 @@ def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=
         tgt = dw_out
     g = (ctypes.c_int * 15)(N, H, W, C, OH, OW, K, R, S, stride[0], stride[1], padding[0], padding[1], dilation[0],
                             dilation[1])
-    if R * S == 1:
-        L.check(L.hip().dl4j_igemm_wgrad(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks),
-                                         L.c_int(1 if (prezeroed and tgt is dw_out) else 0), L.stream()), "igemm_wgrad")
+    dt = L.c_int(1 if x.dtype == torch.float16 else 0)
+    if dz.dtype != x.dtype:
+        dz = dz.to(x.dtype)
+    if x.dtype == torch.float32:
+        if R * S == 1:
+            L.check(L.hip().dl4j_wgrad_f32(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(1 if (prezeroed and tgt is dw_out) else 0),
+                                           L.stream()), "wgrad_f32")
+        else:
+            scratch = _ws(K * R * S * C, x.device, "igemm_wgrad")
+            L.check(L.hip().dl4j_wgrad_f32(L.ptr(dz), L.ptr(x), L.ptr(scratch), g, L.c_int(1), L.stream()), "wgrad_f32")
+            # single-split launches overwrite instead of accumulating: either way the transposer re-zeroes what it read
+            L.check(L.hip().dl4j_ohwi_to_oihw(L.ptr(scratch), L.ptr(tgt), L.c_int(K), L.c_int(R * S), L.c_int(C), L.c_int(1),
+                                              L.stream()), "ohwi_to_oihw")
+    elif R * S == 1:
+        L.check(L.hip().dl4j_igemm_wgrad_dt(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks),
+                                            L.c_int(1 if (prezeroed and tgt is dw_out) else 0), dt, L.stream()), "igemm_wgrad")
     else:
         # scratch starts zeroed and the layout transposer re-zeroes exactly what it read: no memset per layer
         scratch = _ws(K * R * S * C, x.device, "igemm_wgrad")
-        L.check(L.hip().dl4j_igemm_wgrad(L.ptr(dz), L.ptr(x), L.ptr(scratch), g, L.c_int(target_blocks), L.c_int(1), L.stream()),
-                "igemm_wgrad")
+        L.check(L.hip().dl4j_igemm_wgrad_dt(L.ptr(dz), L.ptr(x), L.ptr(scratch), g, L.c_int(target_blocks), L.c_int(1), dt,
+                                            L.stream()), "igemm_wgrad")
         L.check(L.hip().dl4j_ohwi_to_oihw(L.ptr(scratch), L.ptr(tgt), L.c_int(K), L.c_int(R * S), L.c_int(C), L.c_int(1),
                                           L.stream()), "ohwi_to_oihw")
     if ret is not None and dw_out is not None:

@@ -155,6 +155,19 @@ def forward(x, w, b, stride, padding, dilation, want_stats=False, stat_shift=Non
     ksz = _triple(w.shape[2:], 1)
     st, pd, dl = _triple(stride, 1), _triple(padding, 0), _triple(dilation, 1)
     osz = tuple(out_size(isz[i], ksz[i], st[i], pd[i], dl[i]) for i in range(3))
+    if ksz == (1, 1, 1) and st == (1, 1, 1) and pd == (0, 0, 0) and act == 0:
+        # 1x1 / stride 1: channels-last x IS the [N*spatial, C] matrix -> plain NT GEMM kernel (no gather, no tap table)
+        from . import gemm as G
+        M = N * isz[0] * isz[1] * isz[2]
+        y = _empty_cl((N, K) + isz[3 - nd:], x.dtype, x.device)
+        x2 = x.permute(0, *range(2, 2 + nd), 1).reshape(M, C)
+        w2 = w.reshape(K, C) if w.is_contiguous() else w.permute(0, *range(2, 2 + nd), 1).reshape(K, C)
+        y2 = y.permute(0, *range(2, 2 + nd), 1).reshape(M, K)
+        assert x2.data_ptr() == x.data_ptr() and y2.data_ptr() == y.data_ptr() and w2.data_ptr() == w.data_ptr()
+        tile = pick_tile(M, K, C)
+        bias = b.float().contiguous() if b is not None else None
+        stats = G.gemm_nt_stats(x2, w2, y2, bias, tile, want_stats, stat_shift)
+        return y, (StatPartials(stats, mtiles(M, tile), K, stat_shift) if want_stats else None)
     key = ("f", N, C, K, isz, ksz, st, pd, dl, x.dtype, act)
     d = _DESC.get(key)
     if d is None:
@@ -197,6 +210,14 @@ def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation, accum_into=None):
             dz.permute(0, 2, 1).contiguous().permute(0, 2, 1)
     acc = accum_into is not None
     dx = accum_into if acc else _empty_cl(tuple(x_shape), dz.dtype, dz.device)
+    if ksz == (1, 1, 1) and st == (1, 1, 1) and pd == (0, 0, 0):
+        from . import gemm as G
+        M = N * isz[0] * isz[1] * isz[2]
+        dz2 = dz.permute(0, *range(2, 2 + nd), 1).reshape(M, K)
+        dx2 = dx.permute(0, *range(2, 2 + nd), 1).reshape(M, C)
+        assert dz2.data_ptr() == dz.data_ptr() and dx2.data_ptr() == dx.data_ptr()
+        G.gemm_nt_stats(dz2, w_dgrad.reshape(C, K), dx2, None, pick_tile(M, C, K), False, None, accum=acc)
+        return dx
     wrow = ksz[0] * ksz[1] * ksz[2] * K
     for ca in range(st[0]):
         for cb in range(st[1]):

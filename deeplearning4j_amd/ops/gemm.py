@@ -52,10 +52,24 @@ def pick_tile(M, N, K, dtype):
     return 2
 
 
-def _launch(x, w, y, bias, residual, alpha, act, M, N, K, lda, ldb, ldc, sA, sB, sC, batch, tile, out_f32):
+def _launch(x, w, y, bias, residual, alpha, act, M, N, K, lda, ldb, ldc, sA, sB, sC, batch, tile, out_f32, stats=None,
+            stat_shift=None, accum=False):
     d = (ctypes.c_int64 * 14)(M, N, K, lda, ldb, ldc, sA, sB, sC, batch, tile, _DT[x.dtype], 1 if out_f32 else 0, ACTS[act])
-    L.check(L.hip().dl4j_gemm_nt(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(bias), L.ptr(residual), ctypes.c_float(alpha), d, L.stream()),
-            "gemm_nt")
+    L.check(L.hip().dl4j_gemm_nt_ex(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(bias), L.ptr(residual), ctypes.c_float(alpha),
+                                    L.ptr(stats), L.ptr(stat_shift), L.c_int(1 if accum else 0), d, L.stream()), "gemm_nt")
+
+
+def gemm_nt_stats(x, w, y, bias, tile, want_stats, stat_shift=None, accum=False):
+    """y[M, N] (preallocated, row stride N) = x . w^T + bias, optionally with the per-M-tile column statistics of the rounded output
+    (returns the [mtiles, 2, N] fp32 partials) — the 1x1 / stride-1 convolution path of ops/conv_mfma.py."""
+    M, K = x.shape
+    N = w.shape[0]
+    stats = None
+    if want_stats:
+        bm = TILES[tile][0]
+        stats = torch.empty(((M + bm - 1) // bm) * 2 * N, device=x.device, dtype=torch.float32)
+    _launch(x, w, y, bias, None, 1.0, None, M, N, K, x.stride(0), w.stride(0), N, 0, 0, 0, 1, tile, False, stats, stat_shift, accum)
+    return stats
 
 
 def gemm_nt(x, w, bias=None, act=None, residual=None, alpha=1.0, out_dtype=None, tile=None):

@@ -33,10 +33,10 @@ __global__ void cmp_kernel(const bf16_t* C, const float* R, int64_t n, float* ma
 }
 
 struct Variant { const char* name; int (*launch)(GemmP&, int, hipStream_t); int bm, bn, gm; };
-#define V(bm, bn, wm, wn, st, mf, gm) {#bm "x" #bn "_w" #wm "x" #wn "_s" #st "_mf" #mf "_g" #gm, &launch_gemm<Cfg<bm, bn, wm, wn, st, mf>>, bm, bn, gm}
+#define V(bm, bn, wm, wn, st, mf, gm) {#bm "x" #bn "_w" #wm "x" #wn "_s" #st "_mf" #mf "_g" #gm, &launch_gemm<Cfg<bm, bn, wm, wn, st, mf>, OT_BF16>, bm, bn, gm}
 static Variant variants[] = {
-  {"256x256_pingpong_g4", &launch_gemm<Cfg<256, 256, 2, 4, 2, 16>, true>, 256, 256, 4},
-  {"256x256_pingpong_g8", &launch_gemm<Cfg<256, 256, 2, 4, 2, 16>, true>, 256, 256, 8},
+  {"256x256_pingpong_g4", &launch_gemm<Cfg<256, 256, 2, 4, 2, 16>, OT_BF16, true>, 256, 256, 4},
+  {"256x256_pingpong_g8", &launch_gemm<Cfg<256, 256, 2, 4, 2, 16>, OT_BF16, true>, 256, 256, 8},
   V(256, 256, 2, 4, 2, 32, 1), V(256, 256, 2, 4, 2, 32, 4), V(256, 256, 2, 4, 2, 16, 4), V(256, 256, 2, 4, 2, 16, 8),
   V(256, 128, 4, 2, 3, 32, 4), V(256, 128, 4, 2, 3, 16, 4), V(256, 128, 4, 2, 2, 16, 4), V(128, 256, 2, 4, 3, 16, 4),
   V(128, 128, 2, 2, 2, 32, 4), V(128, 128, 2, 2, 2, 16, 4), V(128, 128, 2, 2, 2, 16, 8),
@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
       if (vfilter[0] && !strstr(v.name, vfilter)) continue;
       if (v.launch == nullptr) continue;
       if ((s.K + 63) / 64 > 1 && strstr(v.name, "_s1_")) continue;     // single-stage build is for one k-tile only
-      GemmP p{}; p.gm = v.gm; p.A = A; p.B = B; p.C = C; p.M = s.M; p.N = s.N; p.K = s.K; p.lda = s.K; p.ldb = s.K; p.ldc = s.N; p.alpha = 1.f;
+      GemmP p{}; p.gm = v.gm; p.A = A; p.B = B; p.epi.out = C; p.epi.alpha = 1.f; p.M = s.M; p.N = s.N; p.K = s.K; p.lda = s.K; p.ldb = s.K; p.ldc = s.N;
       CK(hipMemsetAsync(C, 0, nc * 2, st));
       int rc = v.launch(p, 1, st);
       if (rc) { printf("  %-18s launch rc=%d\n", v.name, rc); continue; }
