@@ -8,8 +8,11 @@
 #include "common.h"
 #include <stdlib.h>
 
+struct f16_t { _Float16 v; };     // IEEE half activations (DL4J network dtype HALF); distinct type so the templates can dispatch
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 template <typename T> struct VecOf;
 template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
+template <> struct VecOf<f16_t> { static constexpr int N = 8; };
 template <> struct VecOf<float> { static constexpr int N = 4; };
 
 template <typename T, int V>
@@ -28,6 +31,14 @@ __device__ __forceinline__ void load_vec<float, 4>(const float* p, float (&o)[4]
 }
 template <>
 __device__ __forceinline__ void load_vec<bf16_t, 1>(const bf16_t* p, float (&o)[1]) { o[0] = bf2f(*p); }
+template <>
+__device__ __forceinline__ void load_vec<f16_t, 8>(const f16_t* p, float (&o)[8]) {
+  const f16x8v v = *reinterpret_cast<const f16x8v*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+}
+template <>
+__device__ __forceinline__ void load_vec<f16_t, 1>(const f16_t* p, float (&o)[1]) { o[0] = (float)p->v; }
 template <>
 __device__ __forceinline__ void load_vec<float, 1>(const float* p, float (&o)[1]) { o[0] = *p; }
 
@@ -49,6 +60,15 @@ __device__ __forceinline__ void store_vec<float, 4>(float* p, const float (&o)[4
 }
 template <>
 __device__ __forceinline__ void store_vec<bf16_t, 1>(bf16_t* p, const float (&o)[1]) { *p = f2bf(o[0]); }
+template <>
+__device__ __forceinline__ void store_vec<f16_t, 8>(f16_t* p, const float (&o)[8]) {
+  f16x8v v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (_Float16)o[j];
+  *reinterpret_cast<f16x8v*>(p) = v;
+}
+template <>
+__device__ __forceinline__ void store_vec<f16_t, 1>(f16_t* p, const float (&o)[1]) { p->v = (_Float16)o[0]; }
 template <>
 __device__ __forceinline__ void store_vec<float, 1>(float* p, const float (&o)[1]) { *p = o[0]; }
 
@@ -490,7 +510,7 @@ static int launch_bwd_dx(const void* x, const void* dy, const void* out, const f
   DL4J_RET_LAST();
 }
 
-// dtype codes: 0 = fp32, 1 = bf16
+// dtype codes: 0 = fp32, 1 = bf16, 2 = fp16
 DL4J_API int64_t dl4j_bn_ws_floats(int C) { return colreduce_ws_floats(C); }
 
 // Reduce [gy][2][C] partials (e.g. produced by the conv epilogue) to sums[2C].
@@ -506,6 +526,9 @@ DL4J_API int dl4j_bn_stats(const void* x, float* partial_ws, float* sums, int64_
   if (dtype == 1)
     return launch_colreduce<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, partial_ws, sums, nullptr,
                                        nullptr, M, C, st);
+  if (dtype == 2)
+    return launch_colreduce<f16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, partial_ws, sums, nullptr,
+                                      nullptr, M, C, st);
   return launch_colreduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, partial_ws, sums, nullptr, nullptr,
                                     M, C, st);
 }
@@ -541,6 +564,7 @@ DL4J_API int dl4j_bn_apply(const void* x, const float* scale, const float* shift
                            const float* rscale, const float* rshift, void* y, int64_t M, int C, int relu, int dtype,
                            hipStream_t st) {
   if (dtype == 1) return launch_apply<bf16_t>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st);
+  if (dtype == 2) return launch_apply<f16_t>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st);
   return launch_apply<float>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st);
 }
 
@@ -552,6 +576,9 @@ DL4J_API int dl4j_bn_bwd_reduce(const void* x, const void* dy, const void* out, 
   if (dtype == 1)
     return launch_colreduce<bf16_t, 1>(x, dy, out, mean, invstd, mscale, mshift, partial_ws, sums, dbeta_out, dgamma_out,
                                        M, C, st);
+  if (dtype == 2)
+    return launch_colreduce<f16_t, 1>(x, dy, out, mean, invstd, mscale, mshift, partial_ws, sums, dbeta_out, dgamma_out,
+                                      M, C, st);
   return launch_colreduce<float, 1>(x, dy, out, mean, invstd, mscale, mshift, partial_ws, sums, dbeta_out, dgamma_out, M, C,
                                     st);
 }
@@ -560,5 +587,6 @@ DL4J_API int dl4j_bn_bwd_dx(const void* x, const void* dy, const void* out, cons
                             const float* gamma, const float* sums, const float* mscale, const float* mshift, void* dx,
                             void* dz, int64_t M, int C, int dtype, hipStream_t st) {
   if (dtype == 1) return launch_bwd_dx<bf16_t>(x, dy, out, mean, invstd, gamma, sums, mscale, mshift, dx, dz, M, C, st);
+  if (dtype == 2) return launch_bwd_dx<f16_t>(x, dy, out, mean, invstd, gamma, sums, mscale, mshift, dx, dz, M, C, st);
   return launch_bwd_dx<float>(x, dy, out, mean, invstd, gamma, sums, mscale, mshift, dx, dz, M, C, st);
 }

@@ -157,7 +157,14 @@ struct __attribute__((packed, aligned(8))) CastSeg {
 static_assert(sizeof(CastSeg) == 40, "CastSeg layout is part of the ctypes ABI");
 
 #define CAST_LDS_FLOATS 13312
-__global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+// destination element types of the compute replicas: bf16 (raw bits), fp16, fp32 (layout change only: the OHWI / flipped filter
+// images of an fp32 network)
+struct CastBf16 { typedef bf16_t T; static __device__ __forceinline__ T cv(float f) { return f2bf(f); } };
+struct CastF16 { typedef _Float16 T; static __device__ __forceinline__ T cv(float f) { return (_Float16)f; } };
+struct CastF32 { typedef float T; static __device__ __forceinline__ T cv(float f) { return f; } };
+
+template <class CV>
+__global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict__ src, typename CV::T* __restrict__ dst,
                                                          const CastSeg* __restrict__ segs,
                                                          const int32_t* __restrict__ blk_seg,
                                                          const int32_t* __restrict__ blk_chunk) {
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
   const uint32_t I = (uint32_t)s.I, K = (uint32_t)s.K, O = (uint32_t)s.O;
   const uint32_t IK = I * K, KO = K * O;
   const float* sp = src + s.src_off;
-  bf16_t* dp = dst + s.dst_off;
+  typename CV::T* dp = dst + s.dst_off;
   const uint32_t d0 = (uint32_t)start, d1 = (uint32_t)end;
   if (s.mode == 0 && K > 1) {                       // [o][i][k] -> [o][k][i]: the permutation stays inside each o block
     const uint32_t o0 = d0 / IK, o1 = (d1 - 1) / IK;
@@ -182,7 +189,7 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
       for (uint32_t d = d0 + threadIdx.x; d < d1; d += 256) {
         const uint32_t o = d / IK, rem = d - o * IK;
         const uint32_t k = rem / I, i = rem - k * I;
-        dp[d] = f2bf(lds[o * IK + i * K + k - base]);
+        dp[d] = CV::cv(lds[o * IK + i * K + k - base]);
       }
       return;
     }
@@ -199,7 +206,7 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
       for (uint32_t d = d0 + threadIdx.x; d < d1; d += 256) {
         const uint32_t r = d / O, o = d - r * O;
         const uint32_t i = r / K, kf = r - i * K;
-        dp[d] = f2bf(lds[o * pitch + i * K + (K - 1 - kf) - q0]);
+        dp[d] = CV::cv(lds[o * pitch + i * K + (K - 1 - kf) - q0]);
       }
       return;
     }
@@ -215,16 +222,31 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
       const uint32_t k = rem / I, i = rem - k * I;
       si = o * IK + i * K + k;
     }
-    dp[d] = f2bf(sp[si]);
+    dp[d] = CV::cv(sp[si]);
   }
 }
 
+// dtype of the replicas: 0 fp32, 1 bf16, 2 fp16
+DL4J_API int dl4j_cast_table_dt(const float* src, void* dst, const void* segs, const int32_t* blk_seg,
+                                const int32_t* blk_chunk, int num_blocks, int dtype, hipStream_t st) {
+  if (num_blocks > 0) {
+    if (dtype == 1)
+      hipLaunchKernelGGL(cast_table_kernel<CastBf16>, dim3(num_blocks), dim3(256), 0, st, src, (bf16_t*)dst,
+                         (const CastSeg*)segs, blk_seg, blk_chunk);
+    else if (dtype == 2)
+      hipLaunchKernelGGL(cast_table_kernel<CastF16>, dim3(num_blocks), dim3(256), 0, st, src, (_Float16*)dst,
+                         (const CastSeg*)segs, blk_seg, blk_chunk);
+    else if (dtype == 0)
+      hipLaunchKernelGGL(cast_table_kernel<CastF32>, dim3(num_blocks), dim3(256), 0, st, src, (float*)dst,
+                         (const CastSeg*)segs, blk_seg, blk_chunk);
+    else
+      return -2;
+  }
+  DL4J_RET_LAST();
+}
 DL4J_API int dl4j_cast_table(const float* src, void* dst_bf16, const void* segs, const int32_t* blk_seg,
                              const int32_t* blk_chunk, int num_blocks, hipStream_t st) {
-  if (num_blocks > 0)
-    hipLaunchKernelGGL(cast_table_kernel, dim3(num_blocks), dim3(256), 0, st, src, (bf16_t*)dst_bf16,
-                       (const CastSeg*)segs, blk_seg, blk_chunk);
-  DL4J_RET_LAST();
+  return dl4j_cast_table_dt(src, dst_bf16, segs, blk_seg, blk_chunk, num_blocks, 1, st);
 }
 
 // Sum of squares over the flat gradient (global L2 norm for gradient clipping), two-stage.

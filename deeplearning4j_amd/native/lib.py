@@ -176,11 +176,16 @@ def dtype_code_all(t: torch.Tensor) -> int:
     return _DT_ALL.get(t.dtype, -1)
 
 
+DT_F16 = 2     # in the fp32 / bf16 / fp16 code space of the NN kernels (batchnorm, conv, gemm); the generic kernels use _DT_ALL
+
+
 def dtype_code(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return DT_F32
     if t.dtype == torch.bfloat16:
         return DT_BF16
+    if t.dtype == torch.float16:
+        return DT_F16
     return -1
 
 

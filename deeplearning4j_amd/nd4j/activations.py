@@ -173,13 +173,14 @@ class ActivationSoftmax(IActivation):
     JAVA_CLASS, NAME = _PKG + "ActivationSoftmax", "SOFTMAX"
 
     def forward(self, z, training=False):
-        if z.dim() == 2:
+        # the HIP kernel has no autograd node: inside a recorded graph (generic loss gradients, SameDiff sessions) stay on ATen
+        if z.dim() == 2 and not (z.requires_grad and torch.is_grad_enabled()):
             from ..ops.softmax import softmax
             return softmax(z)
         return torch.softmax(z, dim=1)
 
     def backprop(self, z, eps):
-        p = self.forward(z)
+        p = self.forward(z.detach())
         if z.dim() == 2:
             from ..ops.softmax import softmax_bp
             return softmax_bp(p, eps.contiguous())

@@ -662,3 +662,18 @@ def _sru_bi(ins, i, t, b, d):
           and ins[2].is_cuda and (not i or int(i[0]) == ins[3].shape[0]) and ins[0].numel() >= ins[3].shape[0] + 1)
 def _barnes_edge_forces(ins, i, t, b, d):
     return H.barnes_edge_forces(ins[0], ins[1], ins[2], ins[3])
+
+
+# ------------------------------------------------------------------ recurrent: fused GRU cell + native sequence loop (rnn_seq.hip)
+def _gru_usable(ins, i, t, b, d):
+    from ...ops import lstm as R
+    return len(ins) >= 4 and ins[0].dim() == 3 and R.gru_native_ok(ins[0], ins[1].shape[-1]) and all(
+        x is None or x.dtype == ins[0].dtype for x in ins[:5]) and (len(ins) < 5 or ins[4] is None or ins[4].dim() == 1)
+
+
+@platform("gru", _gru_usable, differentiable=True)
+def _gru_platform(ins, i, t, b, d):
+    """libnd4j gru time loop (helpers/impl/gru.cpp:123-160: gates = hI x Wh, c = tanh(gates_c * r + x x Wxc + bc)). gruCell keeps the
+    generic path: its candidate is ((r * hI) x Wch), a second GEMM between the two halves of the gate math."""
+    from ...ops import lstm as R
+    return R.gru_sequence(ins[0], ins[1], ins[2], ins[3], ins[4] if len(ins) > 4 else None)

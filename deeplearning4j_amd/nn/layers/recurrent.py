@@ -71,6 +71,17 @@ class LSTMImpl(LayerImpl):
             h = torch.zeros(mb, n, dtype=x.dtype, device=x.device)
             cs = torch.zeros(mb, n, dtype=x.dtype, device=x.device)
         mask = self.maskArray
+        if LSTMOP.native_seq_ok(xw, RW4, n, c.activationFn, c.gateActivationFn):
+            # whole sequence issued from C++ (native/csrc/rnn_seq.hip): recurrent GEMM on the in-tree MFMA kernel + fused cell
+            H, st = LSTMOP.seq_forward(xw, RW4, h, cs, peep, mask, train, self.reverse)
+            if train:
+                self._saved, self._xt, self._dims, self._peep = ("native", st), xt, (mb, nIn, T, n), peep
+            t_last = 0 if self.reverse else T - 1
+            h, cs = H[t_last], st["Cs"][t_last]
+            if store_state:
+                self.stateMap = {"prevActivation": h.detach(), "prevMemCell": cs.detach()}
+            self._last_state = (h, cs)
+            return H.permute(1, 2, 0)
         H = torch.empty(T, mb, n, dtype=x.dtype, device=x.device)
         saved = [] if train else None
         order = range(T - 1, -1, -1) if self.reverse else range(T)
@@ -97,11 +108,15 @@ class LSTMImpl(LayerImpl):
         W, RW = self._p("W"), self._p("RW")
         RW4 = RW[:, :4 * n]
         E = eps.permute(2, 0, 1).to(W.dtype)                           # [T, mb, n]
-        dG = torch.empty(T, mb, 4 * n, dtype=W.dtype, device=W.device)
-        Hprev = torch.empty(T, mb, n, dtype=W.dtype, device=W.device)
+        if isinstance(self._saved, tuple) and self._saved[0] == "native":
+            dG, Hprev, dpeep = LSTMOP.seq_backward(E, RW4, self._saved[1], self.reverse)
+            self._saved = []
+        else:
+            dG = torch.empty(T, mb, 4 * n, dtype=W.dtype, device=W.device)
+            Hprev = torch.empty(T, mb, n, dtype=W.dtype, device=W.device)
+            dpeep = [torch.zeros(n, dtype=torch.float32, device=W.device) for _ in range(3)] if self._peep is not None else None
         dh_next = torch.zeros(mb, n, dtype=W.dtype, device=W.device)
         dc_next = torch.zeros(mb, n, dtype=W.dtype, device=W.device)
-        dpeep = [torch.zeros(n, dtype=torch.float32, device=W.device) for _ in range(3)] if self._peep is not None else None
         for (t, h_prev, c_prev, sv, m) in reversed(self._saved):
             dh = E[t] + dh_next
             dgates, dc_prev, dp = LSTMOP.cell_backward(dh, dc_next, c_prev, sv, self._peep, c.activationFn,

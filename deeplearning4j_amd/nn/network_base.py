@@ -146,7 +146,11 @@ class BaseNetwork:
         ctx = self.ctx
         self._cast_table = None
         self._cparams_flat = None
-        if not ctx.mixed:
+        # mixed precision: every requested parameter gets a compute-dtype replica. Same-dtype networks on the GPU (fp32 / fp16
+        # masters) still get the PERMUTED filter images the implicit-GEMM kernels read (OHWI forward, flipped [I][k][O] data
+        # gradient); plain parameters are used in place.
+        layout_only = not ctx.mixed
+        if layout_only and (ctx.device.type != "cuda" or ctx.dtype not in (torch.float32, torch.float16)):
             return
         ents = []
         off = 0
@@ -158,6 +162,9 @@ class BaseNetwork:
             for key, layout in l.compute_replicas():
                 e = by_layer.get(li, {}).get(key)
                 if e is None:
+                    continue
+                if layout_only and not (len(e.spec.shape) == 4 and (layout == "dgrad" or (layout == "ohwi" and
+                                                                                              e.spec.shape[2] * e.spec.shape[3] > 1))):
                     continue
                 n = e.spec.numel
                 off = (off + 7) // 8 * 8      # 16-byte aligned replicas

@@ -41,7 +41,7 @@ def _workspace(C, device):
 
 
 def _hip_ok(x):
-    return L.use_hip(x) and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous()
+    return L.use_hip(x) and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.is_contiguous()
 
 
 def running_stat_grads(mean, var, gmean, gvar, decay, log_std, conv_bias=None):
@@ -83,7 +83,7 @@ def apply(x2d, scale, shift, residual=None, rscale=None, rshift=None, relu=False
                                       L.ptr(rshift), L.ptr(y), L.c_int64(M), L.c_int(C), L.c_int(1 if relu else 0),
                                       L.c_int(L.dtype_code(x2d)), L.stream()), "bn_apply")
         return y
-    cd = torch.float32 if x2d.dtype == torch.bfloat16 else x2d.dtype
+    cd = torch.float32 if x2d.dtype in (torch.bfloat16, torch.float16) else x2d.dtype
     y = x2d.to(cd) * scale.to(cd) + shift.to(cd)
     if residual is not None:
         r = residual.to(cd)
@@ -125,7 +125,7 @@ def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std
                                    L.ptr(dgmean_out), L.ptr(dgvar_out), L.c_int(C), L.c_int64(M), L.c_float(eps),
                                    L.c_float(decay), L.c_int(stat_mode), L.stream()), "bn_finalize")
         return mean, invstd, scale, shift
-    cd = torch.float32 if x2d.dtype == torch.bfloat16 else x2d.dtype
+    cd = torch.float32 if x2d.dtype in (torch.bfloat16, torch.float16) else x2d.dtype
     xf = x2d.to(cd)
     mean = xf.mean(0)
     var = xf.var(0, unbiased=False)
@@ -175,7 +175,7 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
             if dgamma_out is not None:
                 dgamma_out.copy_(sums[C:])
         return dx, dz
-    cd = torch.float32 if x2d.dtype == torch.bfloat16 else x2d.dtype
+    cd = torch.float32 if x2d.dtype in (torch.bfloat16, torch.float16) else x2d.dtype
     xf, dz = x2d.to(cd), dy2d.to(cd)
     if out2d is not None:
         dz = dz * (out2d > 0).to(cd)

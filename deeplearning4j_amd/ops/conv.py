@@ -168,7 +168,12 @@ def _backward_mfma(dz, x, w, stride, padding, dilation, need_dx, need_dw, need_d
         else:
             dW = torch.ops.aten.convolution_backward(dz, x, w, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
                                                      [False, True, False])[1]
-    if need_dx:
+    if need_dx and not CM.dgrad_supported(w):
+        dx = torch.ops.aten.convolution_backward(dz, x, w, None, list(stride), list(padding), list(dilation), False, [0, 0], 1,
+                                                 [True, False, False])[0]
+        if dx_accum is not None:
+            dx = dx_accum + dx
+    elif need_dx:
         wd = w_dgrad if w_dgrad is not None else CM.flip_filters(w)
         acc = dx_accum if (dx_accum is not None and dx_accum.dtype == dz.dtype and tuple(dx_accum.shape) == tuple(x.shape)
                            and dx_accum.is_contiguous(memory_format=torch.channels_last)) else None

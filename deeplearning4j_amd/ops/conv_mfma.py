@@ -119,6 +119,11 @@ def supported(x, w, groups=1):
     return _cl(x) and _w_cl(w) and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
 
 
+def dgrad_supported(w):
+    """The data gradient gathers dy rows, so the OUTPUT channel count must be a whole number of 16-byte chunks too."""
+    return w.shape[0] % chunk(w.dtype) == 0
+
+
 def out_size(i, k, s, p, d):
     return (i + 2 * p - d * (k - 1) - 1) // s + 1
 

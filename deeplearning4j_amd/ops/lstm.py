@@ -87,3 +87,132 @@ def cell_backward(dh, dc_next, c_prev, sv, peep, act, gate_act, mask):
         dc_prev = dc_prev + dzf * wFF + dzg * wGG
         dp = ((dzf * c_prev).sum(0).float(), (dzo * c).sum(0).float(), (dzg * c_prev).sum(0).float())
     return torch.cat([dza, dzf, dzo, dzg], dim=1), dc_prev, dp
+
+
+# ------------------------------------------------------------------------------------------------------ native sequence loops
+def native_seq_ok(xw, RW4, n, act, gate_act):
+    """Whole-sequence C++ loop (native/csrc/rnn_seq.hip): GPU, fp32 / bf16, tanh + sigmoid, n a multiple of the 16-byte chunk, and
+    the DL4J 'f'-order recurrent weights whose memory image is the [4n, n] NT operand."""
+    if not (L.use_hip(xw) and xw.dtype in (torch.float32, torch.bfloat16) and isinstance(act, ActivationTanH)
+            and isinstance(gate_act, ActivationSigmoid) and xw.is_contiguous()):
+        return False
+    ch = 4 if xw.dtype == torch.float32 else 8
+    return n % ch == 0 and RW4.dtype == xw.dtype and RW4.t().is_contiguous() and RW4.data_ptr() % 16 == 0
+
+
+def seq_forward(xw, RW4, h0, c0, peep, mask, train, reverse):
+    """xw [T, mb, 4n]. Returns (H [T, mb, n], state dict for seq_backward)."""
+    T, mb, n4 = xw.shape
+    n = n4 // 4
+    dev, dt = xw.device, xw.dtype
+    H = torch.empty(T, mb, n, device=dev, dtype=dt)
+    Cs = torch.empty(T, mb, n, device=dev, dtype=dt)
+    SV = torch.empty(T, mb, 6 * n, device=dev, dtype=dt) if train else None
+    ws = torch.empty(mb, n4, device=dev, dtype=dt)
+    pf = po = pg = None
+    if peep is not None:
+        pf, po, pg = (p.contiguous().float() for p in peep)
+    maskT = mask.to(dev).t().contiguous().float() if mask is not None else None
+    h0c, c0c = h0.to(dt).contiguous(), c0.to(dt).contiguous()
+    L.check(L.hip().dl4j_lstm_seq_fwd(L.ptr(xw), L.ptr(RW4), L.c_int64(n), L.ptr(h0c), L.ptr(c0c), L.ptr(pf), L.ptr(po), L.ptr(pg),
+                                      L.ptr(maskT), L.ptr(H), L.ptr(Cs), L.ptr(SV), L.ptr(ws), L.c_int(T), L.c_int(mb), L.c_int(n),
+                                      L.c_int(L.dtype_code(xw)), L.c_int(1 if reverse else 0), L.stream()), "lstm_seq_fwd")
+    return H, {"H": H, "Cs": Cs, "SV": SV, "h0": h0c, "c0": c0c, "peep": (pf, po, pg), "maskT": maskT}
+
+
+def seq_backward(E, RW4, st, reverse):
+    """E [T, mb, n] = dL/dH. Returns (dG [T, mb, 4n], Hprev [T, mb, n], [dwFF, dwOO, dwGG] or None)."""
+    T, mb, n = E.shape
+    dev, dt = E.device, E.dtype
+    E = E.contiguous()
+    rw4t = RW4.contiguous()                       # [n, 4n]: the NT operand of dh_prev = dgates . RW4^T
+    dG = torch.empty(T, mb, 4 * n, device=dev, dtype=dt)
+    pf, po, pg = st["peep"]
+    dpeep = torch.zeros(3, n, device=dev, dtype=torch.float32) if pf is not None else None
+    dh_ws = torch.empty(mb, n, device=dev, dtype=dt)
+    dc_ws = torch.empty(2, mb, n, device=dev, dtype=dt)
+    L.check(L.hip().dl4j_lstm_seq_bwd(L.ptr(E), L.ptr(rw4t), L.c_int64(4 * n), L.ptr(st["SV"]), L.ptr(st["Cs"]), L.ptr(st["c0"]),
+                                      L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(dh_ws),
+                                      L.ptr(dc_ws), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(L.dtype_code(E)),
+                                      L.c_int(1 if reverse else 0), L.stream()), "lstm_seq_bwd")
+    H, h0 = st["H"], st["h0"]
+    if reverse:
+        Hprev = torch.cat([H[1:], h0.unsqueeze(0)], 0)
+    else:
+        Hprev = torch.cat([h0.unsqueeze(0), H[:-1]], 0)
+    return dG, Hprev, (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
+
+
+# ------------------------------------------------------------------------------------------------------ GRU (libnd4j gru / gruCell)
+def gru_native_ok(x, n):
+    ch = 4 if x.dtype == torch.float32 else 8
+    return L.use_hip(x) and x.dtype in (torch.float32, torch.bfloat16) and n % ch == 0
+
+
+def gru_cell(xz, hz, hprev, train=True):
+    """Fused pointwise GRU cell: returns (h, sv = [r | u | c] or None)."""
+    mb, n = hprev.shape
+    h = torch.empty_like(hprev)
+    sv = torch.empty(mb, 3 * n, device=hprev.device, dtype=hprev.dtype) if train else None
+    L.check(L.hip().dl4j_gru_cell_fwd(L.ptr(xz.contiguous()), L.ptr(hz.contiguous()), L.ptr(hprev.contiguous()), L.ptr(h), L.ptr(sv),
+                                      L.c_int(mb), L.c_int(n), L.c_int(L.dtype_code(hprev)), L.stream()), "gru_cell_fwd")
+    return h, sv
+
+
+def gru_cell_backward(dh, sv, hz, hprev):
+    """Returns (dxz, dhz, dhp_direct): gradients of the two pre-activation operands and the direct part of dL/dh_prev."""
+    mb, n = hprev.shape
+    dxz = torch.empty(mb, 3 * n, device=dh.device, dtype=dh.dtype)
+    dhz = torch.empty_like(dxz)
+    dhp = torch.empty_like(hprev)
+    L.check(L.hip().dl4j_gru_cell_bwd(L.ptr(dh.contiguous()), L.ptr(sv), L.ptr(hz.contiguous()), L.ptr(hprev.contiguous()), L.ptr(dxz),
+                                      L.ptr(dhz), L.ptr(dhp), L.c_int(mb), L.c_int(n), L.c_int(L.dtype_code(dh)), L.stream()),
+            "gru_cell_bwd")
+    return dxz, dhz, dhp
+
+
+class _GruSeq(torch.autograd.Function):
+    """gru layer on the native loop: forward = C++ time loop (recurrent GEMM on the MFMA kernel + fused cell), backward = fused cell
+    backward per step + one GEMM per step for dh, the weight gradients as big GEMMs over all steps."""
+
+    @staticmethod
+    def forward(ctx, xz, h0, Wh):
+        T, mb, n3 = xz.shape
+        n = n3 // 3
+        dev, dt = xz.device, xz.dtype
+        wh_t = Wh.t().contiguous()                               # [3n, n] NT operand
+        H = torch.empty(T, mb, n, device=dev, dtype=dt)
+        HZ = torch.empty(T, mb, n3, device=dev, dtype=dt)
+        SV = torch.empty(T, mb, n3, device=dev, dtype=dt)
+        h0c = h0.contiguous()
+        L.check(L.hip().dl4j_gru_seq_fwd(L.ptr(xz.contiguous()), L.ptr(wh_t), L.c_int64(n), L.ptr(h0c), L.ptr(H), L.ptr(HZ), L.ptr(SV),
+                                         None, L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(L.dtype_code(xz)), L.stream()),
+                "gru_seq_fwd")
+        ctx.save_for_backward(H, HZ, SV, h0c, Wh)
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        H, HZ, SV, h0, Wh = ctx.saved_tensors
+        T, mb, n = H.shape
+        dXZ = torch.empty_like(HZ)
+        dHZ = torch.empty_like(HZ)
+        dh = torch.zeros(mb, n, device=H.device, dtype=H.dtype)
+        whc = Wh.contiguous()                                    # [n, 3n]: dh_prev += dhz . Wh^T  ==  gemm_nt(dhz, Wh)
+        from . import gemm as G
+        for t in range(T - 1, -1, -1):
+            hprev = H[t - 1] if t > 0 else h0
+            dxz, dhz, dhp = gru_cell_backward(dH[t] + dh, SV[t], HZ[t], hprev)
+            dXZ[t], dHZ[t] = dxz, dhz
+            dh = G.gemm_nt(dhz, whc, residual=dhp) if G.supported(dhz, whc) else dhp + dhz @ whc.t()
+        Hprev = torch.cat([h0.unsqueeze(0), H[:-1]], 0)
+        dWh = Hprev.reshape(T * mb, n).t() @ dHZ.reshape(T * mb, 3 * n)
+        return dXZ, dh, dWh
+
+
+def gru_sequence(x, h0, Wx, Wh, b):
+    """x [T, mb, nIn] -> H [T, mb, n] (libnd4j `gru`)."""
+    xz = x @ Wx
+    if b is not None:
+        xz = xz + b
+    return _GruSeq.apply(xz, h0, Wh)

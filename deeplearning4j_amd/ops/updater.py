@@ -212,9 +212,10 @@ class CastTable:
         self._blk_chunk = torch.from_numpy(bc).to(self.device)
 
     def run(self, src_f32, dst_bf16):
-        if L.use_hip(src_f32):
-            L.check(L.hip().dl4j_cast_table(L.ptr(src_f32), L.ptr(dst_bf16), L.ptr(self._seg), L.ptr(self._blk_seg),
-                                            L.ptr(self._blk_chunk), L.c_int(self.num_blocks), L.stream()),
+        if L.use_hip(src_f32) and src_f32.dtype == torch.float32 and dst_bf16.dtype in (torch.float32, torch.bfloat16, torch.float16):
+            code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dst_bf16.dtype]
+            L.check(L.hip().dl4j_cast_table_dt(L.ptr(src_f32), L.ptr(dst_bf16), L.ptr(self._seg), L.ptr(self._blk_seg),
+                                               L.ptr(self._blk_chunk), L.c_int(self.num_blocks), L.c_int(code), L.stream()),
                     "cast_table")
             return
         for (so, do, n, I, K, O, mode) in self.entries:

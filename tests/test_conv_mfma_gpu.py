@@ -159,3 +159,53 @@ def test_gemm_batched_strided():
     y = G.bgemm_nt(q, k, alpha=0.125)
     ref = 0.125 * torch.einsum("bmk,bnk->bmn", q.float(), k.float())
     assert (y.float() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+
+
+WG_CASES = [(4, 64, 14, 14, 64, 1, 1, 0, 1), (3, 64, 13, 13, 128, 3, 1, 1, 1), (2, 24, 9, 11, 40, 3, 1, 1, 1),
+            (2, 128, 8, 8, 128, 3, 2, 1, 1), (3, 8, 10, 7, 72, 5, 3, 2, 1), (2, 2048, 4, 4, 1000, 1, 1, 0, 1)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", WG_CASES)
+def test_wgrad_all_dtypes_and_partial_channel_tiles(case, dtype):
+    """Weight gradient on the own kernels for bf16 / fp16 (transposing-read MFMA) and fp32 (exact fp32 MFMA), including channel counts
+    that are not multiples of the 64-wide tiles (masked loads / stores)."""
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    N, C, H, W, K, R, s, p, d = case
+    x, w = _mk(N, C, H, W, K, R, dtype, 2)
+    assert IG.wgrad_supported(x, w)
+    wf = w.float().requires_grad_(True)
+    ref_y = F.conv2d(x.float(), wf, None, s, p, d)
+    dz = torch.randn_like(ref_y).to(dtype).contiguous(memory_format=torch.channels_last)
+    (ref_dw,) = torch.autograd.grad(ref_y, wf, dz.float())
+    dw = IG.wgrad(dz, x, w.shape, (s, s), (p, p), (d, d))
+    assert dw.shape == ref_dw.shape and dw.dtype == torch.float32
+    tol = {torch.bfloat16: 1e-4, torch.float16: 1e-4, torch.float32: 2e-5}[dtype]      # fp32 accumulation of exact products
+    err = (dw - ref_dw).abs().max().item()
+    assert err < tol * max(1.0, ref_dw.abs().max().item()), err
+    out = torch.zeros_like(ref_dw)
+    assert IG.wgrad(dz, x, w.shape, (s, s), (p, p), (d, d), dw_out=out, prezeroed=True) is None
+    assert (out - ref_dw).abs().max().item() < tol * max(1.0, ref_dw.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_conv_layer_dispatch_uses_own_kernels(dtype, monkeypatch):
+    """conv2d_forward / conv2d_backward in fp32 and fp16 must not reach the library: aten convolution entry points are poisoned."""
+    from deeplearning4j_amd.ops import conv as CONV
+    x, w = _mk(4, 32, 12, 12, 48, 3, dtype, 7)
+    ref = F.conv2d(x.float(), w.float(), None, 2, 1, 1)
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    ry = F.conv2d(xf, wf, None, 2, 1, 1)
+    dz = torch.randn_like(ry).to(dtype).contiguous(memory_format=torch.channels_last)
+    rdx, rdw = torch.autograd.grad(ry, [xf, wf], dz.float())
+
+    def boom(*a, **k):
+        raise AssertionError("library convolution called")
+    monkeypatch.setattr(F, "conv2d", boom)
+    monkeypatch.setattr(torch.ops.aten, "convolution_backward", boom, raising=False)
+    y, _ = CONV.conv2d_forward(x, w, None, (2, 2), (1, 1), (1, 1))
+    dx, dw, _ = CONV.conv2d_backward(dz, x, w, (2, 2), (1, 1), (1, 1))
+    t = TOL[dtype]
+    assert (y.float() - ref).abs().max().item() < t * max(1.0, ref.abs().max().item())
+    assert (dx.float() - rdx).abs().max().item() < t * max(1.0, rdx.abs().max().item())
+    assert (dw.float() - rdw).abs().max().item() < 1e-3 * max(1.0, rdw.abs().max().item())

@@ -335,3 +335,60 @@ def test_wgrad_side_stream_matches_main_stream_eager_and_captured():
         assert rel < 1e-3, float(rel)
     finally:
         streams.set_enabled(False)
+
+
+def test_resnet50_bf16_gpu_gradients_match_fp32_cpu():
+    """Full zoo ResNet-50 graph: bf16 compute on the GPU (own igemm / BN / pooling kernels) against the fp32 CPU network, same
+    parameters and batch. bf16 rounding through 53 BatchNorms bounds the agreement: score within 2 %, flat gradient cosine > 0.98."""
+    from tests.test_networks_cpu import _onehot
+    from deeplearning4j_amd.models.resnet50 import ResNet50
+    a = ResNet50(numClasses=10, inputShape=(3, 160, 160)).init(device="cpu")
+    b = ResNet50(numClasses=10, inputShape=(3, 160, 160), computeDataType="BFLOAT16").init(device=dev())
+    assert torch.equal(a.params(), b.params().cpu())
+    x = torch.rand(4, 3, 160, 160)
+    y = _onehot(4, 10).float()
+    a.computeGradientAndScore([x], [y])
+    b.computeGradientAndScore([x.to(dev())], [y.to(dev())])
+    sa, sb = float(a._score), float(b._score)
+    assert abs(sa - sb) < 2e-2 * max(1.0, abs(sa)), (sa, sb)
+    ga, gb = a._grads.double(), b._grads.cpu().double()
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()).clamp_min(1e-30))
+    assert cos > 0.98, cos
+    assert 0.9 < float(gb.norm() / ga.norm()) < 1.1
+
+
+@pytest.mark.parametrize("cdt", [None, "HALF"])
+def test_resnet50_fp32_and_fp16_run_on_own_conv_kernels(cdt, monkeypatch):
+    """FLOAT network (DL4J's default dtype) and FLOAT master + HALF compute: every convolution except the 3-channel stem runs on
+    the in-tree kernels (the library entry points are poisoned after the stem) and the gradients match the fp32 CPU network."""
+    import torch.nn.functional as F
+    from tests.test_networks_cpu import _onehot
+    from deeplearning4j_amd.models.resnet50 import ResNet50
+    from deeplearning4j_amd.ops import conv as CONV
+    a = ResNet50(numClasses=5, inputShape=(3, 160, 160)).init(device="cpu")
+    b = ResNet50(numClasses=5, inputShape=(3, 160, 160), computeDataType=cdt).init(device=dev())
+    x = torch.rand(2, 3, 160, 160)
+    y = _onehot(2, 5).float()
+    a.computeGradientAndScore([x], [y])
+    real_fwd, real_bwd = F.conv2d, torch.ops.aten.convolution_backward
+    calls = {"lib": 0}
+
+    def fwd(inp, w, *r, **k):
+        calls["lib"] += 1
+        assert w.shape[1] == 3, "library forward convolution on a %s filter" % (tuple(w.shape),)
+        return real_fwd(inp, w, *r, **k)
+
+    def bwd(dz, inp, w, *r, **k):
+        calls["lib"] += 1
+        assert w.shape[1] == 3, "library convolution backward on a %s filter" % (tuple(w.shape),)
+        return real_bwd(dz, inp, w, *r, **k)
+    monkeypatch.setattr(F, "conv2d", fwd)
+    monkeypatch.setattr(CONV.F, "conv2d", fwd)
+    monkeypatch.setattr(torch.ops.aten, "convolution_backward", bwd, raising=False)
+    b.computeGradientAndScore([x.to(dev())], [y.to(dev())])
+    assert calls["lib"] <= 2
+    sa, sb = float(a._score), float(b._score)
+    assert abs(sa - sb) < (2e-2 if cdt else 1e-3) * max(1.0, abs(sa)), (sa, sb)
+    ga, gb = a._grads.double(), b._grads.cpu().double()
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()).clamp_min(1e-30))
+    assert cos > (0.995 if cdt else 0.9999), cos

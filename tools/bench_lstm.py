@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Character-RNN style benchmark (DL4J TextGenerationLSTM / char-modelling example shape): 2 x LSTM(512) + RnnOutputLayer over 77
-characters, batch 64, sequence length 128, MultiLayerNetwork.fit with bf16 compute. Reports ms/step eager, HIP-graph captured, and
-the same model in plain PyTorch (nn.LSTM -> MIOpen RNN kernels) for orientation."""
+"""Character-RNN benchmark on BASELINE.json config 3: GravesLSTM / LSTM char-RNN, 3 x 512 units, truncated BPTT 50 (the DL4J
+char-modelling example shape: one-hot characters in, softmax over the vocabulary out, MultiLayerNetwork.fit). One "step" = one fit()
+of a [batch 64, 77 chars, 200 time steps] minibatch = 4 tBPTT segments of 50 steps, each with its own forward, backward and update.
+Reports ms/step for fp32 eager, bf16 eager, bf16 HIP-graph, and the same model in plain PyTorch (nn.LSTM -> MIOpen RNN kernels,
+same segmenting with detached state) for orientation."""
 import json
 import sys
 import time
@@ -10,20 +12,24 @@ import torch
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from deeplearning4j_amd.nd4j.learning import Adam  # noqa: E402
-from deeplearning4j_amd.nn.conf.base import InputType  # noqa: E402
+from deeplearning4j_amd.nn.conf.base import InputType, BackpropType  # noqa: E402
 from deeplearning4j_amd.nn.conf.configuration import NeuralNetConfiguration  # noqa: E402
-from deeplearning4j_amd.nn.conf.layers import LSTM, RnnOutputLayer  # noqa: E402
+from deeplearning4j_amd.nn.conf.layers import LSTM, GravesLSTM, RnnOutputLayer  # noqa: E402
 from deeplearning4j_amd.nn.multilayer import MultiLayerNetwork  # noqa: E402
 
-V, Hn, B, T = 77, 512, 64, 128
+V, Hn, B, T, TB, NL = 77, 512, 64, 200, 50, 3
 
 
-def build(dtype, graph):
+def build(dtype, graph, graves=False):
     b = NeuralNetConfiguration.Builder().seed(1).updater(Adam(1e-3)).weightInit("XAVIER")
     if dtype:
         b = b.computeDataType(dtype)
-    conf = (b.list().layer(LSTM(nIn=V, nOut=Hn, activation="TANH")).layer(LSTM(nIn=Hn, nOut=Hn, activation="TANH"))
-            .layer(RnnOutputLayer(nIn=Hn, nOut=V, activation="SOFTMAX", lossFunction="MCXENT"))
+    Lc = GravesLSTM if graves else LSTM
+    lb = b.list()
+    for i in range(NL):
+        lb = lb.layer(Lc(nIn=V if i == 0 else Hn, nOut=Hn, activation="TANH"))
+    conf = (lb.layer(RnnOutputLayer(nIn=Hn, nOut=V, activation="SOFTMAX", lossFunction="MCXENT"))
+            .backpropType(BackpropType.TruncatedBPTT).tBPTTForwardLength(TB).tBPTTBackwardLength(TB)
             .setInputType(InputType.recurrent(V, T)).build())
     net = MultiLayerNetwork(conf, device="cuda").init()
     if graph:
@@ -31,7 +37,7 @@ def build(dtype, graph):
     return net
 
 
-def timed(fn, steps=15, warm=5):
+def timed(fn, steps=8, warm=4):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -48,33 +54,41 @@ def main():
     x = torch.nn.functional.one_hot(idx, V).permute(0, 2, 1).float().cuda()
     y = torch.nn.functional.one_hot(torch.roll(idx, -1, 1), V).permute(0, 2, 1).float().cuda()
     res = {}
-    for name, dtype, graph in (("fp32_eager", None, False), ("bf16_eager", "BFLOAT16", False), ("bf16_hip_graph", "BFLOAT16", True)):
+    for name, dtype, graph, graves in (("fp32_eager", None, False, False), ("bf16_eager", "BFLOAT16", False, False),
+                                       ("bf16_graves_eager", "BFLOAT16", False, True), ("bf16_hip_graph", "BFLOAT16", True, False)):
         try:
-            net = build(dtype, graph)
+            net = build(dtype, graph, graves)
             res[name] = round(timed(lambda: net.fit(x, y)), 2)
             res[name + "_score"] = round(float(net.score()), 4)
         except Exception as e:                      # keep the other variants
-            res[name] = "failed: %s" % (str(e)[:120],)
+            res[name] = "failed: %s" % (str(e)[:160],)
 
     class Ref(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.rnn = torch.nn.LSTM(V, Hn, 2, batch_first=True)
+            self.rnn = torch.nn.LSTM(V, Hn, NL, batch_first=True)
             self.out = torch.nn.Linear(Hn, V)
 
-        def forward(self, z):
-            return self.out(self.rnn(z)[0])
+        def forward(self, z, st):
+            o, st = self.rnn(z, st)
+            return self.out(o), st
     ref = Ref().cuda()
     opt = torch.optim.Adam(ref.parameters(), 1e-3)
     xr, yr = x.permute(0, 2, 1).contiguous(), torch.roll(idx, -1, 1).cuda()
 
     def ref_step():
-        opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.cross_entropy(ref(xr).reshape(-1, V), yr.reshape(-1))
-        loss.backward()
-        opt.step()
+        st = None
+        for s in range(0, T, TB):
+            opt.zero_grad(set_to_none=True)
+            o, st = ref(xr[:, s:s + TB], st)
+            st = tuple(v.detach() for v in st)
+            loss = torch.nn.functional.cross_entropy(o.reshape(-1, V), yr[:, s:s + TB].reshape(-1))
+            loss.backward()
+            opt.step()
     res["pytorch_nn_lstm_fp32_eager"] = round(timed(ref_step), 2)
-    res.update(batch=B, seq_len=T, hidden=Hn, layers=2, unit="ms/step")
+    best = min(v for k, v in res.items() if isinstance(v, float) and not k.endswith("_score") and not k.startswith("pytorch"))
+    res.update(batch=B, seq_len=T, tbptt=TB, hidden=Hn, layers=NL, unit="ms per minibatch fit (4 tBPTT segments)",
+               chars_per_sec_best=round(B * T / best * 1e3))
     print(json.dumps(res))
 
 
