@@ -547,6 +547,9 @@ class SameDiff:
     def _exec_op(self, o: SameDiffOp, ins: List[torch.Tensor], allow_helpers=True):
         ex = OpExecutioner.getInstance()
         t = o.opType
+        if o.opName == "__vjp__":
+            from .gradfn import exec_vjp
+            return exec_vjp(self, o, ins)
         if t in (OpType.CUSTOM, OpType.UDF, OpType.BOOLEAN, OpType.SHAPE):
             res = ex._run(o.opName, ins, o.iArgs, o.tArgs, o.bArgs, o.dArgs, allow_helpers)
             return list(res) if isinstance(res, (tuple, list)) else [res]
@@ -860,6 +863,12 @@ class SameDiff:
                         shadow_ok=False):
         if not self.lossVariables:
             raise RuntimeError("no loss variables set: call setLossVariables / markAsLoss")
+        if getattr(self, "_grad_mode", "autograd") == "graph" and not extra_outputs and all(n in self._arrays for n in wrt):
+            gf = self.createGradFunction(list(wrt))
+            losses, gd = gf.execute(placeholders, list(wrt))
+            if device_losses:
+                return [l.detach().sum() for l in losses], gd, {}
+            return [float(l.detach().sum()) for l in losses], gd, {}
         ph = self._prep_placeholders(placeholders)
         saved = {}
         leaves = []
@@ -911,7 +920,23 @@ class SameDiff:
         _, g, o = self._loss_and_grads(placeholders, list(variables), list(outputs))
         return {n: INDArray(t) for n, t in o.items()}, {n: INDArray(t) for n, t in g.items()}
 
-    def createGradFunction(self, *_):
+    def createGradFunction(self, *variables):
+        """Build (and cache) the gradient function as a graph of ``_bp`` ops (autodiff/gradfn.py; SameDiff.java:5013). The result's
+        ``sd`` holds forward + backward ops and a ``<name>-grad`` variable per differentiated variable."""
+        from .gradfn import create_grad_function
+        names = [v.name if isinstance(v, SDVariable) else v for v in
+                 (variables[0] if len(variables) == 1 and isinstance(variables[0], (list, tuple)) else variables)]
+        key = (len(self.ops), len(self.variables), tuple(self.lossVariables), tuple(names))
+        c = getattr(self, "_gradfn_cache", None)
+        if c is None or c[0] != key:
+            self._gradfn_cache = (key, create_grad_function(self, names or None))
+        return self._gradfn_cache[1]
+
+    def setGradientMode(self, mode):
+        """'autograd' (default: tape over the session interpreter) or 'graph' (execute the gradient graph of createGradFunction:
+        every backward op is a custom op, so the ``_bp`` platform kernels run)."""
+        assert mode in ("autograd", "graph")
+        self._grad_mode = mode
         return self
 
     def grad(self, name):

@@ -1064,13 +1064,42 @@ def _matmul(ins, i, t, b, d):
     return z.transpose(-1, -2) if tz and z.dim() > 1 else z
 
 
+def _unbatch(g, shape):
+    """Sum a batched gradient back onto an operand whose leading (batch) dims were broadcast."""
+    if list(g.shape) == list(shape):
+        return g
+    while g.dim() > len(shape):
+        g = g.sum(0)
+    for ax, (a, b_) in enumerate(zip(g.shape, shape)):
+        if a != b_ and b_ == 1:
+            g = g.sum(ax, keepdim=True)
+    return g
+
+
 @op("matmul_bp")
 def _matmul_bp(ins, i, t, b, d):
+    """Analytic: z = op(x) . op(y)  =>  d op(x) = g . op(y)^T,  d op(y) = op(x)^T . g  (two GEMMs, no forward re-run;
+    reference generic/blas/matmul.cpp matmul_bp). Vector operands keep the autograd form."""
     x, y, g = ins[0], ins[1], ins[2]
-    xr, yr = x.detach().clone().requires_grad_(True), y.detach().clone().requires_grad_(True)
-    with torch.enable_grad():
-        z = _matmul([xr, yr], i, t, b, d)
-    return torch.autograd.grad(z, [xr, yr], g.to(z.dtype))
+    if x.dim() < 2 or y.dim() < 2:
+        xr, yr = x.detach().clone().requires_grad_(True), y.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            z = _matmul([xr, yr], i, t, b, d)
+        return torch.autograd.grad(z, [xr, yr], g.to(z.dtype))
+    ta, tb, tz = (list(i) + [0, 0, 0])[:3]
+    alpha = (list(t) + [1.0])[0] if t else 1.0
+    g = g.to(x.dtype)
+    if tz:
+        g = g.transpose(-1, -2)
+    if alpha != 1.0:
+        g = g * alpha
+    A = x.transpose(-1, -2) if ta else x
+    B = y.transpose(-1, -2) if tb else y
+    dA = torch.matmul(g, B.transpose(-1, -2))
+    dB = torch.matmul(A.transpose(-1, -2), g)
+    dx = dA.transpose(-1, -2) if ta else dA
+    dy = dB.transpose(-1, -2) if tb else dB
+    return _unbatch(dx, x.shape), _unbatch(dy, y.shape)
 
 
 @op("tensormmul")

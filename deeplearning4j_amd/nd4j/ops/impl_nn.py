@@ -382,15 +382,47 @@ def _conv2d_hip(ins, i, t, b, d):
 
 @op("conv2d_bp")
 def _conv2d_bp(ins, i, t, b, d):
+    """gradI, gradW[, gradB] straight from the convolution backward kernels (own implicit-GEMM kernels on the GPU, ATen on the CPU):
+    no forward re-computation (reference: generic/nn/convo/conv2d.cpp conv2d_bp -> ConvolutionUtils::conv2dBP)."""
     x, w = ins[0], ins[1]
     bias = ins[2] if len(ins) > 3 else None
     g = ins[-1]
-    leaves = [x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)]
+    c = _conv2d_args(i)
+    nd = 2
+    xs = x.permute(0, 3, 1, 2) if c["nhwc"] else x
+    gs = g.permute(0, 3, 1, 2) if c["nhwc"] else g
+    W = _w_to_oihw(w, c["wfmt"], nd).to(xs.dtype)
+    p = list(c["p"])
+    padded = None
+    if c["same"]:
+        pads = [_same_pad(xs.shape[2 + a], W.shape[2 + a], c["s"][a], c["dl"][a]) for a in range(nd)]
+        if any(lo != hi for lo, hi in pads):
+            flat = []
+            for lo, hi in reversed(pads):
+                flat += [lo, hi]
+            padded = pads
+            xs = F.pad(xs, flat)
+            p = [0] * nd
+        else:
+            p = [lo for lo, _ in pads]
+    from ...ops import conv as CONV
+    if xs.is_cuda:
+        xs = xs.contiguous(memory_format=torch.channels_last)
+        gs = gs.contiguous(memory_format=torch.channels_last).to(xs.dtype)
+        Wc = W.contiguous(memory_format=torch.channels_last)
+    else:
+        xs, gs, Wc = xs.contiguous(), gs.contiguous().to(xs.dtype), W.contiguous()
+    dx, dW, db = CONV.conv2d_backward(gs, xs, Wc, c["s"], p, c["dl"], True, True, bias is not None)
+    if padded is not None:
+        (t0, t1), (l0, l1) = padded
+        dx = dx[:, :, t0:dx.shape[2] - t1, l0:dx.shape[3] - l1]
+    if c["nhwc"]:
+        dx = dx.permute(0, 2, 3, 1)
+    dw = _w_from_oihw(dW.to(w.dtype), c["wfmt"], nd)
+    out = [dx.to(x.dtype), dw]
     if bias is not None:
-        leaves.append(bias.detach().clone().requires_grad_(True))
-    with torch.enable_grad():
-        y = _conv2d(leaves, i, t, b, d)
-    return torch.autograd.grad(y, leaves, g)
+        out.append(db.to(bias.dtype).reshape(bias.shape))
+    return tuple(out)
 
 
 @op("conv2d_input_bp")

@@ -31,7 +31,7 @@ def softmax_xent(z, y=None, labels_idx=None, want_probs=False):
                                           L.ptr(None), L.ptr(score), L.c_int64(M), L.c_int(N),
                                           L.c_int(L.dtype_code(z) | (ycode << 8)), L.stream()), "softmax_xent")
         return score, grad, probs
-    cd = torch.float32 if z.dtype == torch.bfloat16 else z.dtype
+    cd = torch.float32 if z.dtype in (torch.bfloat16, torch.float16) else z.dtype     # 1e-10 clip underflows in fp16
     p = torch.softmax(z.to(cd), dim=1)
     if y is None:
         yv = torch.zeros_like(p)
