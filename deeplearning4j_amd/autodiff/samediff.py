@@ -544,7 +544,9 @@ class SameDiff:
         return "\n".join(rows)
 
     # ------------------------------------------------------------------ execution
-    def _exec_op(self, o: SameDiffOp, ins: List[torch.Tensor], allow_helpers=True):
+    def _exec_op(self, o: SameDiffOp, ins: List[torch.Tensor], allow_helpers=True, mmgr=None):
+        """Run one op. ``mmgr`` (an inference session's SessionMemMgr) supplies the output buffer of same-shape legacy
+        transforms / pairwise ops, so recycled arrays are written in place of fresh allocations."""
         ex = OpExecutioner.getInstance()
         t = o.opType
         if o.opName == "__vjp__":
@@ -565,12 +567,17 @@ class SameDiff:
         ext = o.tArgs or None
         n = o.opNum
         x = ins[0] if ins else None
-        if t == OpType.TRANSFORM_SAME: return [lg.execTransformSame(n, x, None, ext)]
-        if t == OpType.TRANSFORM_STRICT: return [lg.execTransformStrict(n, x, None, ext)]
+        z = None
+        if mmgr is not None and x is not None and x.is_floating_point() and not torch.is_grad_enabled() and (
+                t in (OpType.TRANSFORM_SAME, OpType.TRANSFORM_STRICT) or
+                (t == OpType.PAIRWISE and ins[1].shape == x.shape and ins[1].dtype == x.dtype)):
+            z = mmgr.allocate(False, x.dtype, *x.shape, device=x.device)
+        if t == OpType.TRANSFORM_SAME: return [lg.execTransformSame(n, x, z, ext)]
+        if t == OpType.TRANSFORM_STRICT: return [lg.execTransformStrict(n, x, z, ext)]
         if t == OpType.TRANSFORM_FLOAT: return [lg.execTransformFloat(n, x, None, ext)]
         if t == OpType.TRANSFORM_BOOL: return [lg.execTransformBool(n, x, None, ext)]
         if t == OpType.TRANSFORM_ANY: return [lg.execTransformAny(n, x, None, ext)]
-        if t == OpType.PAIRWISE: return [lg.execPairwiseTransform(n, x, ins[1], None, ext)]
+        if t == OpType.PAIRWISE: return [lg.execPairwiseTransform(n, x, ins[1], z, ext)]
         if t == OpType.PAIRWISE_BOOL: return [lg.execPairwiseTransformBool(n, x, ins[1], None, ext)]
         if t == OpType.BROADCAST: return [lg.execBroadcast(n, x, ins[1], None, dims)]
         if t == OpType.BROADCAST_BOOL: return [lg.execBroadcastBool(n, x, ins[1], None, dims)]
@@ -662,8 +669,12 @@ class SameDiff:
             stack += o.inputs + o.controlDeps
         return need
 
-    def _run_graph(self, placeholders: Dict[str, torch.Tensor], outputs: Sequence[str], training=False, listeners=(), at=None):
-        """Dataflow interpreter with frames. Values are keyed by (variable, frame, iteration)."""
+    def _run_graph(self, placeholders: Dict[str, torch.Tensor], outputs: Sequence[str], training=False, listeners=(), at=None, lifetime=None):
+        """Dataflow interpreter with frames. Values are keyed by (variable, frame, iteration).
+
+        ``lifetime`` (sessions.ArrayLifetime, set by InferenceSession) tracks, per produced array, the ops that still have to read it
+        (a DependencyTracker: array -> consumer ops) and hands the array to the session's memory manager as soon as the last one has
+        run — the reference's InferenceSession.arrayUseTracker (internal/InferenceSession.java:96-140). Only graphs without frames."""
         need = self._required_ops(outputs)
         ROOT = ("", 0)
         vals: Dict[tuple, torch.Tensor] = {}
@@ -678,6 +689,12 @@ class SameDiff:
         if missing:
             raise ValueError("no value provided for placeholder(s) %s" % missing)
         has_control = any(self.ops[o].opName.lower() in _CONTROL for o in need)
+        if lifetime is not None and (has_control or torch.is_grad_enabled()):
+            lifetime = None
+        if lifetime is not None:
+            lifetime.begin(set(outputs))
+            for v in vals.values():
+                lifetime.pin(v)                   # parameters / constants / fed arrays are not the session's to recycle
 
         def lookup(var, frame, it):
             f, i = frame, it
@@ -745,7 +762,7 @@ class SameDiff:
                     t0 = time.perf_counter_ns()
                     for l in listeners:
                         l.preOpExecution(self, at, o, ins)
-                    outs = self._exec_op(o, ins, allow_helpers=True)
+                    outs = self._exec_op(o, ins, allow_helpers=True, mmgr=lifetime.mmgr if lifetime is not None else None)
                     for l in listeners:
                         l.opExecution(self, at, o, ins, outs, time.perf_counter_ns() - t0)
             produced = []
@@ -756,6 +773,13 @@ class SameDiff:
                 if oframe == "":
                     results[n] = val
                 produced.append((n, oframe, oit))
+            if lifetime is not None:
+                for n, val in zip(o.outputs, outs):
+                    if val is not None:
+                        lifetime.produced(n, val, [c for c in self._consumers.get(n, ()) if c in need])
+                for dead in lifetime.executed(o.name):
+                    vals.pop((dead, "", 0), None)
+                    results.pop(dead, None)
             return produced
 
         # exact-context propagation with a worklist ...

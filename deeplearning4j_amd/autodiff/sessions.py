@@ -4,10 +4,9 @@ The reference executes a graph through ``AbstractSession`` subclasses (nd4j-api
 org/nd4j/autodiff/samediff/internal/AbstractSession.java, InferenceSession.java, TrainingSession.java), hands array
 lifetimes to a ``SessionMemMgr`` (internal/memory/ArrayCacheMemoryMgr.java, NoOpMemoryMgr.java) and tracks readiness with
 a ``DependencyTracker`` (internal/DependencyTracker.java). Here the dataflow interpreter lives in
-:meth:`SameDiff._run_graph`, array memory is torch's caching HIP allocator and readiness is the interpreter's worklist;
-these classes are the public handles onto that machinery: a session runs a fixed output set, a memory manager recycles
-output buffers between executions, a dependency tracker is the general-purpose "X becomes available once all of D are
-satisfied" structure that listeners and custom schedulers can use.
+:meth:`SameDiff._run_graph`; an :class:`InferenceSession` plugs an :class:`ArrayLifetime` into it: a DependencyTracker records
+which ops still have to read each produced array, the array goes to the session's memory manager the moment the last reader has
+run, and same-shape transform / pairwise ops take their output buffer from that manager (ArrayCacheMemoryMgr: recycled).
 """
 from __future__ import annotations
 
@@ -254,6 +253,66 @@ class IdentityDependencyTracker(DependencyTracker):
         return [w.o for w in super().getNewAllSatisfiedList()]
 
 
+class ArrayLifetime:
+    """Per-execution array lifetimes of an inference session (reference: InferenceSession.arrayUseTracker + mmgr.release in
+    internal/InferenceSession.java:96-140, 340-380). Arrays that share storage (views from reshape / permute / identity) are released
+    only when the last alias is dead."""
+
+    def __init__(self, mmgr: SessionMemMgr):
+        self.mmgr = mmgr
+        self.tracker = DependencyTracker()
+        self.released = 0
+        self.peakLive = 0
+
+    def begin(self, keep):
+        self.tracker.clear()
+        self._keep = set(keep)
+        self._arrays: Dict[str, torch.Tensor] = {}
+        self._aliases: Dict[int, int] = defaultdict(int)
+        self.released = 0
+        self.peakLive = 0
+
+    @staticmethod
+    def _sid(t):
+        return t.untyped_storage().data_ptr() if t.numel() else id(t)
+
+    def produced(self, name, arr, consumers):
+        if not isinstance(arr, torch.Tensor) or name in self._keep:
+            if isinstance(arr, torch.Tensor):
+                self._aliases[self._sid(arr)] += 1                      # an alias that never dies: pins the storage
+            return
+        self._arrays[name] = arr
+        self._aliases[self._sid(arr)] += 1
+        self.peakLive = max(self.peakLive, len(self._arrays))
+        for c in consumers:
+            self.tracker.addDependency(("arr", name), ("op", c))
+        if not consumers:
+            self.tracker.addDependency(("arr", name), ("op", None))
+            self.tracker.markSatisfied(("op", None))
+
+    def pin(self, arr):
+        """Storage owned by someone else (variables, constants, placeholders): never recycled."""
+        if isinstance(arr, torch.Tensor):
+            self._aliases[self._sid(arr)] += 1
+
+    def executed(self, opName) -> List[str]:
+        self.tracker.markSatisfied(("op", opName))
+        dead = []
+        while self.tracker.hasNewAllSatisfied():
+            _, name = self.tracker.getNewAllSatisfied()
+            arr = self._arrays.pop(name, None)
+            if arr is None:
+                continue
+            dead.append(name)
+            sid = self._sid(arr)
+            self._aliases[sid] -= 1
+            if self._aliases[sid] <= 0:
+                del self._aliases[sid]
+                self.mmgr.release(arr)
+                self.released += 1
+        return dead
+
+
 # ---------------------------------------------------------------------------------------------- sessions
 class AbstractSession:
     """One graph + one executor (reference: internal/AbstractSession.java:output())."""
@@ -291,8 +350,11 @@ class InferenceSession(AbstractSession):
     def output(self, variables=None, placeholderValues=None, listeners=(), at=None, training=False):
         from .listeners import At, Operation
         at = at or At(0, 0, Operation.INFERENCE)
+        sd = self.sameDiff
+        self.lifetime = ArrayLifetime(self.mmgr)
         with torch.no_grad():
-            return super().output(variables, placeholderValues, listeners, at, False)
+            ph = sd._prep_placeholders(placeholderValues)
+            return sd._run_graph(ph, self._names(variables), False, tuple(sd.listeners) + tuple(listeners), at, lifetime=self.lifetime)
 
     def release(self, outputs: Dict[str, torch.Tensor]):
         for t in outputs.values():

@@ -530,6 +530,12 @@ class ComputationGraph(BaseNetwork):
         labels = [self._prep_labels(y) for y in labels]
         mb = inputs[0].shape[0]
         self._last_batch = mb
+        if self._grads.is_cuda:
+            # one clear of the flat gradient vector replaces a memset in front of every split-K wgrad (53 on ResNet-50). It has to
+            # come BEFORE the forward pass: BatchNormalization writes its running-statistics deltas (the "gradients" of mean /
+            # var, BatchNormalization.java:330-360) into this vector while it normalises.
+            self._grads.zero_()
+            self.ctx.grads_zeroed = True
         self._forward(inputs, True, mode, fmasks=fmasks)
         total = None
         for i, o in enumerate(self.conf.networkOutputs):
@@ -541,10 +547,6 @@ class ComputationGraph(BaseNetwork):
             s = ol.compute_score_sum()
             total = s if total is None else total + s
         self._score = (total / mb) if self._minibatch else total
-        if self._grads.is_cuda:
-            # one clear of the flat gradient vector replaces a memset in front of every split-K wgrad (53 on ResNet-50)
-            self._grads.zero_()
-            self.ctx.grads_zeroed = True
         self._backward(mb)
         for lst in self.listeners:
             if hasattr(lst, "onGradientCalculation"):

@@ -17,6 +17,7 @@ from ...nd4j.activations import ActivationIdentity, ActivationReLU, ActivationSo
 from ...ops import batchnorm as BN
 from ...ops import pooling as POOL
 from ...ops import conv as CONV
+from ...ops import dense as DENSE
 from ..conf import layers as C
 from ..conf.base import ConvolutionMode, PoolingType, InputType
 from .base import LayerImpl, AutogradLayerImpl
@@ -25,16 +26,29 @@ from .base import LayerImpl, AutogradLayerImpl
 # ------------------------------------------------------------------ dense family
 class DenseLayerImpl(LayerImpl):
     def compute_replicas(self):
-        return [("W", "plain")] + ([("b", "plain")] if "b" in self.params else [])
+        # "dgrad": the [nIn, nOut] row-major image of W for the input-gradient GEMM (ops/dense.py)
+        return [("W", "plain"), ("W", "dgrad")] + ([("b", "plain")] if "b" in self.params else [])
 
     def _wt(self):
         # flat layout is 'f' order [nIn, nOut]  ==  contiguous [nOut, nIn]; use it as linear weight
         return self.w("W").t()
 
+    def _bias32(self):
+        if "b" not in self.params:
+            return None
+        b = self.params["b"]
+        return (b if b.dtype == torch.float32 else self.w("b").float()).reshape(-1)
+
     def pre_output(self, x):
         W = self._wt()  # [nOut, nIn] contiguous
-        b = self.w("b").reshape(-1) if "b" in self.params else None
-        z = F.linear(x, W, b)
+        x2 = x.reshape(-1, x.shape[-1]) if x.dim() != 2 else x
+        if x.is_cuda and DENSE.fwd_ok(x2, W):
+            z = DENSE.forward(x2, W, self._bias32())
+            if x.dim() != 2:
+                z = z.view(*x.shape[:-1], W.shape[0])
+        else:
+            b = self.w("b").reshape(-1) if "b" in self.params else None
+            z = F.linear(x, W, b)
         if getattr(self.conf, "hasLayerNorm", False):
             self._ln_in = z
             z = F.layer_norm(z, (z.shape[-1],), self.w("g").reshape(-1), None, 1e-5)
@@ -61,12 +75,22 @@ class DenseLayerImpl(LayerImpl):
         x2 = x.reshape(-1, x.shape[-1])
         d2 = dz.reshape(-1, dz.shape[-1])
         # dW in 'f' layout == [nOut, nIn] contiguous = dz^T x  (BaseLayer.java:96 gemm(input, delta, true, false))
-        self.grads["W"].t().copy_(torch.matmul(d2.t(), x2))
+        if d2.dtype != x2.dtype:
+            d2 = d2.to(x2.dtype)
+        gw = self.grads["W"].t()
+        if x2.is_cuda and DENSE.dw_ok(d2, x2, gw):
+            DENSE.dw(d2, x2, gw, getattr(self.ctx, "grads_zeroed", False))
+        else:
+            gw.copy_(torch.matmul(d2.t(), x2))
         if "b" in self.grads:
-            self.grads["b"].copy_(d2.sum(0, dtype=torch.float32 if d2.dtype == torch.bfloat16 else None).reshape(1, -1))
+            self.grads["b"].copy_(d2.sum(0, dtype=torch.float32 if d2.dtype in (torch.bfloat16, torch.float16) else None).reshape(1, -1))
         if not need_dx:
             return None
-        dx = torch.matmul(dz, self._wt())
+        wd = self.cparams.get("W_dgrad")
+        if x2.is_cuda and DENSE.dx_ok(d2, wd):
+            dx = DENSE.dx(d2, wd).view(*dz.shape[:-1], wd.shape[0])
+        else:
+            dx = torch.matmul(dz, self._wt())
         return self._dropout_back(dx)
 
     def backward(self, eps):

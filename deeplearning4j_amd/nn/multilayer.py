@@ -310,14 +310,16 @@ class MultiLayerNetwork(BaseNetwork):
         for lst in self.listeners:
             if hasattr(lst, "onForwardPass"):
                 pass
+        if self._grads.is_cuda:
+            # one clear of the flat gradient vector replaces a memset in front of every split-K wgrad (53 on ResNet-50). It has to
+            # come BEFORE the forward pass: BatchNormalization writes its running-statistics deltas (the "gradients" of mean /
+            # var, BatchNormalization.java:330-360) into this vector while it normalises.
+            self._grads.zero_()
+            self.ctx.grads_zeroed = True
         self._forward(x, True, mode=mode, fmask=fmask)
         out_layer.setLabels(y, lmask)
         ssum = out_layer.compute_score_sum()
         self._score = (ssum / mb) if self._minibatch else ssum
-        if self._grads.is_cuda:
-            # one clear of the flat gradient vector replaces a memset in front of every split-K wgrad (53 on ResNet-50)
-            self._grads.zero_()
-            self.ctx.grads_zeroed = True
         self._backward(mb)
         for lst in self.listeners:
             if hasattr(lst, "onGradientCalculation"):

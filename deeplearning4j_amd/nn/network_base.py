@@ -163,8 +163,11 @@ class BaseNetwork:
                 e = by_layer.get(li, {}).get(key)
                 if e is None:
                     continue
-                if layout_only and not (len(e.spec.shape) == 4 and (layout == "dgrad" or (layout == "ohwi" and
-                                                                                              e.spec.shape[2] * e.spec.shape[3] > 1))):
+                dense_dgrad = layout == "dgrad" and len(e.spec.shape) == 2 and e.spec.order == "f"
+                if layout == "dgrad" and len(e.spec.shape) == 2 and not dense_dgrad:
+                    continue
+                if layout_only and not dense_dgrad and not (len(e.spec.shape) == 4 and (
+                        layout == "dgrad" or (layout == "ohwi" and e.spec.shape[2] * e.spec.shape[3] > 1))):
                     continue
                 n = e.spec.numel
                 off = (off + 7) // 8 * 8      # 16-byte aligned replicas
@@ -172,6 +175,11 @@ class BaseNetwork:
                     O, I, kh, kw = e.spec.shape
                     ents.append((e.off, off, n, I, kh * kw))
                     views.append((l, key, off, ("ohwi", (O, I, kh, kw))))
+                elif dense_dgrad:
+                    # 'f'-ordered [nIn, nOut] is [nOut][nIn] in memory; the input-gradient GEMM reads [nIn][nOut]
+                    I, O = e.spec.shape
+                    ents.append((e.off, off, n, I, 1, O, 1))
+                    views.append((l, key + "_dgrad", off, ("dgrad", (O, I, 1, 1))))
                 elif layout == "dgrad" and len(e.spec.shape) == 4:
                     # [I][kh*kw flipped][O]: filters as consumed by the dgrad implicit GEMM
                     O, I, kh, kw = e.spec.shape
@@ -188,7 +196,8 @@ class BaseNetwork:
                 l.cparams[key] = self._cparams_flat[o:o + O * I * kh * kw].view(O, kh, kw, I).permute(0, 3, 1, 2)
             elif kind == "dgrad":
                 O, I, kh, kw = info
-                l.cparams[key] = self._cparams_flat[o:o + O * I * kh * kw].view(I, kh, kw, O)
+                v = self._cparams_flat[o:o + O * I * kh * kw]
+                l.cparams[key] = v.view(I, O) if key == "W_dgrad" and len(l.params["W"].shape) == 2 else v.view(I, kh, kw, O)
             else:
                 l.cparams[key] = _strided_view(self._cparams_flat, o, info)
         self._cast_table = U.CastTable(ents, ctx.device)

@@ -1,0 +1,47 @@
+"""Dense (fully connected) layer math on the in-tree MFMA kernels instead of library GEMMs:
+
+    z  = x . Wt^T + b            ops/gemm.py gemm_nt (bias in the epilogue)            Wt = [nOut, nIn], DL4J's 'f'-ordered W in memory
+    dx = dz . W_dgrad^T          gemm_nt on the [nIn, nOut] image of W kept by the cast table ("dgrad" replica)
+    dW = dz^T . x                the split-K weight-gradient kernel (a dense layer is a 1x1 convolution over M "pixels")
+
+Reference: nn/layers/BaseLayer.java:92-111 (backpropGradient: gemm(input, delta, true, false), W.mmul(delta^T)^T) and :322-331
+(preOutput), which go to cuBLAS through MmulHelper; here no rocBLAS/hipBLASLt kernel (``Cijk_*``) is launched for these shapes.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import gemm as G
+from . import conv_igemm as IG
+
+
+def fwd_ok(x2, wt):
+    return G.supported(x2, wt) and not (torch.is_grad_enabled() and (x2.requires_grad or wt.requires_grad))
+
+
+def forward(x2, wt, bias32, act=None):
+    return G.gemm_nt(x2, wt, bias=bias32, act=act)
+
+
+def dx_ok(dz2, w_dgrad):
+    return w_dgrad is not None and dz2.dtype == w_dgrad.dtype and G.supported(dz2, w_dgrad)
+
+
+def dx(dz2, w_dgrad):
+    return G.gemm_nt(dz2, w_dgrad)
+
+
+def dw_ok(dz2, x2, dw_t):
+    """dw_t: the [nOut, nIn] fp32 contiguous image of the gradient (= grads['W'].t() for an 'f'-ordered W)."""
+    if not (x2.is_cuda and dz2.dtype == x2.dtype and dw_t.dtype == torch.float32 and dw_t.is_contiguous() and x2.is_contiguous()
+            and dz2.is_contiguous() and x2.data_ptr() % 16 == 0 and dz2.data_ptr() % 16 == 0):
+        return False
+    ch = 4 if x2.dtype == torch.float32 else 8
+    return x2.dtype in (torch.bfloat16, torch.float16, torch.float32) and x2.shape[1] % ch == 0 and dz2.shape[1] % ch == 0
+
+
+def dw(dz2, x2, dw_t, prezeroed):
+    M, nIn = x2.shape
+    nOut = dz2.shape[1]
+    IG.wgrad(dz2.view(M, nOut, 1, 1), x2.view(M, nIn, 1, 1), (nOut, nIn, 1, 1), (1, 1), (0, 0), (1, 1), dw_out=dw_t.view(nOut, nIn, 1, 1),
+             prezeroed=prezeroed)

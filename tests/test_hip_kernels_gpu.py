@@ -337,27 +337,51 @@ def test_wgrad_side_stream_matches_main_stream_eager_and_captured():
         streams.set_enabled(False)
 
 
+def _well_conditioned(*nets):
+    """A start point where gradients mean something numerically. The untrained 53-layer graph (He or the zoo's TruncatedNormal init,
+    all gammas 1, logits of magnitude ~10) is chaotic: tools/debug_bf16_grads.py shows that perturbing the fp32 parameters ONCE by
+    bf16-sized relative noise already drops the fp32-vs-fp32 gradient cosine to 0.42 (profiles/r2_bf16_grad_conditioning.txt), so no
+    reduced-precision kernel could agree with fp32 there. Scaling the last BatchNorm gamma of every residual branch to 0.2 and the
+    classifier weights by 0.05 (the usual "small residual branch" start) makes the same perturbation give cosine 0.9997."""
+    p = nets[0].params().clone().view(-1)
+    for e in nets[0]._entries:
+        name = str(nets[0]._layer_key(e.layer_idx))
+        if e.spec.key == "gamma" and name.endswith("branch2c"):
+            p[e.off:e.off + e.spec.numel] = 0.2
+        if name == "output" and e.spec.key == "W":
+            p[e.off:e.off + e.spec.numel] *= 0.05
+    for n in nets:
+        n.setParams(p.to(n.params().device))
+
+
 def test_resnet50_bf16_gpu_gradients_match_fp32_cpu():
     """Full zoo ResNet-50 graph: bf16 compute on the GPU (own igemm / BN / pooling kernels) against the fp32 CPU network, same
-    parameters and batch. bf16 rounding through 53 BatchNorms bounds the agreement: score within 2 %, flat gradient cosine > 0.98."""
+    parameters and batch: score within 1 %, flat gradient cosine > 0.995, every conv layer's weight-gradient cosine > 0.8 (the
+    earliest layers see the rounding of all 53 layers above them; a single bf16-sized parameter perturbation gives 0.97 there)."""
     from tests.test_networks_cpu import _onehot
     from deeplearning4j_amd.models.resnet50 import ResNet50
-    # He ("RELU") initialisation: with the zoo default TruncatedNormal(0, 0.5) the untrained 53-layer graph amplifies rounding
-    # noise chaotically (fp32 GPU vs fp32 CPU already differ by 3 % there), which says nothing about the kernels
     a = ResNet50(numClasses=10, inputShape=(3, 160, 160), weightInit="RELU").init(device="cpu")
     b = ResNet50(numClasses=10, inputShape=(3, 160, 160), weightInit="RELU", computeDataType="BFLOAT16").init(device=dev())
+    _well_conditioned(a, b)
     assert torch.equal(a.params(), b.params().cpu())
     x = torch.rand(8, 3, 160, 160)
     y = _onehot(8, 10).float()
     a.computeGradientAndScore([x], [y])
     b.computeGradientAndScore([x.to(dev())], [y.to(dev())])
     sa, sb = float(a._score), float(b._score)
-    assert abs(sa - sb) < 5e-2 * max(1.0, abs(sa)), (sa, sb)
+    assert abs(sa - sb) < 1e-2 * max(1.0, abs(sa)), (sa, sb)
     ga, gb = a._grads.double(), b._grads.cpu().double()
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()).clamp_min(1e-30))
     print("bf16 vs fp32 gradient cosine %.5f, norm ratio %.4f" % (cos, float(gb.norm() / ga.norm())))
-    assert cos > 0.97, cos
-    assert 0.9 < float(gb.norm() / ga.norm()) < 1.1
+    assert cos > 0.995, cos
+    assert 0.97 < float(gb.norm() / ga.norm()) < 1.03
+    worst = 1.0
+    for e in a._entries:
+        if e.spec.key == "W":
+            u, v = ga[e.off:e.off + e.spec.numel], gb[e.off:e.off + e.spec.numel]
+            worst = min(worst, float((u * v).sum() / (u.norm() * v.norm()).clamp_min(1e-30)))
+    print("worst per-layer weight-gradient cosine %.4f" % worst)
+    assert worst > 0.8, worst
 
 
 @pytest.mark.parametrize("cdt", [None, "HALF"])
@@ -370,6 +394,7 @@ def test_resnet50_fp32_and_fp16_run_on_own_conv_kernels(cdt, monkeypatch):
     from deeplearning4j_amd.ops import conv as CONV
     a = ResNet50(numClasses=5, inputShape=(3, 160, 160), weightInit="RELU").init(device="cpu")
     b = ResNet50(numClasses=5, inputShape=(3, 160, 160), weightInit="RELU", computeDataType=cdt).init(device=dev())
+    _well_conditioned(a, b)
     x = torch.rand(8, 3, 160, 160)
     y = _onehot(8, 5).float()
     a.computeGradientAndScore([x], [y])
@@ -395,4 +420,39 @@ def test_resnet50_fp32_and_fp16_run_on_own_conv_kernels(cdt, monkeypatch):
     ga, gb = a._grads.double(), b._grads.cpu().double()
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()).clamp_min(1e-30))
     print("%s vs fp32 CPU gradient cosine %.6f" % (cdt or "FLOAT", cos))
-    assert cos > (0.99 if cdt else 0.9995), cos
+    # fp32: the kernels are exact to ~1e-5; what remains are single ReLU-mask flips at |y| ~ 1e-7 (tools/debug_fp32_bn.py found
+    # one in 51200 elements of bn4f_branch2a), each worth ~3e-3 relative error downstream
+    assert cos > (0.999 if cdt else 0.9999), cos
+    # BatchNorm running-statistic deltas travel in the gradient vector (written by the forward pass): they must survive on the GPU
+    for e in a._entries:
+        if e.spec.key in ("mean", "var", "log10stdev"):
+            u, v = ga[e.off:e.off + e.spec.numel], gb[e.off:e.off + e.spec.numel]
+            assert float(u.norm()) > 0 and float((u - v).norm() / u.norm()) < (2e-2 if cdt else 1e-3), (e.spec.key, e.layer_idx)
+
+
+@pytest.mark.parametrize("capture", [False, True])
+def test_batchnorm_running_statistics_follow_cpu_training(capture):
+    """Two fit() steps: the global mean / variance parameters of every BatchNormalization move exactly as on the CPU (they are updated
+    through the gradient vector by the NoOp updater, BatchNormalization.java:330-360), eager and with the step captured in a graph."""
+    from tests.test_networks_cpu import _onehot
+    from deeplearning4j_amd.models.resnet50 import ResNet50
+    from deeplearning4j_amd.nd4j.learning import Sgd
+    a = ResNet50(numClasses=5, inputShape=(3, 160, 160), weightInit="RELU", updater=Sgd(1e-3)).init(device="cpu")
+    b = ResNet50(numClasses=5, inputShape=(3, 160, 160), weightInit="RELU", updater=Sgd(1e-3)).init(device=dev())
+    _well_conditioned(a, b)
+    if capture:
+        b.enableGraphCapture(True)
+    x = torch.rand(4, 3, 160, 160)
+    y = _onehot(4, 5).float()
+    p0 = a.params().clone().view(-1)
+    for _ in range(3):
+        a.fit([x], [y])
+        b.fit([x.to(dev())], [y.to(dev())])
+    pa, pb = a.params().view(-1), b.params().cpu().view(-1)
+    moved = 0.0
+    for e in a._entries:
+        if e.spec.key in ("mean", "var", "log10stdev"):
+            sl = slice(e.off, e.off + e.spec.numel)
+            moved += float((pa[sl] - p0[sl]).norm())
+            assert float((pa[sl] - pb[sl]).norm()) < 2e-3 * max(1e-3, float((pa[sl] - p0[sl]).norm())) + 1e-6, (e.spec.key, e.layer_idx)
+    assert moved > 1.0

@@ -277,3 +277,33 @@ def test_grad_function_vjp_fallback_for_ops_without_rule():
     _, got = gf.execute(ph, ["w"])
     ref_t = ref.tensor() if hasattr(ref, "tensor") else ref._t
     assert torch.allclose(got["w"], ref_t, atol=1e-5)
+
+
+def test_inference_session_releases_dead_arrays_and_recycles_buffers():
+    """DependencyTracker + ArrayCacheMemoryMgr are live parts of InferenceSession: intermediates are released when their last reader
+    has run, and transform outputs are written into recycled buffers (reference: internal/InferenceSession.java arrayUseTracker)."""
+    from deeplearning4j_amd.autodiff.samediff import SameDiff
+    from deeplearning4j_amd.autodiff.sessions import InferenceSession, ArrayCacheMemoryMgr
+    sd = SameDiff.create(device="cpu")
+    x = sd.placeHolder("x", "FLOAT", -1, 32)
+    w = sd.var("w", torch.randn(32, 32, generator=torch.Generator().manual_seed(0)) * 0.2)
+    h = x
+    for i in range(6):
+        h = sd.math.tanh(h.mmul(w))
+        h = sd.math.abs(h) if i % 2 else sd.math.neg(h)
+    r = sd._op("reshape", [w], iArgs=[-99, 1024])[0]           # a view of a PARAMETER: must never reach the cache
+    out = h.add(r.sum())
+    out.rename("out")
+    mm = ArrayCacheMemoryMgr(maxCacheBytes=1 << 20)
+    sess = InferenceSession(sd, mm)
+    xin = torch.randn(16, 32, generator=torch.Generator().manual_seed(1))
+    ref = sd.output({"x": xin}, ["out"])["out"].clone()
+    w0 = sd._arrays["w"].clone()
+    o1 = sess.output(["out"], {"x": xin})["out"]
+    assert torch.allclose(o1, ref)
+    lt = sess.lifetime
+    assert lt.released >= 10 and lt.peakLive <= 4, (lt.released, lt.peakLive)     # 19 intermediates, at most a few alive at once
+    assert mm.hits > 0                                                              # later transforms wrote into recycled buffers
+    o1 = o1.clone()
+    o2 = sess.output(["out"], {"x": xin})["out"]
+    assert torch.allclose(o2, o1) and torch.equal(sd._arrays["w"], w0)
