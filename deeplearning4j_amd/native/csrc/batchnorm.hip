@@ -6,6 +6,7 @@
 // with a residual add — itself optionally batch-normalised — and ReLU), and a 2-pass backward.
 // Memory-bound: 16-byte vector accesses, fp32 accumulation, one float atomic per block/channel.
 #include "common.h"
+#include "ticket.h"
 #include <stdlib.h>
 
 struct f16_t { _Float16 v; };     // IEEE half activations (DL4J network dtype HALF); distinct type so the templates can dispatch
@@ -105,7 +106,9 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ out,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ mscale, const float* __restrict__ mshift,
-    float* __restrict__ partial, int64_t M, int C, int cpb, int rpi) {
+    float* __restrict__ partial, int64_t M, int C, int cpb, int rpi,
+    float* __restrict__ sums, float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ gpart,
+    unsigned* __restrict__ cnt, int G) {
   __shared__ float red[2 * V * 256];
   const int cv = C / V;
   const int tid = threadIdx.x;
@@ -157,9 +160,33 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
     for (int j = 0; j < V; ++j) {
       float s0 = 0.f, s1 = 0.f;
       for (int r = 0; r < rpi; ++r) { s0 += red[j * 256 + r * cpb + c_in]; s1 += red[(V + j) * 256 + r * cpb + c_in]; }
-      partial[((int64_t)blockIdx.y * 2) * C + cvec * V + j] = s0;
-      partial[((int64_t)blockIdx.y * 2 + 1) * C + cvec * V + j] = s1;
+      ticket::st_agent(partial + ((int64_t)blockIdx.y * 2) * C + cvec * V + j, s0);
+      ticket::st_agent(partial + ((int64_t)blockIdx.y * 2 + 1) * C + cvec * V + j, s1);
     }
+  }
+  if (cnt == nullptr) return;
+  // ---------------- second stage inside this launch (ticket.h): the last block of each group of G row-blocks sums the group's
+  // partial rows, the last group sums the group results into sums[2C] (+ the dbeta / dgamma gradient views)
+  __shared__ int s_last;
+  const int gy = gridDim.y, ngroups = (gy + G - 1) / G;
+  const int g = blockIdx.y / G, gbeg = g * G, gend = (gbeg + G < gy) ? gbeg + G : gy;
+  const int cbeg = blockIdx.x * cpb * V;
+  const int ncol = (C - cbeg < cpb * V) ? C - cbeg : cpb * V;       // channels owned by this column block
+  if (!ticket::arrive_last(cnt + gridDim.x + blockIdx.x * ngroups + g, (unsigned)(gend - gbeg), &s_last)) return;
+  for (int idx = tid; idx < 2 * ncol; idx += 256) {
+    const int q = idx / ncol, c = cbeg + idx - q * ncol;
+    float a = 0.f;
+    for (int r = gbeg; r < gend; ++r) a += ticket::ld_agent(partial + ((int64_t)r * 2 + q) * C + c);
+    ticket::st_agent(gpart + ((int64_t)g * 2 + q) * C + c, a);
+  }
+  if (!ticket::arrive_last(cnt + blockIdx.x, (unsigned)ngroups, &s_last)) return;
+  for (int idx = tid; idx < 2 * ncol; idx += 256) {
+    const int q = idx / ncol, c = cbeg + idx - q * ncol;
+    float a = 0.f;
+    for (int r = 0; r < ngroups; ++r) a += ticket::ld_agent(gpart + ((int64_t)r * 2 + q) * C + c);
+    sums[q * C + c] = a;
+    if (q == 0) { if (out0) out0[c] = a; }
+    else if (out1) out1[c] = a;
   }
 }
 
@@ -199,6 +226,8 @@ __global__ void __launch_bounds__(1024) bn_sum_partials_kernel(const float* __re
 }
 
 #define BN_MAX_ROWBLOCKS 2048                 // workspace bound
+#define BN_TICKET_COUNTERS 4096               // entries of the self-resetting ticket counter array (dl4j_bn_ticket_counters)
+#define BN_TICKET_GROUPS ((BN_MAX_ROWBLOCKS + 31) / 32)
 // grid policy of the column reductions (tunable for tools/bn_microbench.py through the environment)
 static int bn_env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -212,7 +241,8 @@ static inline int64_t colreduce_ws_floats(int C) { return (int64_t)BN_MAX_ROWBLO
 template <typename T, int MODE>
 static int launch_colreduce(const void* x, const void* dy, const void* out, const float* mean,
                             const float* invstd, const float* mscale, const float* mshift, float* partial, float* sums,
-                            float* out0, float* out1, int64_t M, int C, hipStream_t st) {
+                            float* out0, float* out1, int64_t M, int C, hipStream_t st, float* gpart = nullptr,
+                            unsigned* cnt = nullptr) {
   constexpr int VFULL = VecOf<T>::N;
   const bool vec_ok = (C % VFULL) == 0;
   const int V = vec_ok ? VFULL : 1;
@@ -226,14 +256,19 @@ static int launch_colreduce(const void* x, const void* dy, const void* out, cons
   int64_t cap = bn_rowblocks() / gx; if (cap < 1) cap = 1;
   if (gy > cap) gy = cap;
   dim3 grid(gx, (unsigned)gy);
+  constexpr int G = 32;
+  // fused second stage: counters laid out as [gx] level-2 + [gx][ngroups] level-1 (BN_TICKET_COUNTERS entries available)
+  const bool fused = cnt != nullptr && gpart != nullptr && (int64_t)gx * (1 + (gy + G - 1) / G) <= BN_TICKET_COUNTERS;
+  unsigned* c = fused ? cnt : nullptr;
   if (vec_ok)
     hipLaunchKernelGGL((bn_colreduce_kernel<T, VFULL, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
-                       (const T*)out, mean, invstd, mscale, mshift, partial, M, C, cpb, rpi);
+                       (const T*)out, mean, invstd, mscale, mshift, partial, M, C, cpb, rpi, sums, out0, out1, gpart, c, G);
   else
     hipLaunchKernelGGL((bn_colreduce_kernel<T, 1, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
-                       (const T*)out, mean, invstd, mscale, mshift, partial, M, C, cpb, rpi);
-  hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, st, partial, (int)gy, C, sums, out0,
-                     out1);
+                       (const T*)out, mean, invstd, mscale, mshift, partial, M, C, cpb, rpi, sums, out0, out1, gpart, c, G);
+  if (!fused)
+    hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, st, partial, (int)gy, C, sums, out0,
+                       out1);
   DL4J_RET_LAST();
 }
 
@@ -566,6 +601,25 @@ DL4J_API int dl4j_bn_apply(const void* x, const float* scale, const float* shift
   if (dtype == 1) return launch_apply<bf16_t>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st);
   if (dtype == 2) return launch_apply<f16_t>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st);
   return launch_apply<float>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st);
+}
+
+DL4J_API int dl4j_bn_ticket_counters() { return BN_TICKET_COUNTERS; }
+DL4J_API int64_t dl4j_bn_ticket_gpart_floats(int C) { return (int64_t)BN_TICKET_GROUPS * 2 * C; }
+
+// Same as dl4j_bn_bwd_reduce, second reduction stage fused into the launch (ticket.h). cnt: BN_TICKET_COUNTERS zero-initialised
+// uint32 (self-resetting, may be shared by all layers on a stream); gpart: dl4j_bn_ticket_gpart_floats(C) floats.
+DL4J_API int dl4j_bn_bwd_reduce_fused(const void* x, const void* dy, const void* out, const float* mean,
+                                      const float* invstd, const float* mscale, const float* mshift, float* partial_ws,
+                                      float* sums, float* dbeta_out, float* dgamma_out, int64_t M, int C, int dtype,
+                                      float* gpart, unsigned* cnt, hipStream_t st) {
+  if (dtype == 1)
+    return launch_colreduce<bf16_t, 1>(x, dy, out, mean, invstd, mscale, mshift, partial_ws, sums, dbeta_out, dgamma_out,
+                                       M, C, st, gpart, cnt);
+  if (dtype == 2)
+    return launch_colreduce<f16_t, 1>(x, dy, out, mean, invstd, mscale, mshift, partial_ws, sums, dbeta_out, dgamma_out,
+                                      M, C, st, gpart, cnt);
+  return launch_colreduce<float, 1>(x, dy, out, mean, invstd, mscale, mshift, partial_ws, sums, dbeta_out, dgamma_out, M, C,
+                                    st, gpart, cnt);
 }
 
 // mscale/mshift (optional, used when out == nullptr): recompute the fused-ReLU mask from x instead of reading the output.

@@ -19,6 +19,7 @@
 // tile t, LDS write after), XOR-swizzled 16-byte chunks so ds_read_b128 / tr reads are bank
 // conflict free, XCD-aware workgroup->tile map so tiles sharing an A panel share an L2.
 #include "common.h"
+#include "ticket.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -38,6 +39,7 @@ struct IGemmP {
   int nbuf;           // LDS stages: 2 (double buffered) or 1 when the reduction is a single 64-wide tile (1x1 conv, C = 64):
                       // halves the LDS footprint so twice as many workgroups are resident to hide the load latency
   int accum;          // 1: y += result (in-place gradient accumulation at graph fan-out points, saves a separate add pass)
+  ticket::BnFin fin;  // fin.cnt != null: the last workgroup of every N tile reduces the statistics and runs the BatchNorm finalize
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   __syncthreads();
   if (p.stats != nullptr && tid < 2 * BN) {
     const int qs = tid / BN, col = tid - qs * BN;
-    p.stats[((int64_t)mt * 2 + qs) * p.K + n0 + col] = sS[(0 * 2 + qs) * BN + col] + sS[(1 * 2 + qs) * BN + col];
+    ticket::st_agent(p.stats + ((int64_t)mt * 2 + qs) * p.K + n0 + col, sS[(0 * 2 + qs) * BN + col] + sS[(1 * 2 + qs) * BN + col]);
   }
   constexpr int CPR = BN / 8;
   for (int idx = tid; idx < BM * CPR; idx += 256) {
@@ -203,6 +205,28 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
       }
       *reinterpret_cast<s16x8*>(p.y + o) = v;
     }
+  }
+  if (p.fin.cnt == nullptr) return;
+  // ---------------- in-kernel BatchNorm finalize (ticket.h): two levels so no block reads more than ~G + mtiles/G partial rows
+  __shared__ int s_last;
+  const ticket::BnFin& f = p.fin;
+  const int G = f.G, ngroups = (p.mtiles + G - 1) / G;
+  const int g = mt / G, gbeg = g * G, gend = (gbeg + G < p.mtiles) ? gbeg + G : p.mtiles;
+  if (!ticket::arrive_last(f.cnt + p.ntiles + nt * ngroups + g, (unsigned)(gend - gbeg), &s_last)) return;
+  if (tid < 2 * BN) {
+    const int qs = tid / BN, col = tid - qs * BN;
+    float a = 0.f;
+    for (int r = gbeg; r < gend; ++r) a += ticket::ld_agent(p.stats + ((int64_t)r * 2 + qs) * p.K + n0 + col);
+    ticket::st_agent(f.gpart + ((int64_t)g * 2 + qs) * p.K + n0 + col, a);
+  }
+  if (!ticket::arrive_last(f.cnt + nt, (unsigned)ngroups, &s_last)) return;
+  if (tid < BN) {
+    float su = 0.f, sq = 0.f;
+    for (int r = 0; r < ngroups; ++r) {
+      su += ticket::ld_agent(f.gpart + ((int64_t)r * 2 + 0) * p.K + n0 + tid);
+      sq += ticket::ld_agent(f.gpart + ((int64_t)r * 2 + 1) * p.K + n0 + tid);
+    }
+    ticket::bn_finalize_channel(f, n0 + tid, su, sq);
   }
 }
 
@@ -222,17 +246,40 @@ static int launch_fwd(IGemmP& p, hipStream_t st) {
   DL4J_RET_LAST();
 }
 
+DL4J_API int dl4j_igemm_conv_fin(const void* x, const void* w, void* y, const float* bias, float* stats,
+                                 const int* g, int tile, int accum, int* mtiles_out, void* const* ptrs, const float* fparams,
+                                 float* gpart, unsigned* cnt, hipStream_t st);
+
 // geom = [N,H,W,C, OH,OW,K, R,S, sh,sw, ph,pw, dh,dw, OHs,OWs,oys,oxs]
 // returns the number of M tiles used (needed to reduce the BN-stat partials) via *mtiles_out.
 DL4J_API int dl4j_igemm_conv(const void* x, const void* w, void* y, const float* bias, float* stats,
                              const int* g, int tile, int accum, int* mtiles_out, hipStream_t st) {
+  return dl4j_igemm_conv_fin(x, w, y, bias, stats, g, tile, accum, mtiles_out, nullptr, nullptr, nullptr, nullptr, st);
+}
+
+// Same, with the BatchNorm finalize of the consuming layer fused into the launch (ticket.h). ptrs: gamma, beta, conv_bias, gmean,
+// gvar (inputs, may be null), mean, invstd, scale, shift, dgmean, dgvar (outputs); fparams: eps, decay; stat_mode as bn_finalize.
+// cnt: zero-initialised counters (self-resetting), at least ntiles * (1 + ceil(mtiles / 32)) entries; gpart: >= ceil(mtiles/32)*2*K.
+DL4J_API int dl4j_igemm_conv_fin(const void* x, const void* w, void* y, const float* bias, float* stats,
+                                 const int* g, int tile, int accum, int* mtiles_out, void* const* ptrs, const float* fparams,
+                                 float* gpart, unsigned* cnt, hipStream_t st) {
   IGemmP p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.bias = bias; p.stats = stats; p.accum = accum;
+  p.fin = ticket::BnFin{};
   p.N = g[0]; p.H = g[1]; p.W = g[2]; p.C = g[3]; p.OH = g[4]; p.OW = g[5]; p.K = g[6]; p.R = g[7]; p.S = g[8];
   p.sh = g[9]; p.sw = g[10]; p.ph = g[11]; p.pw = g[12]; p.dh = g[13]; p.dw = g[14];
   p.OHs = g[15]; p.OWs = g[16]; p.oys = g[17]; p.oxs = g[18];
   p.M = p.N * p.OH * p.OW;
   if (p.C % 64 != 0 || p.K % 64 != 0) return -2;
+  if (cnt != nullptr && stats != nullptr && ptrs != nullptr) {
+    ticket::BnFin& f = p.fin;
+    f.gamma = (const float*)ptrs[0]; f.beta = (const float*)ptrs[1]; f.conv_bias = (const float*)ptrs[2];
+    f.gmean = (const float*)ptrs[3]; f.gvar = (const float*)ptrs[4];
+    f.mean = (float*)ptrs[5]; f.invstd = (float*)ptrs[6]; f.scale = (float*)ptrs[7]; f.shift = (float*)ptrs[8];
+    f.dgmean = (float*)ptrs[9]; f.dgvar = (float*)ptrs[10];
+    f.gpart = gpart; f.cnt = cnt; f.invM = 1.f / (float)p.M; f.eps = fparams[0]; f.decay = fparams[1];
+    f.stat_mode = (int)fparams[2]; f.G = 32;
+  }
   int rc;
   if (tile == 0) { if (p.K % 128) return -2; rc = launch_fwd<128, 128>(p, st); }
   else if (tile == 1) rc = launch_fwd<128, 64>(p, st);

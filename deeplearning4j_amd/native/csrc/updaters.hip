@@ -23,18 +23,44 @@ static_assert(sizeof(UpdSeg) == 64, "UpdSeg layout is part of the ctypes ABI");
 
 #define UPD_CHUNK 2048
 
+// element type of the flat params / grads / state vectors: fp32 masters, or a bf16 / fp16 network without fp32 masters
+// (DL4J dataType(HALF): NeuralNetConfiguration.java:1149-1154). Math is always fp32.
+struct PF32 { typedef float T; static __device__ __forceinline__ float ld(const T* p, int64_t i) { return p[i]; }
+              static __device__ __forceinline__ void st(T* p, int64_t i, float v) { p[i] = v; } };
+struct PBF16 { typedef bf16_t T; static __device__ __forceinline__ float ld(const T* p, int64_t i) { return bf2f(p[i]); }
+               static __device__ __forceinline__ void st(T* p, int64_t i, float v) { p[i] = f2bf(v); } };
+struct PF16 { typedef _Float16 T; static __device__ __forceinline__ float ld(const T* p, int64_t i) { return (float)p[i]; }
+              static __device__ __forceinline__ void st(T* p, int64_t i, float v) { p[i] = (_Float16)v; } };
+
+// Device-resident learning-rate schedule: lr_sched[(iter - sched_base) * nseg + segment] for the next sched_window iterations,
+// pre-evaluated on the host (ISchedule.valueAt) and refilled between replays when the window runs out — so a network with a
+// schedule keeps its captured training step (the reference re-reads the schedule on the host every iteration,
+// BaseMultiLayerUpdater.java:329-382). NaN entries mean "segment has no learning rate": the table value is kept.
+struct LrSched {
+  const float* table;
+  const int64_t* base;
+  int window, nseg;
+};
+
+template <class P>
 __global__ void __launch_bounds__(256) segmented_updater_kernel(
-    float* __restrict__ params, float* __restrict__ grads, float* __restrict__ state,
+    typename P::T* __restrict__ params, typename P::T* __restrict__ grads, typename P::T* __restrict__ state,
     bf16_t* __restrict__ shadow, const UpdSeg* __restrict__ segs, const int32_t* __restrict__ blk_seg,
     const int32_t* __restrict__ blk_chunk, const int64_t* __restrict__ iter_dev, float inv_batch,
-    int write_update) {
-  const UpdSeg s = segs[blk_seg[blockIdx.x]];
+    int write_update, LrSched sched) {
+  UpdSeg s = segs[blk_seg[blockIdx.x]];
+  if (sched.table != nullptr) {
+    int64_t k = iter_dev[0] - sched.base[0];
+    k = k < 0 ? 0 : (k >= sched.window ? sched.window - 1 : k);
+    const float lr = sched.table[k * sched.nseg + blk_seg[blockIdx.x]];
+    if (lr == lr) s.lr = lr;
+  }
   const int64_t start = (int64_t)blk_chunk[blockIdx.x] * UPD_CHUNK;
   const int64_t end = (start + UPD_CHUNK < s.len) ? start + UPD_CHUNK : s.len;
   const float t = (float)(iter_dev[0] + 1);
   const bool div = s.flags & 1, wd_lr = s.flags & 2, upd_only = s.flags & 4;
   const int64_t n = s.len;
-  float* st = state + s.state_off;
+  typename P::T* stp = state + s.state_off;
   // per-launch scalars
   float alpha_t = s.lr;
   const float eps = (s.eps == 0.f && s.kind >= 3) ? 1e-7f : s.eps;
@@ -50,9 +76,9 @@ __global__ void __launch_bounds__(256) segmented_updater_kernel(
   }
   for (int64_t i = start + threadIdx.x; i < end; i += 256) {
     const int64_t gi = s.off + i;
-    float g = grads[gi];
+    float g = P::ld(grads, gi);
     if (div) g *= inv_batch;
-    const float w = upd_only ? 0.f : params[gi];
+    const float w = upd_only ? 0.f : P::ld(params, gi);
     if (s.l1 != 0.f) g += s.l1 * (w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f));
     if (s.l2 != 0.f) g += s.l2 * w;
     float u;
@@ -60,68 +86,68 @@ __global__ void __launch_bounds__(256) segmented_updater_kernel(
       case 0: u = g; break;
       case 1: u = s.lr * g; break;
       case 2: {  // Nesterovs
-        const float vprev = s.a * st[i];
+        const float vprev = s.a * P::ld(stp, i);
         const float v = vprev - s.lr * g;
-        st[i] = v;
+        P::st(stp, i, v);
         u = vprev - (s.a + 1.f) * v;
       } break;
       case 3: {  // Adam, state [m | v]
-        const float m = s.a * st[i] + (1.f - s.a) * g;
-        const float v = s.b * st[n + i] + (1.f - s.b) * g * g;
-        st[i] = m; st[n + i] = v;
+        const float m = s.a * P::ld(stp, i) + (1.f - s.a) * g;
+        const float v = s.b * P::ld(stp, n + i) + (1.f - s.b) * g * g;
+        P::st(stp, i, m); P::st(stp, n + i, v);
         u = m * alpha_t / (sqrtf(v) + eps);
       } break;
       case 4: {  // RmsProp
-        const float r = s.a * st[i] + (1.f - s.a) * g * g;
-        st[i] = r;
+        const float r = s.a * P::ld(stp, i) + (1.f - s.a) * g * g;
+        P::st(stp, i, r);
         u = s.lr * g / (sqrtf(r) + eps);
       } break;
       case 5: {  // AdaGrad
-        const float h = st[i] + g * g;
-        st[i] = h;
+        const float h = P::ld(stp, i) + g * g;
+        P::st(stp, i, h);
         u = s.lr * g / (sqrtf(h) + eps);
       } break;
       case 6: {  // AdaDelta, state [msg | msdx]
-        const float msg = s.a * st[i] + (1.f - s.a) * g * g;
-        const float msdx0 = st[n + i];
+        const float msg = s.a * P::ld(stp, i) + (1.f - s.a) * g * g;
+        const float msdx0 = P::ld(stp, n + i);
         u = g * sqrtf(msdx0 + eps) / sqrtf(msg + eps);
-        st[i] = msg; st[n + i] = s.a * msdx0 + (1.f - s.a) * u * u;
+        P::st(stp, i, msg); P::st(stp, n + i, s.a * msdx0 + (1.f - s.a) * u * u);
       } break;
       case 7: {  // AdaMax, state [m | u]
-        const float m = s.a * st[i] + (1.f - s.a) * g;
-        const float ui = fmaxf(s.b * st[n + i], fabsf(g)) + 1e-32f;
-        st[i] = m; st[n + i] = ui;
+        const float m = s.a * P::ld(stp, i) + (1.f - s.a) * g;
+        const float ui = fmaxf(s.b * P::ld(stp, n + i), fabsf(g)) + 1e-32f;
+        P::st(stp, i, m); P::st(stp, n + i, ui);
         u = m * alpha_t / ui;
       } break;
       case 8: {  // Nadam, state [m | v]
-        const float m = s.a * st[i] + (1.f - s.a) * g;
-        const float v = s.b * st[n + i] + (1.f - s.b) * g * g;
-        st[i] = m; st[n + i] = v;
+        const float m = s.a * P::ld(stp, i) + (1.f - s.a) * g;
+        const float v = s.b * P::ld(stp, n + i) + (1.f - s.b) * g * g;
+        P::st(stp, i, m); P::st(stp, n + i, v);
         u = s.lr * ((s.a * m + (1.f - s.a) * g) * alpha_t) / (sqrtf(v) + eps);
       } break;
       case 9: {  // AMSGrad, state [m | v | vHat]
-        const float m = s.a * st[i] + (1.f - s.a) * g;
-        const float v = s.b * st[n + i] + (1.f - s.b) * g * g;
-        const float h = fmaxf(st[2 * n + i], v);
-        st[i] = m; st[n + i] = v; st[2 * n + i] = h;
+        const float m = s.a * P::ld(stp, i) + (1.f - s.a) * g;
+        const float v = s.b * P::ld(stp, n + i) + (1.f - s.b) * g * g;
+        const float h = fmaxf(P::ld(stp, 2 * n + i), v);
+        P::st(stp, i, m); P::st(stp, n + i, v); P::st(stp, 2 * n + i, h);
         u = alpha_t * m / (sqrtf(h) + eps);
       } break;
       default: {  // AdaBelief, state [m | s]
-        const float m = s.a * st[i] + (1.f - s.a) * g;
+        const float m = s.a * P::ld(stp, i) + (1.f - s.a) * g;
         const float d = g - m;
-        const float sv = s.b * st[n + i] + (1.f - s.b) * d * d + eps;
-        st[i] = m; st[n + i] = sv;
+        const float sv = s.b * P::ld(stp, n + i) + (1.f - s.b) * d * d + eps;
+        P::st(stp, i, m); P::st(stp, n + i, sv);
         u = alpha_t * m / (sqrtf(sv) + eps);
       } break;
     }
     if (s.wd != 0.f) u += s.wd * (wd_lr ? s.lr : 1.f) * w;
     if (upd_only) {
-      grads[gi] = u;
+      P::st(grads, gi, u);
     } else {
       const float wn = w - u;
-      params[gi] = wn;
+      P::st(params, gi, wn);
       if (shadow != nullptr) shadow[gi] = f2bf(wn);
-      if (write_update) grads[gi] = u;
+      if (write_update) P::st(grads, gi, u);
     }
   }
 }
@@ -130,15 +156,110 @@ __global__ void incr_iter_kernel(int64_t* it) {
   if (threadIdx.x == 0 && blockIdx.x == 0) it[0] += 1;
 }
 
+// dtype: 0 fp32, 1 bf16, 2 fp16 (params, grads and state share it). lr_sched / sched_base / window / nseg: see LrSched (null = none).
+DL4J_API int dl4j_segmented_update_ex(void* params, void* grads, void* state, void* shadow_bf16,
+                                      const void* segs, const int32_t* blk_seg, const int32_t* blk_chunk,
+                                      int num_blocks, int64_t* iter_dev, float inv_batch, int write_update,
+                                      int increment_iter, int dtype, const float* lr_sched, const int64_t* sched_base,
+                                      int sched_window, int nseg, hipStream_t st) {
+  LrSched sc{lr_sched, sched_base, sched_window, nseg};
+  if (lr_sched == nullptr || sched_base == nullptr || sched_window <= 0) sc.table = nullptr;
+  if (num_blocks > 0) {
+    if (dtype == 0)
+      hipLaunchKernelGGL(segmented_updater_kernel<PF32>, dim3(num_blocks), dim3(256), 0, st, (float*)params, (float*)grads,
+                         (float*)state, (bf16_t*)shadow_bf16, (const UpdSeg*)segs, blk_seg, blk_chunk, iter_dev, inv_batch,
+                         write_update, sc);
+    else if (dtype == 1)
+      hipLaunchKernelGGL(segmented_updater_kernel<PBF16>, dim3(num_blocks), dim3(256), 0, st, (bf16_t*)params, (bf16_t*)grads,
+                         (bf16_t*)state, (bf16_t*)nullptr, (const UpdSeg*)segs, blk_seg, blk_chunk, iter_dev, inv_batch,
+                         write_update, sc);
+    else if (dtype == 2)
+      hipLaunchKernelGGL(segmented_updater_kernel<PF16>, dim3(num_blocks), dim3(256), 0, st, (_Float16*)params,
+                         (_Float16*)grads, (_Float16*)state, (bf16_t*)nullptr, (const UpdSeg*)segs, blk_seg, blk_chunk, iter_dev,
+                         inv_batch, write_update, sc);
+    else
+      return -2;
+  }
+  if (increment_iter) hipLaunchKernelGGL(incr_iter_kernel, dim3(1), dim3(64), 0, st, iter_dev);
+  DL4J_RET_LAST();
+}
 DL4J_API int dl4j_segmented_update(float* params, float* grads, float* state, void* shadow_bf16,
                                    const void* segs, const int32_t* blk_seg, const int32_t* blk_chunk,
                                    int num_blocks, int64_t* iter_dev, float inv_batch, int write_update,
                                    int increment_iter, hipStream_t st) {
-  if (num_blocks > 0)
-    hipLaunchKernelGGL(segmented_updater_kernel, dim3(num_blocks), dim3(256), 0, st, params, grads, state,
-                       (bf16_t*)shadow_bf16, (const UpdSeg*)segs, blk_seg, blk_chunk, iter_dev, inv_batch,
-                       write_update);
-  if (increment_iter) hipLaunchKernelGGL(incr_iter_kernel, dim3(1), dim3(64), 0, st, iter_dev);
+  return dl4j_segmented_update_ex(params, grads, state, shadow_bf16, segs, blk_seg, blk_chunk, num_blocks, iter_dev, inv_batch,
+                                  write_update, increment_iter, 0, nullptr, nullptr, 0, 0, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Gradient normalization (GradientNormalization.java; applied in BaseMultiLayerUpdater.preApply:405-453) over a table of
+// ranges of the flat gradient vector — one range per layer (…PerLayer modes) or per parameter tensor (…PerParamType):
+//   mode 1 renormalize: g /= ||g||_2      mode 2 clip element-wise to [-thr, thr]      mode 3 clip L2: g *= thr/||g|| if ||g|| > thr
+// Two launches for the whole network (sum of squares per range, then apply), no host round trip: graph-capturable.
+// ---------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(8))) GnSeg {
+  int64_t off, len;
+  int32_t mode;
+  float thr;
+};
+static_assert(sizeof(GnSeg) == 24, "GnSeg layout is part of the ctypes ABI");
+
+template <class P>
+__global__ void __launch_bounds__(256) gn_sumsq_kernel(const typename P::T* __restrict__ grads, const GnSeg* __restrict__ segs,
+                                                       const int32_t* __restrict__ blk_seg, const int32_t* __restrict__ blk_chunk,
+                                                       float* __restrict__ acc) {
+  __shared__ float red[16];
+  const int si = blk_seg[blockIdx.x];
+  const GnSeg s = segs[si];
+  if (s.mode == 2) return;
+  const int64_t start = (int64_t)blk_chunk[blockIdx.x] * UPD_CHUNK;
+  const int64_t end = (start + UPD_CHUNK < s.len) ? start + UPD_CHUNK : s.len;
+  float a = 0.f;
+  for (int64_t i = start + threadIdx.x; i < end; i += 256) { const float g = P::ld(grads, s.off + i); a += g * g; }
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) atomicAdd(acc + si, a);
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) gn_apply_kernel(typename P::T* __restrict__ grads, const GnSeg* __restrict__ segs,
+                                                       const int32_t* __restrict__ blk_seg, const int32_t* __restrict__ blk_chunk,
+                                                       const float* __restrict__ acc) {
+  const int si = blk_seg[blockIdx.x];
+  const GnSeg s = segs[si];
+  const int64_t start = (int64_t)blk_chunk[blockIdx.x] * UPD_CHUNK;
+  const int64_t end = (start + UPD_CHUNK < s.len) ? start + UPD_CHUNK : s.len;
+  float scale = 1.f;
+  if (s.mode == 1) {
+    scale = 1.f / fmaxf(sqrtf(acc[si]), 1e-12f);
+  } else if (s.mode == 3) {
+    const float nrm = sqrtf(acc[si]);
+    if (!(nrm > s.thr)) return;
+    scale = s.thr / fmaxf(nrm, 1e-12f);
+  }
+  for (int64_t i = start + threadIdx.x; i < end; i += 256) {
+    const float g = P::ld(grads, s.off + i);
+    P::st(grads, s.off + i, s.mode == 2 ? fminf(fmaxf(g, -s.thr), s.thr) : g * scale);
+  }
+}
+
+DL4J_API int dl4j_grad_normalize(void* grads, const void* segs, int nseg, const int32_t* blk_seg, const int32_t* blk_chunk,
+                                 int num_blocks, float* acc /* nseg floats */, int dtype, hipStream_t st) {
+  if (num_blocks <= 0 || nseg <= 0) return 0;
+  if (hipMemsetAsync(acc, 0, sizeof(float) * (size_t)nseg, st) != hipSuccess) return -1;
+  const dim3 g(num_blocks), b(256);
+  const GnSeg* sg = (const GnSeg*)segs;
+  if (dtype == 0) {
+    hipLaunchKernelGGL(gn_sumsq_kernel<PF32>, g, b, 0, st, (const float*)grads, sg, blk_seg, blk_chunk, acc);
+    hipLaunchKernelGGL(gn_apply_kernel<PF32>, g, b, 0, st, (float*)grads, sg, blk_seg, blk_chunk, acc);
+  } else if (dtype == 1) {
+    hipLaunchKernelGGL(gn_sumsq_kernel<PBF16>, g, b, 0, st, (const bf16_t*)grads, sg, blk_seg, blk_chunk, acc);
+    hipLaunchKernelGGL(gn_apply_kernel<PBF16>, g, b, 0, st, (bf16_t*)grads, sg, blk_seg, blk_chunk, acc);
+  } else if (dtype == 2) {
+    hipLaunchKernelGGL(gn_sumsq_kernel<PF16>, g, b, 0, st, (const _Float16*)grads, sg, blk_seg, blk_chunk, acc);
+    hipLaunchKernelGGL(gn_apply_kernel<PF16>, g, b, 0, st, (_Float16*)grads, sg, blk_seg, blk_chunk, acc);
+  } else {
+    return -2;
+  }
   DL4J_RET_LAST();
 }
 

@@ -24,6 +24,26 @@ _IMPL: Dict[str, Callable] = {}
 _PLATFORM: Dict[str, List] = {}
 _LOADED = False
 
+# Platform-helper accounting (reference: the helperCountFail / "helper not used" diagnostics of the cuDNN / oneDNN platform ops,
+# ops/declarable/PlatformHelper.h + Environment::helpersAllowed): every time an op that HAS a hand-written HIP route is executed
+# on GPU tensors, either the route ran ("hit") or the generic ATen implementation did ("fail", with the reason). Nothing falls back
+# unseen: OpExecutioner.helperStatistics() returns the counters, DL4J_AMD_LOG_FALLBACKS=1 logs each (op, reason) once.
+import collections
+import logging
+import os
+
+HELPER_HIT: Dict[str, int] = collections.Counter()
+HELPER_FAIL: Dict[tuple, int] = collections.Counter()
+_LOG_FALLBACKS = os.environ.get("DL4J_AMD_LOG_FALLBACKS", "0") == "1"
+_log = logging.getLogger("deeplearning4j_amd.ops")
+
+
+def _helper_fail(name, reason):
+    key = (name, reason)
+    if _LOG_FALLBACKS and key not in HELPER_FAIL:
+        _log.warning("op %s: platform helper not used (%s) - generic implementation runs", name, reason)
+    HELPER_FAIL[key] += 1
+
 
 def op(*names):
     """Register the generic implementation: fn(ins, i, t, b, d) -> tensor | tuple of tensors."""
@@ -154,6 +174,8 @@ class OpContext:
 def _t(x):
     if x is None:
         return None
+    if getattr(x, "_nd4j_opaque", False):
+        return x                      # NDArrayList handles travel through op inputs / outputs as they are
     if hasattr(x, "tensor"):
         return x.tensor()
     if isinstance(x, torch.Tensor):
@@ -310,11 +332,19 @@ class OpExecutioner:
 
     def _run(self, name, ins, i, t, b, d, allow_helpers=True):
         _load_impls()
-        if allow_helpers and self.env.helpersAllowed() and name in _PLATFORM:
-            tracked = torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in ins)
-            for usable, fn in _PLATFORM[name]:
-                if (not tracked or getattr(fn, "_differentiable", False)) and usable(ins, i, t, b, d):
-                    return fn(ins, i, t, b, d)
+        if name in _PLATFORM:
+            on_gpu = any(isinstance(x, torch.Tensor) and x.is_cuda for x in ins)
+            if allow_helpers and self.env.helpersAllowed():
+                tracked = torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in ins)
+                for usable, fn in _PLATFORM[name]:
+                    if (not tracked or getattr(fn, "_differentiable", False)) and usable(ins, i, t, b, d):
+                        HELPER_HIT[name] += 1
+                        return fn(ins, i, t, b, d)
+                if on_gpu:
+                    _helper_fail(name, "autograd-tracked inputs" if tracked and not any(getattr(f, "_differentiable", False) for _, f in _PLATFORM[name])
+                                 else "isUsable predicate rejected the arguments")
+            elif on_gpu and allow_helpers:
+                _helper_fail(name, "helpers disabled (Environment.allowHelpers=false)")
         if name not in _IMPL:
             canon = name_by_hash(op_hash(name))         # DECLARE_SYN aliases resolve to the canonical op (mmul -> matmul)
             if canon is None or canon not in _IMPL:
@@ -351,7 +381,8 @@ class OpExecutioner:
                 if dst is not None and src is not None and dst is not src:
                     dst.copy_(src.reshape(dst.shape) if src.numel() == dst.numel() else src)
             outs = [dst if dst is not None else src for dst, src in zip(ctx.outputs, outs)] + outs[len(ctx.outputs):]
-        elif ctx.inplace and outs and ins and outs[0].shape == ins[0].shape and outs[0].dtype == ins[0].dtype:
+        elif ctx.inplace and outs and ins and isinstance(outs[0], torch.Tensor) and isinstance(ins[0], torch.Tensor) \
+                and outs[0].shape == ins[0].shape and outs[0].dtype == ins[0].dtype:
             ins[0].copy_(outs[0])
             outs[0] = ins[0]
         ctx.outputs = outs
@@ -359,6 +390,19 @@ class OpExecutioner:
 
     def execAndReturn(self, op_):
         return self.exec(op_)[0]
+
+    @staticmethod
+    def helperStatistics():
+        """{'hit': {op: n}, 'fail': {(op, reason): n}, 'legacy': {(family, reason): n}} since the last reset."""
+        from . import legacy
+        return {"hit": dict(HELPER_HIT), "fail": dict(HELPER_FAIL), "legacy": dict(legacy.FALLBACKS)}
+
+    @staticmethod
+    def resetHelperStatistics():
+        from . import legacy
+        HELPER_HIT.clear()
+        HELPER_FAIL.clear()
+        legacy.FALLBACKS.clear()
 
     def calculateOutputShape(self, op_) -> List[List[int]]:
         """Shape inference by meta execution (DECLARE_SHAPE_FN analogue)."""

@@ -627,6 +627,7 @@ def _firas_sparse(ins, i, t, b, d):
 
 # ----------------------------------------------------------------------------- TensorArray list ops
 class NDArrayList:
+    _nd4j_opaque = True
     """TensorArray used by the list ops (reference: array/NDArrayList.h)."""
 
     def __init__(self, height=0, expandable=True):

@@ -1219,6 +1219,11 @@ def _updater(kind_name, n_state):
     def f(ins, i, t, b, d):
         g = ins[0]
         states = [s.clone() for s in ins[1:1 + n_state]]
+        # the Adam family declares its state arrays as (U | V = second moment, M = first moment[, H]) — generic/updaters/
+        # adamUpdater.cpp:36-40 — while the fused kernel's flat layout is [m | v | h]
+        swap = kind_name in ("Adam", "AdaMax", "Nadam", "AMSGrad", "AdaBelief")
+        if swap:
+            states[0], states[1] = states[1], states[0]
         extra_in = ins[1 + n_state:]
         tt = list(t) if t else [float(v) for v in extra_in]
         it = int(i[0]) if i else 0
@@ -1243,8 +1248,10 @@ def _updater(kind_name, n_state):
         flat_state = torch.cat([s.reshape(-1) for s in states]) if states else g.new_zeros(0)
         grads = g.reshape(-1).clone()
         U.apply_segment_reference(seg, grads.new_zeros(n), grads, flat_state, 1.0, float(it + 1))
-        outs = [grads.reshape(g.shape)] + [flat_state[k * n:(k + 1) * n].reshape(g.shape) for k in range(n_state)]
-        return tuple(outs)
+        new_states = [flat_state[k * n:(k + 1) * n].reshape(g.shape) for k in range(n_state)]
+        if swap:
+            new_states[0], new_states[1] = new_states[1], new_states[0]
+        return tuple([grads.reshape(g.shape)] + new_states)
     return f
 
 
@@ -1302,7 +1309,7 @@ def _random_poisson(ins, i, t, b, d):
 @op("random_multinomial")
 def _random_multinomial(ins, i, t, b, d):
     logits, n = ins[0], int(ins[1])
-    dim = int(i[0]) if i else 0
+    dim = int(i[0]) if i else -1          # libnd4j random_multinomial: classes along the last dimension unless dimC is given
     lg = logits if dim in (1, -1) or logits.dim() == 1 else logits.t()
     g = torch.Generator(device=lg.device).manual_seed(_rng().getRandom().nextInt())
     r = torch.multinomial(torch.softmax(lg.float(), -1), n, True, generator=g)

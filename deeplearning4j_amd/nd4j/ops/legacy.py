@@ -412,6 +412,22 @@ def _prod(x, d):
     return x
 
 
+# GPU operands that do NOT reach the HIP legacy kernels are counted here by reason (OpExecutioner.helperStatistics()['legacy'])
+# and, with DL4J_AMD_LOG_FALLBACKS=1, logged once per reason — there is no unseen fallback.
+import collections as _collections
+import logging as _logging
+import os as _os
+
+FALLBACKS = _collections.Counter()
+_LOG_FB = _os.environ.get("DL4J_AMD_LOG_FALLBACKS", "0") == "1"
+
+
+def _fallback(reason):
+    if _LOG_FB and reason not in FALLBACKS:
+        _logging.getLogger("deeplearning4j_amd.ops").warning("legacy op on GPU operands runs on ATen: %s", reason)
+    FALLBACKS[reason] += 1
+
+
 # ----------------------------------------------------------------------------- executioner
 class LegacyOpExecutioner:
     """exec* entry points by (family, opNum). Mirrors NativeOpExecutioner::exec* (legacy/cuda/NativeOpExecutioner.cu)."""
@@ -419,9 +435,16 @@ class LegacyOpExecutioner:
     # -- helpers
     @staticmethod
     def _gpu_ok(*ts):
+        on_gpu = any(t is not None and t.is_cuda for t in ts)
         if _FORCE_TORCH[0] or any(t is not None and t.requires_grad for t in ts):
-            return False        # autograd sessions (SameDiff training) need the differentiable ATen formulation
-        return L.use_hip(*ts) and all(t is None or L.dtype_code_all(t) >= 0 for t in ts)
+            if on_gpu:      # autograd sessions (SameDiff training) need the differentiable ATen formulation
+                _fallback("forced ATen (gradient recording)" if _FORCE_TORCH[0] else "autograd-tracked operand")
+            return False
+        ok = L.use_hip(*ts) and all(t is None or L.dtype_code_all(t) >= 0 for t in ts)
+        if on_gpu and not ok:
+            _fallback("dtype without a HIP instantiation: %s" % sorted({str(t.dtype) for t in ts if t is not None and L.dtype_code_all(t) < 0})
+                      if L.use_hip(*ts) else "operands on different devices / eager forced")
+        return ok
 
     def _pairwise(self, name, x, y, z, extra, scalar=None, zbool=False):
         if scalar is None:

@@ -195,6 +195,7 @@ class ComputationGraph(BaseNetwork):
             if isinstance(impl, ConvolutionLayerImpl):
                 impl.fold_bias = False
                 impl.want_stats = False
+                impl.stats_consumer = None
             elif isinstance(impl, BatchNormalizationImpl):
                 impl.conv_bias = None
                 impl.producer = None
@@ -246,6 +247,7 @@ class ComputationGraph(BaseNetwork):
                             and b.conf.idropout is None and (a.fold_bias or "b" not in a.params)):
                         a.want_stats = True
                         b.producer = a
+                        a.stats_consumer = b
         plan = []
         for n in self.topologicalOrder:
             if n in fused_away:

@@ -4,7 +4,7 @@ The reference drains both CUDA streams before every custom op (CudaExecutioner.j
 so an iteration is thousands of synchronous launches. Here, for static shapes, the iteration is
 captured once into hipGraphs and replayed: launch overhead disappears and the GPU runs
 back-to-back kernels. Everything the iteration reads that changes between steps lives in device
-memory (input/label staging buffers, updater iteration counter, learning-rate segment table).
+memory (input/label staging buffers, updater iteration counter, learning-rate segment table, learning-rate SCHEDULE table).
 
 Data-parallel mode splits the capture: A = forward+backward, B = fused update, with the RCCL
 gradient all-reduce issued eagerly between the replays. When the wrapper provides gradient buckets
@@ -49,8 +49,7 @@ class CapturedTrainStep:
         self._x.copy_(x, non_blocking=True)
         self._y.copy_(y, non_blocking=True)
         if self.graph_a is None:
-            if self._seen < self.warmup or net._has_schedule:
-                # LR schedules re-upload the segment table from the host every step: stay eager
+            if self._seen < self.warmup:
                 self._seen += 1
                 hook, net._on_backward_progress = net._on_backward_progress, None
                 self._compute(self._x, self._y)
@@ -85,11 +84,20 @@ class CapturedTrainStep:
             self.graph_a.replay()
             if net._grad_sync is not None:
                 net._grad_sync()
+        if net._has_schedule:
+            # learning-rate schedules live in a device table indexed by the device iteration counter; the host only tops the
+            # table up when its window runs out (ops/updater.SegmentedUpdater.ensure_schedule)
+            net._updater.ensure_schedule(net.iterationCount, net.epochCount)
         self.graph_b.replay()
 
     def _capture_stream(self):
         if self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream()
+            # persistent per-stream scratch the kernels need must exist BEFORE the capture starts (a buffer allocated while
+            # capturing would live in the graph's private pool): the ticket counters of the in-kernel BatchNorm reductions
+            from ..ops import batchnorm as BN
+            with torch.cuda.stream(self._cap_stream):
+                BN.ticket_ws(self.net.ctx.device)
         return self._cap_stream
 
     def _capture_segmented(self, buckets):

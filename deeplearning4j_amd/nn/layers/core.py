@@ -318,6 +318,12 @@ class BatchNormalizationImpl(LayerImpl):
             return y2.view(shp).permute(0, 2, 1)
         return y2.view(shp).permute(0, 4, 1, 2, 3)
 
+    def finalize_request(self):
+        """Everything the producing conv needs to run this layer's training-mode finalize inside its own launch."""
+        gamma, beta, gmean, gvar, dgm, dgv = self._views()
+        cb = self.conv_bias() if self.conv_bias is not None else None
+        return BN.FinalizeRequest(gamma, beta, cb, gmean, gvar, dgm, dgv, self.conf.eps, self.conf.decay, self.conf.useLogStd)
+
     def coefficients(self, x2, train):
         """(scale, shift) for this call; in training also stores mean/invstd and writes stat gradients."""
         gamma, beta, gmean, gvar, dgm, dgv = self._views()
@@ -413,8 +419,11 @@ class ConvolutionLayerImpl(LayerImpl):
         self.input, self._pad = x, pad
         c = self.conf
         b = None if (self.fold_bias or "b" not in self.params) else self.w("b").reshape(-1)
+        fin = None
+        if self.want_stats and train and getattr(self, "stats_consumer", None) is not None:
+            fin = self.stats_consumer.finalize_request()
         z, self.out_sums = CONV.conv2d_forward(x, self.w("W"), b, c.stride, pad, c.dilation,
-                                               want_stats=self.want_stats and train)
+                                               want_stats=self.want_stats and train, bn_fin=fin)
         act = c.activationFn
         if act is None or isinstance(act, ActivationIdentity):
             self.z = None

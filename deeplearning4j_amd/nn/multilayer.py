@@ -91,6 +91,7 @@ class MultiLayerNetwork(BaseNetwork):
                     and b.conf.idropout is None and (a.fold_bias or "b" not in a.params)):
                 a.want_stats = True
                 b.producer = a
+                a.stats_consumer = b
         return plan
 
     # ------------------------------------------------------------------ accessors

@@ -244,6 +244,38 @@ class BaseNetwork:
                 self._updater_state[s.state_off:s.state_off + U.STATE_MULT[s.kind] * s.length].fill_(v)
         self._updater = U.SegmentedUpdater(segs, self.ctx.device)
         self._updater.set_iteration(self.iterationCount)
+        if self._has_schedule:
+            ups = list(self._seg_updaters)
+            self._updater.set_schedule(lambda it, ep: [u.getLearningRate(it, ep) if u.hasLearningRate() else None for u in ups])
+        self._gn_table = self._build_grad_norm_table()
+
+    def _build_grad_norm_table(self):
+        """Ranges of the flat gradient vector for the configured GradientNormalization modes (one per layer or per parameter)."""
+        by_layer = {}
+        for e in self._entries:
+            by_layer.setdefault(id(e.layer), []).append(e)
+        ranges = []
+        for l in self._ordered_layers():
+            gn = getattr(l.conf, "gradientNormalization", None)
+            if not gn or gn == GradientNormalization.NONE:
+                continue
+            ents = by_layer.get(id(l), [])
+            if not ents:
+                continue
+            name = gn if isinstance(gn, str) else getattr(gn, "name", str(gn))
+            if name not in U.GradNormTable.MODES:
+                return None
+            mode, scope = U.GradNormTable.MODES[name]
+            thr = getattr(l.conf, "gradientNormalizationThreshold", 1.0) or 1.0
+            if scope == "param":
+                ranges += [(e.off, e.spec.numel, mode, thr) for e in ents]
+            else:
+                lo = min(e.off for e in ents)
+                hi = max(e.off + e.spec.numel for e in ents)
+                if hi - lo != sum(e.spec.numel for e in ents):
+                    return None                       # layer not contiguous in the flat vector: per-layer eager path
+                ranges.append((lo, hi - lo, mode, thr))
+        return U.GradNormTable(ranges, self.ctx.device)
 
     def getUpdaterBlocks(self):
         """[(offset, length, IUpdater)] — UpdaterBlock structure of the flat vector."""
@@ -252,12 +284,12 @@ class BaseNetwork:
     def _apply_update(self, batch_size, sync=True):
         if sync and self._grad_sync is not None:
             self._grad_sync()
-        if self._has_schedule:
-            self._updater.set_learning_rates([u.getLearningRate(self.iterationCount, self.epochCount)
-                                              if u.hasLearningRate() else None for u in self._seg_updaters])
+        if self._has_schedule and not (self._params.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._updater.ensure_schedule(self.iterationCount, self.epochCount)
         self._pre_apply_gradient_normalization()
         mb = batch_size if getattr(self, "_minibatch", True) else 1
-        if self._params.dtype == torch.float32:
+        if self._params.dtype == torch.float32 or (self._params.is_cuda and self._params.dtype in (torch.bfloat16, torch.float16)
+                                                   and self._grads.dtype == self._params.dtype):
             self._updater.step(self._params, self._grads, self._updater_state, mb)
         else:
             t = float(self.iterationCount + 1)
@@ -267,6 +299,9 @@ class BaseNetwork:
         self._refresh_replicas()
 
     def _pre_apply_gradient_normalization(self):
+        if getattr(self, "_gn_table", None) is not None:
+            self._gn_table.run(self._grads)
+            return
         for l in self._ordered_layers():
             gn = getattr(l.conf, "gradientNormalization", None)
             if not gn or gn == GradientNormalization.NONE or not l.grads:

@@ -40,6 +40,49 @@ def _workspace(C, device):
     return ws
 
 
+# DL4J_AMD_BN_TICKET=0 restores the two-launch reductions (bn_sum_partials / bn_finalize_partials kernels)
+_FUSE_STAGE2 = __import__("os").environ.get("DL4J_AMD_BN_TICKET", "1") != "0"
+_TICKET = {}
+TICKET_COUNTERS = 65536
+TICKET_GPART = 1 << 20
+
+
+def ticket_ws(device):
+    """(counters, group partials) of the in-kernel second reduction stage (native/csrc/ticket.h): zero-initialised, self-resetting
+    counters shared by every launch on the stream. None while a graph is being captured and no buffer exists yet (a buffer from
+    the capture's private pool must not outlive the graph) — callers then use the two-launch form."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    e = _TICKET.get(key)
+    if e is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        e = (torch.zeros(TICKET_COUNTERS, device=device, dtype=torch.int32), torch.empty(TICKET_GPART, device=device, dtype=torch.float32))
+        _TICKET[key] = e
+    return e
+
+
+class FinalizeRequest:
+    """What the conv kernel needs to run this BatchNorm's finalize in its own epilogue (conv_igemm.forward(bn_fin=...))."""
+    __slots__ = ("gamma", "beta", "conv_bias", "gmean", "gvar", "dgmean", "dgvar", "eps", "decay", "stat_mode")
+
+    def __init__(self, gamma, beta, conv_bias, gmean, gvar, dgmean, dgvar, eps, decay, log_std):
+        self.gamma, self.beta, self.conv_bias, self.gmean, self.gvar = gamma, beta, conv_bias, gmean, gvar
+        self.dgmean, self.dgvar, self.eps, self.decay = dgmean, dgvar, float(eps), float(decay)
+        self.stat_mode = 0 if dgmean is None else (2 if log_std else 1)
+
+    def ok(self):
+        ts = [t for t in (self.gamma, self.beta, self.conv_bias, self.gmean, self.gvar, self.dgmean, self.dgvar) if t is not None]
+        return all(t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+
+
+class Finalized:
+    """mean / invstd / scale / shift already written by the producing conv's last workgroup."""
+    __slots__ = ("mean", "invstd", "scale", "shift", "K")
+
+    def __init__(self, buf, K):
+        self.mean, self.invstd, self.scale, self.shift, self.K = buf[:K], buf[K:2 * K], buf[2 * K:3 * K], buf[3 * K:], K
+
+
 def _hip_ok(x):
     return L.use_hip(x) and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.is_contiguous()
 
@@ -107,6 +150,9 @@ def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std
         buf = torch.empty(6 * C, device=dev, dtype=torch.float32)
         mean, invstd, scale, shift = buf[2 * C:3 * C], buf[3 * C:4 * C], buf[4 * C:5 * C], buf[5 * C:]
         h = L.hip()
+        if isinstance(sums, Finalized):
+            assert sums.K == C
+            return sums.mean, sums.invstd, sums.scale, sums.shift
         if sums is not None and hasattr(sums, "partial"):
             # conv-epilogue partials: reduce + finalize in one launch
             assert sums.K == C and sums.partial.numel() >= sums.gy * 2 * C
@@ -159,10 +205,17 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
         direct = (dbeta_out is None or (dbeta_out.is_contiguous() and dbeta_out.dtype == torch.float32)) and \
                  (dgamma_out is None or (dgamma_out.is_contiguous() and dgamma_out.dtype == torch.float32))
         ms, mt = mask_coeffs if (mask_coeffs is not None and out2d is None) else (None, None)
-        L.check(h.dl4j_bn_bwd_reduce(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(ms), L.ptr(mt),
-                                     L.ptr(ws), L.ptr(sums), L.ptr(dbeta_out if direct else None),
-                                     L.ptr(dgamma_out if direct else None), L.c_int64(M), L.c_int(C), dt, L.stream()),
-                "bn_bwd_reduce")
+        tk = ticket_ws(x2d.device) if (_FUSE_STAGE2 and 128 * C <= TICKET_GPART) else None
+        if tk is not None:
+            L.check(h.dl4j_bn_bwd_reduce_fused(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(ms), L.ptr(mt),
+                                               L.ptr(ws), L.ptr(sums), L.ptr(dbeta_out if direct else None),
+                                               L.ptr(dgamma_out if direct else None), L.c_int64(M), L.c_int(C), dt, L.ptr(tk[1]),
+                                               L.ptr(tk[0]), L.stream()), "bn_bwd_reduce_fused")
+        else:
+            L.check(h.dl4j_bn_bwd_reduce(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(ms), L.ptr(mt),
+                                         L.ptr(ws), L.ptr(sums), L.ptr(dbeta_out if direct else None),
+                                         L.ptr(dgamma_out if direct else None), L.c_int64(M), L.c_int(C), dt, L.stream()),
+                    "bn_bwd_reduce")
         dx = torch.empty_like(x2d)
         dz = torch.empty_like(x2d) if want_dz else None
         L.check(h.dl4j_bn_bwd_dx(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),

@@ -88,7 +88,7 @@ class StatPartials:
         return out
 
 
-def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False):
+def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False, bn_fin=None):
     tile = pick_tile(M, Kout)
     stats = None
     mt = int(L.hip().dl4j_igemm_mtiles(L.c_int64(M), L.c_int(tile)))
@@ -96,6 +96,24 @@ def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False):
         # own buffer per call (not the shared scratch): two convs may run before their fused BN node consumes both
         stats = torch.empty(mt * 2 * Kout, device=x_t.device, dtype=torch.float32)
     g = (ctypes.c_int * 19)(*geom)
+    if want_stats and bn_fin is not None and bn_fin.ok():
+        from . import batchnorm as BN
+        ngroups = (mt + 31) // 32
+        ntiles = Kout // _TILES[tile][1]
+        tk = BN.ticket_ws(x_t.device) if (BN._FUSE_STAGE2 and ntiles * (1 + ngroups) <= BN.TICKET_COUNTERS
+                                          and ngroups * 2 * Kout <= BN.TICKET_GPART) else None
+        if tk is not None:
+            # the consuming BatchNorm's finalize runs in the last workgroup of this launch (native/csrc/ticket.h)
+            buf = torch.empty(4 * Kout, device=x_t.device, dtype=torch.float32)
+            f = bn_fin
+            ptrs = (ctypes.c_void_p * 11)(*[0 if t is None else t.data_ptr() for t in (
+                f.gamma, f.beta, f.conv_bias, f.gmean, f.gvar, buf[:Kout], buf[Kout:2 * Kout], buf[2 * Kout:3 * Kout], buf[3 * Kout:],
+                f.dgmean, f.dgvar)])
+            fp = (ctypes.c_float * 3)(f.eps, f.decay, float(f.stat_mode))
+            L.check(L.hip().dl4j_igemm_conv_fin(L.ptr(x_t), L.ptr(w_t), L.ptr(y_t), L.ptr(bias), L.ptr(stats), g, L.c_int(tile),
+                                                L.c_int(1 if accum else 0), None, ptrs, fp, L.ptr(tk[1]), L.ptr(tk[0]), L.stream()),
+                    "igemm_conv_fin")
+            return BN.Finalized(buf, Kout)
     L.check(L.hip().dl4j_igemm_conv(L.ptr(x_t), L.ptr(w_t), L.ptr(y_t), L.ptr(bias), L.ptr(stats), g, L.c_int(tile),
                                     L.c_int(1 if accum else 0), None, L.stream()), "igemm_conv")
     if not want_stats:
@@ -103,8 +121,9 @@ def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False):
     return StatPartials(stats, mt, Kout)
 
 
-def forward(x, w, b, stride, padding, dilation, want_stats=False):
-    """Returns (y, stats) — stats is a StatPartials (per-tile sum / sumsq rows) when want_stats."""
+def forward(x, w, b, stride, padding, dilation, want_stats=False, bn_fin=None):
+    """Returns (y, stats) — stats is a StatPartials (per-tile sum / sumsq rows) when want_stats, or a batchnorm.Finalized when
+    ``bn_fin`` (batchnorm.FinalizeRequest of the consuming layer) was given and the finalize ran inside the conv launch."""
     N, C, H, W = x.shape
     K, _, R, S = w.shape
     OH, OW = _out_hw(H, W, R, S, stride, padding, dilation)
@@ -113,7 +132,7 @@ def forward(x, w, b, stride, padding, dilation, want_stats=False):
     geom = (N, H, W, C, OH, OW, K, R, S, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
             OH, OW, 1, 1)
     bias = b.float().contiguous() if b is not None else None
-    sums = _launch(x, w, y, bias, geom, want_stats, K, M)
+    sums = _launch(x, w, y, bias, geom, want_stats, K, M, bn_fin=bn_fin)
     return y, sums
 
 

@@ -16,6 +16,7 @@ import torch
 
 from ..native import lib as L
 
+_UPD_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 KIND = {"NoOp": 0, "Sgd": 1, "Nesterovs": 2, "Adam": 3, "RmsProp": 4, "AdaGrad": 5, "AdaDelta": 6, "AdaMax": 7,
         "Nadam": 8, "AMSGrad": 9, "AdaBelief": 10}
 STATE_MULT = {0: 0, 1: 0, 2: 1, 3: 2, 4: 1, 5: 1, 6: 2, 7: 2, 8: 2, 9: 3, 10: 2}
@@ -67,6 +68,11 @@ class SegmentedUpdater:
         self._blk_seg = torch.from_numpy(bs).to(self.device)
         self._blk_chunk = torch.from_numpy(bc).to(self.device)
         self.iter_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        # device-resident learning-rate schedule (GPU): [window, nseg] table + first iteration it covers
+        self._sched_fn = None
+        self._sched_table = None
+        self._sched_base = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._sched_host = None          # (base, epoch) the table was filled for
         self._upload()
 
     def _upload(self):
@@ -91,15 +97,56 @@ class SegmentedUpdater:
     def set_iteration(self, it: int):
         self.iter_dev.fill_(int(it))
 
+    SCHED_WINDOW = 2048
+
+    def set_schedule(self, fn):
+        """``fn(iteration, epoch) -> [lr or None per segment]``. On the GPU the next SCHED_WINDOW iterations are evaluated once and
+        kept in device memory (the updater kernel indexes the table with its device iteration counter), so a captured training
+        step stays valid while the learning rate changes; the CPU path sets the rates per step."""
+        self._sched_fn = fn
+        self._sched_host = None
+
+    def ensure_schedule(self, iteration: int, epoch: int):
+        """Host side of the device schedule: (re)fill the table when ``iteration`` left the window or the epoch changed. Call it
+        before every step / graph replay; it is a no-op almost always. Also mirrors the current rates into ``segments``."""
+        if self._sched_fn is None:
+            return
+        cur = self._sched_fn(iteration, epoch)
+        for s, lr in zip(self.segments, cur):
+            if lr is not None:
+                s.lr = float(lr)
+        if self.device.type != "cuda":
+            self._tables_dirty = True
+            return
+        h = self._sched_host
+        if h is not None and h[1] == epoch and h[0] <= iteration < h[0] + self.SCHED_WINDOW:
+            return
+        nseg = len(self.segments)
+        rows = np.full((self.SCHED_WINDOW, nseg), np.nan, dtype=np.float32)
+        for k in range(self.SCHED_WINDOW):
+            for j, lr in enumerate(self._sched_fn(iteration + k, epoch)):
+                if lr is not None:
+                    rows[k, j] = lr
+        t = torch.from_numpy(rows)
+        if self._sched_table is None:
+            self._sched_table = t.to(self.device)
+        else:
+            self._sched_table.copy_(t, non_blocking=False)
+        self._sched_base.fill_(int(iteration))
+        self._sched_host = (iteration, epoch)
+
     def step(self, params, grads, state, batch_size: int, write_update: bool = False, shadow=None):
         if self._tables_dirty:
             self._upload()
         inv_b = 1.0 / float(max(batch_size, 1))
-        if L.use_hip(params) and params.dtype == torch.float32:
-            L.check(L.hip().dl4j_segmented_update(
-                L.ptr(params), L.ptr(grads), L.ptr(state), L.ptr(shadow), L.ptr(self._seg_dev), L.ptr(self._blk_seg),
-                L.ptr(self._blk_chunk), L.c_int(self.num_blocks), L.ptr(self.iter_dev), L.c_float(inv_b),
-                L.c_int(1 if write_update else 0), L.c_int(1), L.stream()), "segmented_update")
+        if L.use_hip(params) and params.dtype in _UPD_DT and grads.dtype == params.dtype and state.dtype == params.dtype:
+            sched = self._sched_table if self._sched_fn is not None else None
+            L.check(L.hip().dl4j_segmented_update_ex(
+                L.ptr(params), L.ptr(grads), L.ptr(state), L.ptr(shadow if params.dtype == torch.float32 else None),
+                L.ptr(self._seg_dev), L.ptr(self._blk_seg), L.ptr(self._blk_chunk), L.c_int(self.num_blocks), L.ptr(self.iter_dev),
+                L.c_float(inv_b), L.c_int(1 if write_update else 0), L.c_int(1), L.c_int(_UPD_DT[params.dtype]), L.ptr(sched),
+                L.ptr(self._sched_base), L.c_int(self.SCHED_WINDOW if sched is not None else 0), L.c_int(len(self.segments)),
+                L.stream()), "segmented_update")
             return
         t = float(self.iter_dev.item() + 1)
         for s in self.segments:
@@ -225,6 +272,45 @@ class CastTable:
             elif K > 1:
                 s = s.view(-1, I, K).permute(0, 2, 1).reshape(-1)
             dst_bf16[do:do + n] = s.to(dst_bf16.dtype)
+
+
+class GradNormTable:
+    """Gradient normalization of the whole network in two launches (native/csrc/updaters.hip gn_*): ``ranges`` =
+    [(offset, length, mode, threshold)] over the flat gradient vector, mode 1 renormalize-L2, 2 clip element-wise, 3 clip-L2; one
+    range per layer or per parameter tensor (GradientNormalization.java, BaseMultiLayerUpdater.preApply:405-453)."""
+    MODES = {"RenormalizeL2PerLayer": (1, "layer"), "RenormalizeL2PerParamType": (1, "param"),
+             "ClipElementWiseAbsoluteValue": (2, "param"), "ClipL2PerLayer": (3, "layer"), "ClipL2PerParamType": (3, "param")}
+
+    def __init__(self, ranges, device):
+        self.ranges = [tuple(r) for r in ranges]
+        self.device = torch.device(device)
+        raw = b"".join(struct.pack("<qqif", int(o), int(n), int(m), float(t)) for (o, n, m, t) in self.ranges)
+        self._seg = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device) if raw
+                     else torch.zeros(0, dtype=torch.uint8, device=self.device))
+        bs, bc = _block_tables([r[1] for r in self.ranges])
+        self.num_blocks = int(bs.shape[0])
+        self._blk_seg = torch.from_numpy(bs).to(self.device)
+        self._blk_chunk = torch.from_numpy(bc).to(self.device)
+        self._acc = torch.zeros(max(len(self.ranges), 1), dtype=torch.float32, device=self.device)
+
+    def run(self, grads):
+        if not self.ranges:
+            return
+        if L.use_hip(grads) and grads.dtype in _UPD_DT:
+            L.check(L.hip().dl4j_grad_normalize(L.ptr(grads), L.ptr(self._seg), L.c_int(len(self.ranges)), L.ptr(self._blk_seg),
+                                                L.ptr(self._blk_chunk), L.c_int(self.num_blocks), L.ptr(self._acc),
+                                                L.c_int(_UPD_DT[grads.dtype]), L.stream()), "grad_normalize")
+            return
+        for (o, n, m, thr) in self.ranges:
+            g = grads[o:o + n]
+            if m == 2:
+                g.clamp_(-thr, thr)
+                continue
+            nrm = torch.sqrt((g.double() ** 2).sum())
+            if m == 1:
+                g.div_(nrm.clamp_min(1e-12).to(g.dtype))
+            else:
+                g.mul_(torch.where(nrm > thr, thr / nrm.clamp_min(1e-12), torch.ones_like(nrm)).to(g.dtype))
 
 
 def global_sumsq(x: torch.Tensor) -> torch.Tensor:

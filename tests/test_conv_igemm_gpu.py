@@ -128,3 +128,66 @@ def test_hand_written_gemm_nt_matches_fp32(M, N, K):
     got = G.gemm_nt(x, w, b).float()
     assert got.shape == ref.shape
     assert float((got - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 28, 28, 256, 1), (4, 128, 14, 14, 128, 3), (64, 64, 28, 28, 64, 1), (2, 256, 7, 7, 1024, 1),
+                                   (32, 64, 56, 56, 64, 1)])
+@pytest.mark.parametrize("log_std", [False, True])
+def test_conv_epilogue_runs_the_batchnorm_finalize(shape, log_std):
+    """The consuming BatchNorm's mean / invstd / scale / shift and running-statistic deltas come out of the conv launch itself
+    (last-workgroup finalize, native/csrc/ticket.h) and equal the statistics of the rounded conv output computed by PyTorch in fp32;
+    repeated launches reuse the self-resetting counters."""
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    from deeplearning4j_amd.ops import batchnorm as BN
+    N, C, H, W, K, R = shape
+    x, w = _mk(N, C, H, W, K, R, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    gamma = torch.rand(K, device="cuda", generator=g) + 0.5
+    beta = torch.randn(K, device="cuda", generator=g)
+    cb = torch.randn(K, device="cuda", generator=g)
+    gmean = torch.randn(K, device="cuda", generator=g)
+    gvar = torch.rand(K, device="cuda", generator=g) * (0.3 if log_std else 1.0) + 0.1
+    eps, decay = 1e-5, 0.9
+    for rep in range(4):
+        dgm, dgv = torch.full((K,), 7.0, device="cuda"), torch.full((K,), 7.0, device="cuda")
+        req = BN.FinalizeRequest(gamma, beta, cb, gmean, gvar, dgm, dgv, eps, decay, log_std)
+        y, fin = IG.forward(x, w, None, (1, 1), (R // 2, R // 2), (1, 1), want_stats=True, bn_fin=req)
+        assert isinstance(fin, BN.Finalized)
+        yf = y.float().permute(0, 2, 3, 1).reshape(-1, K)
+        mean, var = yf.mean(0), yf.var(0, unbiased=False)
+        assert torch.allclose(fin.mean, mean, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(fin.invstd, torch.rsqrt(var + eps), rtol=2e-3)
+        assert torch.allclose(fin.scale, gamma * torch.rsqrt(var + eps), rtol=2e-3)
+        assert torch.allclose(fin.shift, beta - mean * gamma * torch.rsqrt(var + eps), rtol=2e-3, atol=1e-3)
+        rm, rv = BN.running_stat_grads(mean, var, gmean, gvar, decay, log_std, cb)
+        assert torch.allclose(dgm, rm, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(dgv, rv, rtol=2e-3, atol=1e-4)
+    cnt, _ = BN.ticket_ws(x.device)
+    assert int(cnt.abs().sum()) == 0                       # every counter was handed back at zero
+
+
+def test_bn_backward_fused_second_stage_equals_two_launch_form():
+    from deeplearning4j_amd.ops import batchnorm as BN
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for (M, C) in [(200704, 64), (50176, 256), (3136, 2048), (77, 24), (12544, 1024)]:
+        x = torch.randn(M, C, device="cuda", generator=g).bfloat16()
+        dy = torch.randn(M, C, device="cuda", generator=g).bfloat16()
+        mean, invstd = x.float().mean(0), torch.rsqrt(x.float().var(0, unbiased=False) + 1e-5)
+        gamma = torch.rand(C, device="cuda", generator=g) + 0.5
+        outs = []
+        for fused in (True, False, True):
+            BN._FUSE_STAGE2 = fused
+            try:
+                dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+                dx, _ = BN.backward(x, dy, None, mean, invstd, gamma, dg, db, mask_coeffs=(gamma * invstd, -mean * gamma * invstd))
+            finally:
+                BN._FUSE_STAGE2 = True
+            outs.append((dg, db, dx))
+        for a, b in zip(outs[0], outs[1]):
+            # the two forms add the partial rows in a different order: fp32 sums agree to ~1e-6, dx (bf16) to one rounding step
+            tol = 2.0 ** -7 if a.dtype == torch.bfloat16 else 1e-4
+            assert torch.allclose(a.float(), b.float(), rtol=tol, atol=tol * float(b.float().abs().max()))
+        for a, b in zip(outs[0], outs[2]):
+            assert torch.equal(a, b)                        # the fused form is deterministic
+    cnt, _ = BN.ticket_ws(x.device)
+    assert int(cnt.abs().sum()) == 0

@@ -251,3 +251,54 @@ def test_samediff_output_layer_vertex_and_lambda_vertex_train():
              .addVertex("sd", ScaleAddVertex(4), "d0", "d0").addLayer("out", MseOut(nIn=4, nOut=2), "sd").setOutputs("out").build())
     n2 = ComputationGraph(conf2, device="cpu").init()
     assert GradientCheckUtil.checkGradients(n2, [torch.randn(5, 3, dtype=torch.float64)], [torch.rand(5, 2, dtype=torch.float64)], epsilon=1e-6, maxRelError=1e-5)
+
+
+def test_grad_norm_table_equals_layerwise_gradient_normalization():
+    """The range-table form of GradientNormalization (one launch pair on the GPU) is the per-layer / per-parameter reference math."""
+    from deeplearning4j_amd.nn.conf.base import GradientNormalization as GN
+    from deeplearning4j_amd.nd4j.learning import Sgd
+    from deeplearning4j_amd.nn.conf.configuration import NeuralNetConfiguration
+    from deeplearning4j_amd.nn.conf.layers import DenseLayer, OutputLayer
+    from deeplearning4j_amd.nn.conf.base import InputType
+    from deeplearning4j_amd.nn.multilayer import MultiLayerNetwork
+    for mode in (GN.RenormalizeL2PerLayer, GN.RenormalizeL2PerParamType, GN.ClipElementWiseAbsoluteValue, GN.ClipL2PerLayer,
+                 GN.ClipL2PerParamType):
+        conf = (NeuralNetConfiguration.Builder().seed(3).updater(Sgd(0.1)).gradientNormalization(mode)
+                .gradientNormalizationThreshold(0.01).list()
+                .layer(DenseLayer(nIn=6, nOut=9, activation="TANH")).layer(OutputLayer(nIn=9, nOut=3, activation="SOFTMAX", lossFunction="MCXENT"))
+                .setInputType(InputType.feedForward(6)).build())
+        net = MultiLayerNetwork(conf, device="cpu").init()
+        assert net._gn_table is not None and len(net._gn_table.ranges) == (2 if "Layer" in mode else 4)
+        x = torch.randn(10, 6, generator=torch.Generator().manual_seed(1))
+        y = torch.eye(3)[torch.arange(10) % 3]
+        net.computeGradientAndScore(x, y)
+        g0 = net._grads.clone()
+        net._pre_apply_gradient_normalization()
+        got = net._grads.clone()
+        net._grads.copy_(g0)
+        tbl, net._gn_table = net._gn_table, None           # the layer-by-layer reference implementation
+        net._pre_apply_gradient_normalization()
+        net._gn_table = tbl
+        assert torch.allclose(got, net._grads, rtol=1e-6, atol=1e-9), mode
+        assert not torch.equal(got, g0)
+
+
+def test_learning_rate_schedule_is_followed_on_cpu():
+    from deeplearning4j_amd.nd4j.learning import Sgd, StepSchedule
+    from deeplearning4j_amd.nn.conf.configuration import NeuralNetConfiguration
+    from deeplearning4j_amd.nn.conf.layers import OutputLayer
+    from deeplearning4j_amd.nn.conf.base import InputType
+    from deeplearning4j_amd.nn.multilayer import MultiLayerNetwork
+    conf = (NeuralNetConfiguration.Builder().seed(3).updater(Sgd(learningRateSchedule=StepSchedule("ITERATION", 0.1, 0.5, 2))).list()
+            .layer(OutputLayer(nIn=4, nOut=2, activation="SOFTMAX", lossFunction="MCXENT")).setInputType(InputType.feedForward(4)).build())
+    net = MultiLayerNetwork(conf, device="cpu").init()
+    x = torch.randn(6, 4, generator=torch.Generator().manual_seed(1))
+    y = torch.eye(2)[torch.arange(6) % 2]
+    seen = []
+    for _ in range(5):
+        p0 = net.params().clone()
+        net.fit(x, y)
+        g = net._grads.clone() / 6
+        step = (p0.view(-1) - net.params().view(-1))
+        seen.append(float(step.norm() / g.norm()))
+    assert [round(v, 6) for v in seen] == [0.1, 0.1, 0.05, 0.05, 0.025]
