@@ -160,8 +160,9 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
     for (int j = 0; j < V; ++j) {
       float s0 = 0.f, s1 = 0.f;
       for (int r = 0; r < rpi; ++r) { s0 += red[j * 256 + r * cpb + c_in]; s1 += red[(V + j) * 256 + r * cpb + c_in]; }
-      ticket::st_agent(partial + ((int64_t)blockIdx.y * 2) * C + cvec * V + j, s0);
-      ticket::st_agent(partial + ((int64_t)blockIdx.y * 2 + 1) * C + cvec * V + j, s1);
+      float* d0 = partial + ((int64_t)blockIdx.y * 2) * C + cvec * V + j;
+      float* d1 = partial + ((int64_t)blockIdx.y * 2 + 1) * C + cvec * V + j;
+      if (cnt != nullptr) { ticket::st_agent(d0, s0); ticket::st_agent(d1, s1); } else { *d0 = s0; *d1 = s1; }
     }
   }
   if (cnt == nullptr) return;
@@ -175,15 +176,12 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
   if (!ticket::arrive_last(cnt + gridDim.x + blockIdx.x * ngroups + g, (unsigned)(gend - gbeg), &s_last)) return;
   for (int idx = tid; idx < 2 * ncol; idx += 256) {
     const int q = idx / ncol, c = cbeg + idx - q * ncol;
-    float a = 0.f;
-    for (int r = gbeg; r < gend; ++r) a += ticket::ld_agent(partial + ((int64_t)r * 2 + q) * C + c);
-    ticket::st_agent(gpart + ((int64_t)g * 2 + q) * C + c, a);
+    ticket::st_agent(gpart + ((int64_t)g * 2 + q) * C + c, ticket::sum_rows(partial + ((int64_t)gbeg * 2 + q) * C + c, gend - gbeg, 2 * (int64_t)C));
   }
   if (!ticket::arrive_last(cnt + blockIdx.x, (unsigned)ngroups, &s_last)) return;
   for (int idx = tid; idx < 2 * ncol; idx += 256) {
     const int q = idx / ncol, c = cbeg + idx - q * ncol;
-    float a = 0.f;
-    for (int r = 0; r < ngroups; ++r) a += ticket::ld_agent(gpart + ((int64_t)r * 2 + q) * C + c);
+    const float a = ticket::sum_rows(gpart + (int64_t)q * C + c, ngroups, 2 * (int64_t)C);
     sums[q * C + c] = a;
     if (q == 0) { if (out0) out0[c] = a; }
     else if (out1) out1[c] = a;
@@ -389,7 +387,7 @@ __global__ void bn_infer_coeffs_kernel(const float* __restrict__ gamma, const fl
 // issuing 16-40 scalar coefficient loads per vector.
 // ---------------------------------------------------------------------------------------
 static inline int hoist_grid(int64_t nvec, int cv, bool* hoist) {
-  int g = grid_for(nvec, 256);
+  int g = launch_grid(LS_BATCHNORM, grid_for(nvec, 256));
   *hoist = false;
   if (cv <= 256) {
     if (256 % cv == 0) *hoist = true;
@@ -458,7 +456,7 @@ static int launch_apply(const void* x, const float* scale, const float* shift, c
                          (const T*)res, rscale, rshift, (T*)y, nvec, C / VFULL, relu);
   } else {
     const int64_t nvec = M * C;
-    hipLaunchKernelGGL((bn_apply_kernel<T, 1, false>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x, scale,
+    hipLaunchKernelGGL((bn_apply_kernel<T, 1, false>), dim3(launch_grid(LS_BATCHNORM, grid_for(nvec, 256))), dim3(256), 0, st, (const T*)x, scale,
                        shift, (const T*)res, rscale, rshift, (T*)y, nvec, C, relu);
   }
   DL4J_RET_LAST();
@@ -539,7 +537,7 @@ static int launch_bwd_dx(const void* x, const void* dy, const void* out, const f
                          (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM);
   } else {
     const int64_t nvec = M * C;
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1, false>), dim3(grid_for(nvec, 256)), dim3(256), 0, st, (const T*)x,
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1, false>), dim3(launch_grid(LS_BATCHNORM, grid_for(nvec, 256))), dim3(256), 0, st, (const T*)x,
                        (const T*)dy, (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C, C, invM);
   }
   DL4J_RET_LAST();

@@ -85,6 +85,11 @@ static inline int grid_for(int64_t work_items, int per_block) {
   return (int)g;
 }
 
+// launch-dimension overrides (launch_dims.hip; LaunchDims.cu of the reference): kernel families consult these before launching
+enum LaunchSite { LS_PAIRWISE = 0, LS_TRANSFORM, LS_REDUCE, LS_BATCHNORM, LS_POOLING, LS_COUNT };
+int launch_grid(int site, int computed);
+int launch_block(int site, int dflt);
+
 #define DL4J_RET_LAST() return (int)hipGetLastError()
 
 // hipFuncSetAttribute is PER DEVICE: a process that drives several GPUs from worker threads (ParallelInference replicas)

@@ -187,7 +187,21 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   __syncthreads();
   if (p.stats != nullptr && tid < 2 * BN) {
     const int qs = tid / BN, col = tid - qs * BN;
-    ticket::st_agent(p.stats + ((int64_t)mt * 2 + qs) * p.K + n0 + col, sS[(0 * 2 + qs) * BN + col] + sS[(1 * 2 + qs) * BN + col]);
+    const float v = sS[(0 * 2 + qs) * BN + col] + sS[(1 * 2 + qs) * BN + col];
+    float* dst = p.stats + ((int64_t)mt * 2 + qs) * p.K + n0 + col;
+    if (p.fin.cnt != nullptr) ticket::st_agent(dst, v); else *dst = v;      // write-through only when another block reads it
+  }
+  // in-kernel BatchNorm finalize (ticket.h): the ticket is taken BEFORE the output tile is stored, so only the 2*BN statistic
+  // stores are waited for and the atomic's round trip overlaps the tile stores
+  __shared__ int s_last;
+  const ticket::BnFin& f = p.fin;
+  const bool fin = f.cnt != nullptr;
+  const int G = fin ? f.G : 1, ngroups = (p.mtiles + G - 1) / G;
+  const int g = mt / G, gbeg = g * G, gend = (gbeg + G < p.mtiles) ? gbeg + G : p.mtiles;
+  unsigned tk = 0;
+  if (fin) {
+    ticket::publish();
+    if (tid == 0) tk = ticket::take(f.cnt + p.ntiles + nt * ngroups + g);
   }
   constexpr int CPR = BN / 8;
   for (int idx = tid; idx < BM * CPR; idx += 256) {
@@ -206,26 +220,18 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
       *reinterpret_cast<s16x8*>(p.y + o) = v;
     }
   }
-  if (p.fin.cnt == nullptr) return;
-  // ---------------- in-kernel BatchNorm finalize (ticket.h): two levels so no block reads more than ~G + mtiles/G partial rows
-  __shared__ int s_last;
-  const ticket::BnFin& f = p.fin;
-  const int G = f.G, ngroups = (p.mtiles + G - 1) / G;
-  const int g = mt / G, gbeg = g * G, gend = (gbeg + G < p.mtiles) ? gbeg + G : p.mtiles;
-  if (!ticket::arrive_last(f.cnt + p.ntiles + nt * ngroups + g, (unsigned)(gend - gbeg), &s_last)) return;
+  if (!fin) return;
+  // two levels so no block reads more than ~G + mtiles/G partial rows
+  if (!ticket::resolve(f.cnt + p.ntiles + nt * ngroups + g, tk, (unsigned)(gend - gbeg), &s_last)) return;
   if (tid < 2 * BN) {
     const int qs = tid / BN, col = tid - qs * BN;
-    float a = 0.f;
-    for (int r = gbeg; r < gend; ++r) a += ticket::ld_agent(p.stats + ((int64_t)r * 2 + qs) * p.K + n0 + col);
-    ticket::st_agent(f.gpart + ((int64_t)g * 2 + qs) * p.K + n0 + col, a);
+    ticket::st_agent(f.gpart + ((int64_t)g * 2 + qs) * p.K + n0 + col,
+                     ticket::sum_rows(p.stats + ((int64_t)gbeg * 2 + qs) * p.K + n0 + col, gend - gbeg, 2 * (int64_t)p.K));
   }
   if (!ticket::arrive_last(f.cnt + nt, (unsigned)ngroups, &s_last)) return;
   if (tid < BN) {
-    float su = 0.f, sq = 0.f;
-    for (int r = 0; r < ngroups; ++r) {
-      su += ticket::ld_agent(f.gpart + ((int64_t)r * 2 + 0) * p.K + n0 + tid);
-      sq += ticket::ld_agent(f.gpart + ((int64_t)r * 2 + 1) * p.K + n0 + tid);
-    }
+    const float su = ticket::sum_rows(f.gpart + n0 + tid, ngroups, 2 * (int64_t)p.K);
+    const float sq = ticket::sum_rows(f.gpart + p.K + n0 + tid, ngroups, 2 * (int64_t)p.K);
     ticket::bn_finalize_channel(f, n0 + tid, su, sq);
   }
 }

@@ -659,11 +659,12 @@ DL4J_API int dl4j_legacy_pairwise(int f, const void* x, const void* y, void* z, 
                                   int use_scalar, double scalar, int dtype, int zbool, hipStream_t st) {
   if (n <= 0) return 0;
   Extra ex{{extra ? extra[0] : 0, extra ? extra[1] : 0, extra ? extra[2] : 0, extra ? extra[3] : 0}};
-  int g = grid_for(n, 256 * 4);
+  const int blk = launch_block(LS_PAIRWISE, 256);
+  int g = launch_grid(LS_PAIRWISE, grid_for(n, blk * 4));
   if (zbool) {
-    DISPATCH_T(dtype, (pairwise_kernel<T, uint8_t><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (uint8_t*)z, n, f, *s, ex, use_scalar, scalar)))
+    DISPATCH_T(dtype, (pairwise_kernel<T, uint8_t><<<g, blk, 0, st>>>((const T*)x, (const T*)y, (uint8_t*)z, n, f, *s, ex, use_scalar, scalar)))
   } else {
-    DISPATCH_T(dtype, (pairwise_kernel<T, T><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (T*)z, n, f, *s, ex, use_scalar, scalar)))
+    DISPATCH_T(dtype, (pairwise_kernel<T, T><<<g, blk, 0, st>>>((const T*)x, (const T*)y, (T*)z, n, f, *s, ex, use_scalar, scalar)))
   }
   DL4J_RET_LAST();
 }
@@ -672,11 +673,12 @@ DL4J_API int dl4j_legacy_transform(int f, const void* x, void* z, int64_t n, con
                                    int zbool, hipStream_t st) {
   if (n <= 0) return 0;
   Extra ex{{extra ? extra[0] : 0, extra ? extra[1] : 0, extra ? extra[2] : 0, extra ? extra[3] : 0}};
-  int g = grid_for(n, 256 * 4);
+  const int blk = launch_block(LS_TRANSFORM, 256);
+  int g = launch_grid(LS_TRANSFORM, grid_for(n, blk * 4));
   if (zbool) {
-    DISPATCH_T(dtype, (transform_kernel<T, uint8_t><<<g, 256, 0, st>>>((const T*)x, (uint8_t*)z, n, f, *s, ex)))
+    DISPATCH_T(dtype, (transform_kernel<T, uint8_t><<<g, blk, 0, st>>>((const T*)x, (uint8_t*)z, n, f, *s, ex)))
   } else {
-    DISPATCH_T(dtype, (transform_kernel<T, T><<<g, 256, 0, st>>>((const T*)x, (T*)z, n, f, *s, ex)))
+    DISPATCH_T(dtype, (transform_kernel<T, T><<<g, blk, 0, st>>>((const T*)x, (T*)z, n, f, *s, ex)))
   }
   DL4J_RET_LAST();
 }

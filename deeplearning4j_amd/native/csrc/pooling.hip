@@ -181,11 +181,11 @@ static int pool_fwd_launch(const void* x, void* y, uint8_t* amax, const PoolP& p
   constexpr int VF = sizeof(T) == 2 ? 8 : 4;
   if (p.C % VF == 0) {
     const int64_t total = (int64_t)p.N * p.OH * p.OW * (p.C / VF);
-    hipLaunchKernelGGL((pool_fwd_kernel<T, VF, MODE>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, (T*)y,
+    hipLaunchKernelGGL((pool_fwd_kernel<T, VF, MODE>), dim3(launch_grid(LS_POOLING, grid_for(total, 256))), dim3(256), 0, st, (const T*)x, (T*)y,
                        amax, p);
   } else {
     const int64_t total = (int64_t)p.N * p.OH * p.OW * p.C;
-    hipLaunchKernelGGL((pool_fwd_kernel<T, 1, MODE>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, (T*)y,
+    hipLaunchKernelGGL((pool_fwd_kernel<T, 1, MODE>), dim3(launch_grid(LS_POOLING, grid_for(total, 256))), dim3(256), 0, st, (const T*)x, (T*)y,
                        amax, p);
   }
   DL4J_RET_LAST();
@@ -195,11 +195,11 @@ static int pool_bwd_launch(const void* dy, const uint8_t* amax, void* dx, const 
   constexpr int VF = sizeof(T) == 2 ? 8 : 4;
   if (p.C % VF == 0) {
     const int64_t total = (int64_t)p.N * p.H * p.W * (p.C / VF);
-    hipLaunchKernelGGL((pool_bwd_kernel<T, VF, MODE>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, amax,
+    hipLaunchKernelGGL((pool_bwd_kernel<T, VF, MODE>), dim3(launch_grid(LS_POOLING, grid_for(total, 256))), dim3(256), 0, st, (const T*)dy, amax,
                        (T*)dx, p);
   } else {
     const int64_t total = (int64_t)p.N * p.H * p.W * p.C;
-    hipLaunchKernelGGL((pool_bwd_kernel<T, 1, MODE>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)dy, amax,
+    hipLaunchKernelGGL((pool_bwd_kernel<T, 1, MODE>), dim3(launch_grid(LS_POOLING, grid_for(total, 256))), dim3(256), 0, st, (const T*)dy, amax,
                        (T*)dx, p);
   }
   DL4J_RET_LAST();

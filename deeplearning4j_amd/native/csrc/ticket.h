@@ -9,7 +9,10 @@
 //     workgroup barrier (so every thread's stores are complete), then ONE thread takes a ticket with an agent-scope atomic
 //     add. The block whose ticket is expected-1 knows that every other block's partials are complete and visible;
 //   * that block resets the counter, so the same counter array serves every later launch on the stream (self-cleaning,
-//     replay-safe inside captured graphs). Every block arrives exactly once: no spinning, no co-residency requirement.
+//     replay-safe inside captured graphs). Every block arrives exactly once: no spinning, no co-residency requirement;
+//   * the last block then executes ONE agent-scope acquire fence (buffer_inv sc1: drops possibly stale lines of this XCD's
+//     caches) and reads the partials with ordinary, pipelined loads. Reading them with per-element atomic loads serialised
+//     ~32 memory round trips per thread: 50 us per BatchNorm backward (measured, profiles/r2_ticket_finalize.md).
 #pragma once
 #include "common.h"
 
@@ -22,18 +25,45 @@ __device__ __forceinline__ float ld_agent(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Called by ALL threads of the block (contains barriers). s_flag: one int of LDS. True in every thread of the last block.
-__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned expected, int* s_flag) {
+// Split form, so independent work (the output-tile stores of a GEMM epilogue) can be issued while the ticket is in flight:
+//   publish():   all threads, after their partial stores — waits for them, then a workgroup barrier
+//   take():      thread 0 only — returns the ticket (the value is not needed until resolve())
+//   resolve():   all threads — true in every thread of the block that arrived last; that block has acquired the partials
+__device__ __forceinline__ void publish() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+}
+__device__ __forceinline__ unsigned take(unsigned* counter) {
+  return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool resolve(unsigned* counter, unsigned ticket, unsigned expected, int* s_flag) {
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = (t + 1u == expected);
+    const bool last = (ticket + 1u == expected);
     if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_flag = last ? 1 : 0;
   }
   __syncthreads();
-  return *s_flag != 0;
+  const bool last = *s_flag != 0;
+  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return last;
+}
+// Called by ALL threads of the block (contains barriers). s_flag: one int of LDS. True in every thread of the last block.
+__device__ __forceinline__ bool arrive_last(unsigned* counter, unsigned expected, int* s_flag) {
+  publish();
+  unsigned t = 0;
+  if (threadIdx.x == 0) t = take(counter);
+  return resolve(counter, t, expected, s_flag);
+}
+// sum of `rows` floats at p[0], p[stride], ... with four independent accumulators (ordinary loads: call after resolve())
+__device__ __forceinline__ float sum_rows(const float* p, int rows, int64_t stride) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = 0;
+  for (; r + 3 < rows; r += 4) {
+    a0 += p[(int64_t)r * stride]; a1 += p[(int64_t)(r + 1) * stride];
+    a2 += p[(int64_t)(r + 2) * stride]; a3 += p[(int64_t)(r + 3) * stride];
+  }
+  for (; r < rows; ++r) a0 += p[(int64_t)r * stride];
+  return (a0 + a1) + (a2 + a3);
 }
 
 // BatchNorm finalize of one channel from its (sum, sum of squares): shared by the in-kernel and the stand-alone finalize.

@@ -116,7 +116,23 @@ class Environment:
         return tuple(out)
 
     def setLaunchDims(self, name, grid, block, smem=0):
+        """Registry entry + the override the HIP kernel families read before launching (native/csrc/launch_dims.hip): the
+        pairwise / transform / reduce legacy kernels, BatchNorm and pooling cap their grid (and, where the kernel is written for a
+        variable block, their block size) to these values."""
         self._rt.launch_dims_set(name.encode(), grid, block, smem)
+        from ..native import lib as _L
+        if _L.gpu_available():
+            _L.hip().dl4j_launch_dims_set(name.encode(), int(grid), int(block), int(smem))
+
+    def kernelLaunchDims(self, name):
+        """(grid override, block override, workgroups of the family's most recent launch) as seen by the kernels, or None when the
+        name is not one of this library's kernel families."""
+        import ctypes
+        from ..native import lib as _L
+        out = (ctypes.c_int * 3)()
+        if not _L.gpu_available() or _L.hip().dl4j_launch_dims_get(name.encode(), out) != 0:
+            return None
+        return tuple(out)
 
     def launchDimNames(self):
         return [self._rt.launch_dims_name(i).decode() for i in range(self._rt.launch_dims_count())]

@@ -40,8 +40,12 @@ def _workspace(C, device):
     return ws
 
 
-# DL4J_AMD_BN_TICKET=0 restores the two-launch reductions (bn_sum_partials / bn_finalize_partials kernels)
-_FUSE_STAGE2 = __import__("os").environ.get("DL4J_AMD_BN_TICKET", "1") != "0"
+# In-kernel second reduction stage ("last block done", native/csrc/ticket.h). OFF by default: measured on MI355X
+# (profiles/r2_ticket_finalize.md) every device-scope hand-off between workgroups on different XCDs is a ~2-3 us memory round trip,
+# and the two-level scheme chains ~7 of them (store ack, ticket, read, store ack, ticket, read, write): +20 us per BatchNorm backward
+# and +11 us per conv epilogue, against ~5 us for the dependent launch it replaces (step 11.73 ms vs 10.57 ms). DL4J_AMD_BN_TICKET=1
+# enables it (useful where launches are expensive, e.g. eager mode without graph capture); tests cover both forms.
+_FUSE_STAGE2 = __import__("os").environ.get("DL4J_AMD_BN_TICKET", "0") == "1"
 _TICKET = {}
 TICKET_COUNTERS = 65536
 TICKET_GPART = 1 << 20

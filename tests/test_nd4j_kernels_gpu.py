@@ -244,3 +244,33 @@ def test_custom_op_platform_helpers_run_hip_paths():
     bn = exec_op("batchnorm", [xf, mean, var, gamma, beta], iArgs=[1, 1, 1], tArgs=[1e-5])[0]
     ref = (xf - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
     assert torch.allclose(bn, ref, atol=1e-4)
+
+
+def test_launch_dims_overrides_are_honoured_by_the_kernels():
+    """Environment.setLaunchDims reaches the kernels (LaunchDims.cu analogue): the legacy transform family and BatchNorm launch with
+    the capped grid and still produce the right values (grid-stride kernels)."""
+    from deeplearning4j_amd.nd4j.environment import Environment
+    from deeplearning4j_amd.nd4j.ops import legacy as LG
+    from deeplearning4j_amd.ops import batchnorm as BN
+    env = Environment.getInstance()
+    x = torch.randn(1 << 20, device="cuda")
+    lg = LG.executioner()
+    opn = next(k for k, v in LG.TRANSFORM_STRICT.items() if v == "Tanh")
+    ref = torch.tanh(x)
+    try:
+        y0 = lg.execTransformStrict(opn, x, None, None)
+        free = env.kernelLaunchDims("transformScan")
+        assert free is not None and free[2] > 64
+        env.setLaunchDims("transformScan", 7, 128)
+        y1 = lg.execTransformStrict(opn, x, None, None)
+        assert env.kernelLaunchDims("transformScan") == (7, 128, 7)
+        assert torch.allclose(y0, ref, atol=1e-6) and torch.allclose(y1, ref, atol=1e-6)
+        env.setLaunchDims("batch_norm", 3, 256)
+        a = torch.randn(4096, 64, device="cuda")
+        sc, sh = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda")
+        out = BN.apply(a, sc, sh, relu=True)
+        assert env.kernelLaunchDims("batch_norm")[2] == 3
+        assert torch.allclose(out, torch.relu(a * sc + sh), atol=1e-5)
+    finally:
+        env.setLaunchDims("transformScan", 0, 0)
+        env.setLaunchDims("batch_norm", 0, 0)
