@@ -677,3 +677,50 @@ def _gru_platform(ins, i, t, b, d):
     generic path: its candidate is ((r * hI) x Wch), a second GEMM between the two halves of the gate math."""
     from ...ops import lstm as R
     return R.gru_sequence(ins[0], ins[1], ins[2], ins[3], ins[4] if len(ins) > 4 else None)
+
+
+# ----------------------------------------------------------------------------- GEMM-shaped ops on the in-tree MFMA kernels
+def _xwb_ok(ins, i, t, b, d):
+    from ...ops import linear as LIN
+    if len(ins) < 2 or (i and any(int(v) for v in i)):          # transposed-operand variants stay generic
+        return False
+    return ins[0].dim() == 2 and LIN.usable(ins[0], ins[1]) and (len(ins) < 3 or ins[2] is None or ins[2].numel() == ins[1].shape[1])
+
+
+@platform("xw_plus_b", _xwb_ok, differentiable=True)
+def _xw_plus_b_hip(ins, i, t, b, d):
+    from ...ops import linear as LIN
+    return LIN.linear(ins[0], ins[1], ins[2] if len(ins) > 2 else None)
+
+
+def _mm_ok(ins, i, t, b, d):
+    """matmul(x [.., M, K], w [K, N]) with a plain 2-D right operand, no transposes / alpha / beta: the dense-layer shape."""
+    from ...ops import linear as LIN
+    if len(ins) != 2 or (i and any(int(v) for v in list(i)[:3])) or (t and (float(t[0]) != 1.0 or (len(t) > 1 and float(t[1]) != 0.0))):
+        return False
+    return ins[1].dim() == 2 and LIN.usable(ins[0], ins[1])
+
+
+@platform("matmul", _mm_ok, differentiable=True)
+def _matmul_hip(ins, i, t, b, d):
+    from ...ops import linear as LIN
+    return LIN.linear(ins[0], ins[1], None)
+
+
+def _bgemm_ok(ins, i, t, b, d):
+    """matmul of two rank-3 operands with transB (attention scores q . k^T): strided-batched NT GEMM, inference only."""
+    from ...ops import gemm as G
+    if len(ins) != 2 or not i or len(i) < 2 or int(i[0]) or not int(i[1]) or (len(i) > 2 and int(i[2])):
+        return False
+    a, bb = ins
+    if not (_fx(a) and _fx(bb) and a.dim() == 3 and bb.dim() == 3 and a.dtype == bb.dtype and a.shape[0] == bb.shape[0]):
+        return False
+    ch = G.chunk(a.dtype)
+    return a.shape[2] == bb.shape[2] and a.shape[2] % ch == 0 and a.is_contiguous() and bb.is_contiguous() and \
+        (not t or (float(t[0]) != 0.0 and (len(t) < 2 or float(t[1]) == 0.0)))
+
+
+@platform("matmul", _bgemm_ok)
+def _matmul_batched_hip(ins, i, t, b, d):
+    from ...ops import gemm as G
+    return G.bgemm_nt(ins[0], ins[1], alpha=float(t[0]) if t else 1.0)

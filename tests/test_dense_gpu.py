@@ -65,3 +65,40 @@ def test_dense_odd_sizes_fall_back_and_match():
     a.computeGradientAndScore(x, y)
     b.computeGradientAndScore(x.cuda(), y.cuda())
     assert float((a._grads - b._grads.cpu()).norm() / a._grads.norm()) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_samediff_linear_ops_run_on_own_gemm_kernels_forward_and_backward(dtype, monkeypatch):
+    """xw_plus_b / matmul custom ops (the ops an imported BERT is made of): platform route on the in-tree kernels, differentiable,
+    against fp32 PyTorch math; torch.matmul / addmm are poisoned inside the route."""
+    from deeplearning4j_amd.nd4j.ops.custom import exec_op, OpExecutioner
+    import deeplearning4j_amd.ops.linear as LIN
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(4, 50, 96, device="cuda", generator=g).to(dtype).reshape(200, 96)
+    w = (torch.randn(96, 136, device="cuda", generator=g) / 10).to(dtype)
+    bias = torch.randn(136, device="cuda", generator=g).to(dtype)
+    ref_in = [v.float().detach().clone().requires_grad_(True) for v in (x, w, bias)]
+    ref = ref_in[0] @ ref_in[1] + ref_in[2]
+    gy = torch.randn_like(ref)
+    rg = torch.autograd.grad(ref, ref_in, gy)
+    OpExecutioner.resetHelperStatistics()
+    ins = [v.detach().clone().requires_grad_(True) for v in (x, w, bias)]
+    real_mm = torch.matmul
+    monkeypatch.setattr(LIN.torch, "matmul", lambda *a, **k: (_ for _ in ()).throw(AssertionError("library GEMM in the linear route")))
+    out = exec_op("xw_plus_b", ins)[0]
+    got = torch.autograd.grad(out, ins, gy.to(dtype))
+    monkeypatch.setattr(LIN.torch, "matmul", real_mm)
+    assert OpExecutioner.helperStatistics()["hit"].get("xw_plus_b") == 1
+    tol = 2e-4 if dtype == torch.float32 else 5e-2
+    assert (out.float() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    for a_, r_ in zip(got, rg):
+        assert (a_.float() - r_).abs().max().item() < tol * max(1.0, r_.abs().max().item())
+    # matmul with a 3-D left operand and the batched NT form
+    x3 = x.reshape(4, 50, 96)
+    o3 = exec_op("matmul", [x3, w], iArgs=[0, 0, 0])[0]
+    assert o3.shape == (4, 50, 136) and (o3.float() - x3.float() @ w.float()).abs().max().item() < tol * 10
+    q = torch.randn(6, 40, 64, device="cuda", generator=g).to(dtype)
+    k = torch.randn(6, 24, 64, device="cuda", generator=g).to(dtype)
+    s = exec_op("matmul", [q, k], iArgs=[0, 1, 0], tArgs=[0.125, 0.0])[0]
+    assert (s.float() - 0.125 * q.float() @ k.float().transpose(1, 2)).abs().max().item() < tol * 10
+    assert OpExecutioner.helperStatistics()["hit"].get("matmul") == 2
