@@ -23,7 +23,7 @@ from .samediff import OpType, SameDiff, SameDiffOp, VariableType, _CONTROL
 class GraphOptimizer:
     @staticmethod
     def defaultOptimizations():
-        return [ConstantFolding(), ShapeFolding(), IdentityRemoval(), Fusion(), UnusedRemoval()]
+        return [ConstantFolding(), ShapeFolding(), IdentityRemoval(), Fusion(), LinearFusion(), UnusedRemoval()]
 
     @staticmethod
     def optimize(sd: SameDiff, outputs: Optional[Sequence[str]] = None, optimizations=None, maxPasses=10) -> SameDiff:
@@ -349,6 +349,87 @@ class Fusion(Optimization):
         _remove_op(sd, mm2)
         sd._add_op(new)
         return True
+
+
+class LinearFusion(Optimization):
+    """MI355X: dense sub-graphs -> one ``fused_dense`` op (ops/linear.py: GEMM with bias / activation / residual epilogues forward,
+    activation-derivative + bias-gradient pass, dx GEMM and split-K dW backward):
+
+      matmul(x, W) -> add / biasadd(., b)          => xw_plus_b(x, W, b)
+      act(xw_plus_b(x, W, b))                      => fused_dense(x, W, b; act)         act in gelu / precise gelu / erf gelu / tanh / ...
+      add(r, fused_dense | xw_plus_b)              => fused_dense(x, W, b, r; act)      residual connection (same shape, no broadcast)
+
+    The inner op must have no other consumer. Reference counterpart: optimizations/CuDNNFunctionOptimizations (backend-specific rewrites)."""
+    ACTS = {"gelu": 6, "precisegelu": 2, "gelu_erf_fused": 3, "tanh": 4, "sigmoid": 5, "relu": 1, "swish": 7}
+
+    def apply(self, sd, outputs):
+        changed = False
+        for fn in (self._matmul_bias, self._act, self._residual):
+            for o in list(sd.ops.values()):
+                if o.name in sd.ops:
+                    changed = fn(sd, o, outputs) or changed
+        return changed
+
+    @staticmethod
+    def _dense_parts(o):
+        """(x, W, bias, residual, act id) of an xw_plus_b / fused_dense op, or None."""
+        if _is(o, "xw_plus_b") and not (o.iArgs and any(int(v) for v in o.iArgs)) and len(o.inputs) == 3:
+            return o.inputs[0], o.inputs[1], o.inputs[2], None, 0
+        if _is(o, "fused_dense"):
+            ia = [int(v) for v in (o.iArgs or [])] + [0, 0, 0]
+            hb, hr = ia[1], ia[2]
+            return o.inputs[0], o.inputs[1], (o.inputs[2] if hb else None), (o.inputs[2 + hb] if hr else None), ia[0]
+        return None
+
+    @staticmethod
+    def _emit(sd, old, x, w, b, r, act):
+        ins = [x, w] + ([b] if b is not None else []) + ([r] if r is not None else [])
+        new = SameDiffOp(old.name, "fused_dense", ins, old.outputs, iArgs=[int(act), int(b is not None), int(r is not None)])
+        _remove_op(sd, old)
+        sd._add_op(new)
+        return True
+
+    def _matmul_bias(self, sd, o, outputs):
+        if not _is(o, "add", "biasadd") or len(o.inputs) != 2:
+            return False
+        for a, b in (o.inputs, o.inputs[::-1]):
+            mm = _producer(sd, a)
+            if not (_is(mm, "matmul") and len(mm.inputs) == 2 and not (mm.iArgs and any(int(v) for v in list(mm.iArgs)[:3]))
+                    and not (mm.tArgs and (float(mm.tArgs[0]) != 1.0 or (len(mm.tArgs) > 1 and float(mm.tArgs[1]) != 0.0)))
+                    and _single_use(sd, a, outputs)):
+                continue
+            ws, bs = sd.inferShape(mm.inputs[1]), sd.inferShape(b)
+            if ws is None or bs is None or len(ws) != 2 or len(bs) != 1 or bs[0] != ws[1] or ws[1] < 0:
+                continue
+            new = SameDiffOp(o.name, "xw_plus_b", [mm.inputs[0], mm.inputs[1], b], o.outputs)
+            _remove_op(sd, o)
+            sd._add_op(new)
+            return True
+        return False
+
+    def _act(self, sd, o, outputs):
+        act = self.ACTS.get(o.opName.lower())
+        if act is None or len(o.inputs) != 1 or (act == 1 and o.tArgs and float(o.tArgs[0]) != 0.0):
+            return False
+        p = _producer(sd, o.inputs[0])
+        parts = self._dense_parts(p) if p is not None else None
+        if parts is None or parts[3] is not None or parts[4] != 0 or not _single_use(sd, o.inputs[0], outputs):
+            return False
+        return self._emit(sd, o, parts[0], parts[1], parts[2], None, act)
+
+    def _residual(self, sd, o, outputs):
+        if not _is(o, "add") or len(o.inputs) != 2 or o.inputs[0] == o.inputs[1]:
+            return False
+        for a, r in (o.inputs, o.inputs[::-1]):
+            p = _producer(sd, a)
+            parts = self._dense_parts(p) if p is not None else None
+            if parts is None or parts[3] is not None or not _single_use(sd, a, outputs):
+                continue
+            sa, sr = sd.inferShape(a), sd.inferShape(r)
+            if sa is None or sr is None or list(sa) != list(sr):
+                continue
+            return self._emit(sd, o, parts[0], parts[1], parts[2], r, parts[4])
+        return False
 
 
 def _ensure_gelu_udf():

@@ -883,6 +883,62 @@ class SameDiff:
         self._shadow_cache = (key, ok)
         return ok
 
+    def _mixed_precision_state(self, fu):
+        """Persistent compute-precision image of the flat fp32 variable vector for mixed-precision graphs (fp32 master variables
+        whose only consumers are casts to BFLOAT16): [bf16 copy of the whole vector | transposed replicas of the 2-D weights that
+        feed xw_plus_b / fused_dense / matmul], refreshed by two launches per step, plus the ops/linear.py Links (leaf data pointer ->
+        fp32 master view, fp32 gradient view, transposed replica) through which the kernels skip the per-variable glue."""
+        shadowable = self._bf16_shadowable()
+        if not shadowable:
+            return None
+        mp = fu.get("mp")
+        if mp is not None and mp["key"] == (len(self.ops), len(self.variables)):
+            return mp
+        from ..ops import linear as LIN
+        flat = fu["flat"]
+        if fu.get("flat_g") is None:
+            fu["flat_g"] = torch.zeros_like(flat)
+            o_ = 0
+            fu["g_views"] = []
+            for sz in fu["sizes"]:
+                fu["g_views"].append(fu["flat_g"][o_:o_ + sz])
+                o_ += sz
+        offs, off = {}, 0
+        for n_, sz in zip(fu["names"], fu["sizes"]):
+            offs[n_] = (off, sz)
+            off += sz
+        total = off
+        # which shadowable 2-D variables are the weight operand of a linear-type op (through their cast)?
+        as_weight = set()
+        for o in self.ops.values():
+            if o.opName in ("xw_plus_b", "fused_dense", "matmul") and len(o.inputs) >= 2:
+                p = self._producer.get(o.inputs[1])
+                src = self.ops[p].inputs[0] if (p is not None and self.ops[p].opName == "cast") else o.inputs[1]
+                if src in shadowable:
+                    as_weight.add(src)
+        t_entries, t_off, cur = [], {}, (total + 7) // 8 * 8
+        for n_ in fu["names"]:
+            a = self._arrays[n_]
+            if n_ in as_weight and n_ in offs and a.dim() == 2 and a.shape[0] % 8 == 0 and a.shape[1] % 8 == 0:
+                t_entries.append((offs[n_][0], cur, int(a.shape[0]), int(a.shape[1])))
+                t_off[n_] = cur
+                cur += (a.numel() + 7) // 8 * 8
+        shadow = torch.empty(max(cur, 8), dtype=torch.bfloat16, device=flat.device)
+        views, gviews, links, by_name = {}, {}, {}, {}
+        for k, n_ in enumerate(fu["names"]):
+            if n_ not in shadowable:
+                continue
+            o0, sz = offs[n_]
+            a = self._arrays[n_]
+            v = shadow[o0:o0 + sz]
+            views[n_] = v
+            gviews[n_] = fu["g_views"][k]
+            wt = shadow[t_off[n_]:t_off[n_] + sz].view(a.shape[1], a.shape[0]) if n_ in t_off else None
+            links[v.data_ptr()] = by_name[n_] = LIN.Link(flat[o0:o0 + sz], fu["g_views"][k], wt, sz, torch.bfloat16)
+        mp = fu["mp"] = {"key": (len(self.ops), len(self.variables)), "shadow": shadow, "total": total, "offs": offs, "views": views,
+                         "gviews": gviews, "links": links, "link_by_name": by_name, "ttable": LIN.TransposeTable(t_entries, flat.device)}
+        return mp
+
     def _loss_and_grads(self, placeholders, wrt: Sequence[str], extra_outputs=(), listeners=(), at=None, device_losses=False,
                         shadow_ok=False):
         if not self.lossVariables:
@@ -897,14 +953,15 @@ class SameDiff:
         saved = {}
         leaves = []
         fu = getattr(self, "_fused", None) if shadow_ok else None
-        shadow, offs, shadowable = None, {}, ()
-        if fu is not None:
-            shadowable = self._bf16_shadowable()
-            if shadowable:
-                off = 0
-                for n_, sz in zip(fu["names"], fu["sizes"]):
-                    offs[n_] = (off, sz)
-                    off += sz
+        mp = self._mixed_precision_state(fu) if (fu is not None and self.device.type == "cuda") else None
+        if mp is not None:
+            # ONE cast launch + ONE transpose-cast launch refresh every compute-precision replica; gradients of linked variables are
+            # accumulated by the kernels straight into the (zeroed) flat gradient vector
+            mp["shadow"][:mp["total"]].copy_(fu["flat"])
+            mp["ttable"].run(fu["flat"], mp["shadow"])
+            fu["flat_g"].zero_()
+            from ..ops import linear as LIN
+            LIN.set_links(mp["links"])
         for n in wrt:
             if n in ph:
                 t = ph[n].detach().clone().requires_grad_(True)
@@ -912,10 +969,9 @@ class SameDiff:
             else:
                 saved[n] = self._arrays[n]
                 a = self._arrays[n]
-                if n in shadowable and n in offs and a.data_ptr() == fu["flat"].data_ptr() + 4 * offs[n][0] and a.numel() == offs[n][1]:
-                    if shadow is None:
-                        shadow = fu["flat"].to(torch.bfloat16)
-                    t = shadow[offs[n][0]:offs[n][0] + offs[n][1]].view(a.shape).detach().requires_grad_(True)
+                if mp is not None and n in mp["views"] and a.data_ptr() == fu["flat"].data_ptr() + 4 * mp["offs"][n][0] \
+                        and a.numel() == mp["offs"][n][1]:
+                    t = mp["views"][n].view(a.shape).detach().requires_grad_(True)
                 else:
                     t = a.detach().requires_grad_(True)
                 self._arrays[n] = t
@@ -929,6 +985,18 @@ class SameDiff:
         finally:
             for n, a in saved.items():
                 self._arrays[n] = a
+            if mp is not None:
+                LIN.set_links(None)
+        if mp is not None:
+            # linked variables: the kernels already accumulated into the flat gradient views; add what autograd returned on top
+            grads = list(grads)
+            for k, (n, g) in enumerate(zip(wrt, grads)):
+                lk = mp["link_by_name"].get(n)
+                if lk is None or (lk.hits == 0 and g is not None):
+                    continue                      # untouched by the kernels: the multi-tensor copy of _fused_update takes g
+                if g is not None:
+                    lk.grad.add_(g.reshape(-1))
+                grads[k] = lk.grad.view(leaves[k].shape)
         gd = {n: (g if g is not None else torch.zeros_like(t)) for n, g, t in zip(wrt, grads, leaves)}
         if device_losses:          # no host synchronisation (HIP-graph capture of the training step)
             return [l.detach().sum() for l in losses], gd, {n: res[n].detach() for n in extra_outputs}
@@ -1151,7 +1219,10 @@ class SameDiff:
                 fu["g_views"] = [fu["flat_g"][o_:o_ + sz] for o_, sz in zip(offs, sizes)]
             flat_g = fu["flat_g"]
             # multi-tensor copy (with the bf16 -> fp32 conversion of shadow-leaf gradients) instead of one cast + cat per variable
-            torch._foreach_copy_(fu["g_views"], [grads[n].detach().reshape(-1) for n in names])
+            pairs = [(v, grads[n].detach().reshape(-1)) for v, n in zip(fu["g_views"], names)]
+            pairs = [(v, g) for v, g in pairs if g.data_ptr() != v.data_ptr()]
+            if pairs:
+                torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
             if not tc.minimize:
                 flat_g.neg_()
             if not in_capture:             # a captured step relies on the kernel's own device-side iteration increment

@@ -34,7 +34,15 @@ struct AttnP {
   int nbh, nqb;         // number of (batch, head) pairs / of 128-query blocks
   float scale_log2e;    // softmax scale * log2(e)
   int causal;           // 1: key j masked for query i when j > i
+  int bthd;             // layout of q / k / v / o: 0 = [B][H][T][HD], 1 = [B][T][H][HD] (a linear op's [B*T, H*HD] output seen per head)
 };
+
+// first element of (batch, head) bh and the row (token) stride for either layout
+__device__ __forceinline__ int64_t head_base(int bthd, int bh, int H, int T, int HD) {
+  const int b = bh / H, h = bh - b * H;
+  return bthd ? ((int64_t)b * T * H + h) * HD : (int64_t)bh * T * HD;
+}
+__device__ __forceinline__ int64_t row_stride(int bthd, int H, int HD) { return bthd ? (int64_t)H * HD : (int64_t)HD; }
 
 template <int PITCH>
 __device__ __forceinline__ int tr_swz(int row) {
@@ -87,16 +95,17 @@ __global__ void __launch_bounds__(256) sdpa_fwd_kernel(const AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int qi = q0 + wid * 32 + l31;                    // this lane's query (two lanes per query: lh = 0 / 1)
-  const bf16_t* Q = p.q + (int64_t)bh * p.Tq * HD;
-  const bf16_t* K = p.k + (int64_t)bh * p.Tk * HD;
-  const bf16_t* V = p.v + (int64_t)bh * p.Tk * HD;
+  const bf16_t* Q = p.q + head_base(p.bthd, bh, p.H, p.Tq, HD);
+  const int64_t RS = row_stride(p.bthd, p.H, HD);
+  const bf16_t* K = p.k + head_base(p.bthd, bh, p.H, p.Tk, HD);
+  const bf16_t* V = p.v + head_base(p.bthd, bh, p.H, p.Tk, HD);
 
   // Q^T B-operand fragments: column = query, k slots = d
   bf16x8_t qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     s16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (qi < p.Tq) t = *reinterpret_cast<const s16x8*>(Q + (int64_t)qi * HD + ks * 16 + lh * 8);
+    if (qi < p.Tq) t = *reinterpret_cast<const s16x8*>(Q + (int64_t)qi * RS + ks * 16 + lh * 8);
     qf[ks] = __builtin_bit_cast(bf16x8_t, t);
   }
 
@@ -126,8 +135,8 @@ __global__ void __launch_bounds__(256) sdpa_fwd_kernel(const AttnP p) {
       const int key = key0 + row;
       s16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
       if (key < p.Tk) {
-        kv = *reinterpret_cast<const s16x8*>(K + (int64_t)key * HD + chunk * 8);
-        vv = *reinterpret_cast<const s16x8*>(V + (int64_t)key * HD + chunk * 8);
+        kv = *reinterpret_cast<const s16x8*>(K + (int64_t)key * RS + chunk * 8);
+        vv = *reinterpret_cast<const s16x8*>(V + (int64_t)key * RS + chunk * 8);
       }
       *reinterpret_cast<s16x8*>(sK + row * PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
       *reinterpret_cast<s16x8*>(sV + row * PITCH + ((chunk ^ tr_swz<PITCH>(row)) << 4)) = vv;
@@ -207,7 +216,7 @@ __global__ void __launch_bounds__(256) sdpa_fwd_kernel(const AttnP p) {
 
   if (qi >= p.Tq) return;
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-  bf16_t* O = p.o + ((int64_t)bh * p.Tq + qi) * HD;
+  bf16_t* O = p.o + head_base(p.bthd, bh, p.H, p.Tq, HD) + (int64_t)qi * RS;
 #pragma unroll
   for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -247,20 +256,23 @@ struct AttnBwdP {
   int nbh, nblk;
   float scale, scale_log2e;
   int causal;
+  int bthd;             // same layout flag as AttnP, shared by q / k / v / dout / dq / dk / dv
 };
 
 // delta[row] = sum_d dO[row, d] * O[row, d]; HD/8 lanes per row, 16 bytes per lane
 template <int HD>
 __global__ void __launch_bounds__(256) sdpa_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int64_t rows) {
+                                                         float* __restrict__ delta, int64_t rows, int H, int Tq, int bthd) {
   constexpr int LPR = HD / 8;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = t / LPR;
   const int c = (int)(t - row * LPR);
   float s = 0.f;
   if (row < rows) {
-    const s16x8 a = *reinterpret_cast<const s16x8*>(o + row * HD + c * 8);
-    const s16x8 b = *reinterpret_cast<const s16x8*>(dout + row * HD + c * 8);
+    const int bh = (int)(row / Tq);
+    const int64_t off = head_base(bthd, bh, H, Tq, HD) + (row - (int64_t)bh * Tq) * row_stride(bthd, H, HD);
+    const s16x8 a = *reinterpret_cast<const s16x8*>(o + off + c * 8);
+    const s16x8 b = *reinterpret_cast<const s16x8*>(dout + off + c * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += bf2f((bf16_t)a[j]) * bf2f((bf16_t)b[j]);
   }
@@ -296,18 +308,19 @@ __global__ void __launch_bounds__(256) sdpa_bwd_dq_kernel(const AttnBwdP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int qi = q0 + wid * 32 + l31;
-  const bf16_t* Q = p.q + (int64_t)bh * p.Tq * HD;
-  const bf16_t* DO = p.dout + (int64_t)bh * p.Tq * HD;
-  const bf16_t* K = p.k + (int64_t)bh * p.Tk * HD;
-  const bf16_t* V = p.v + (int64_t)bh * p.Tk * HD;
+  const bf16_t* Q = p.q + head_base(p.bthd, bh, p.H, p.Tq, HD);
+  const int64_t RS = row_stride(p.bthd, p.H, HD);
+  const bf16_t* DO = p.dout + head_base(p.bthd, bh, p.H, p.Tq, HD);
+  const bf16_t* K = p.k + head_base(p.bthd, bh, p.H, p.Tk, HD);
+  const bf16_t* V = p.v + head_base(p.bthd, bh, p.H, p.Tk, HD);
 
   bf16x8_t qf[KS], dof[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     s16x8 t = {0, 0, 0, 0, 0, 0, 0, 0}, u = {0, 0, 0, 0, 0, 0, 0, 0};
     if (qi < p.Tq) {
-      t = *reinterpret_cast<const s16x8*>(Q + (int64_t)qi * HD + ks * 16 + lh * 8);
-      u = *reinterpret_cast<const s16x8*>(DO + (int64_t)qi * HD + ks * 16 + lh * 8);
+      t = *reinterpret_cast<const s16x8*>(Q + (int64_t)qi * RS + ks * 16 + lh * 8);
+      u = *reinterpret_cast<const s16x8*>(DO + (int64_t)qi * RS + ks * 16 + lh * 8);
     }
     qf[ks] = __builtin_bit_cast(bf16x8_t, t);
     dof[ks] = __builtin_bit_cast(bf16x8_t, u);
@@ -338,8 +351,8 @@ __global__ void __launch_bounds__(256) sdpa_bwd_dq_kernel(const AttnBwdP p) {
       const int key = key0 + row;
       s16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
       if (key < p.Tk) {
-        kv = *reinterpret_cast<const s16x8*>(K + (int64_t)key * HD + chunk * 8);
-        vv = *reinterpret_cast<const s16x8*>(V + (int64_t)key * HD + chunk * 8);
+        kv = *reinterpret_cast<const s16x8*>(K + (int64_t)key * RS + chunk * 8);
+        vv = *reinterpret_cast<const s16x8*>(V + (int64_t)key * RS + chunk * 8);
       }
       *reinterpret_cast<s16x8*>(sK + row * PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
       *reinterpret_cast<s16x8*>(sKt + row * PITCH + ((chunk ^ tr_swz<PITCH>(row)) << 4)) = kv;
@@ -394,7 +407,7 @@ __global__ void __launch_bounds__(256) sdpa_bwd_dq_kernel(const AttnBwdP p) {
   }
 
   if (qi >= p.Tq) return;
-  bf16_t* DQ = p.dq + ((int64_t)bh * p.Tq + qi) * HD;
+  bf16_t* DQ = p.dq + head_base(p.bthd, bh, p.H, p.Tq, HD) + (int64_t)qi * RS;
 #pragma unroll
   for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -433,18 +446,19 @@ __global__ void __launch_bounds__(256) sdpa_bwd_dkv_kernel(const AttnBwdP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int kj = k0 + wid * 32 + l31;                      // this lane's key
-  const bf16_t* Q = p.q + (int64_t)bh * p.Tq * HD;
-  const bf16_t* DO = p.dout + (int64_t)bh * p.Tq * HD;
-  const bf16_t* K = p.k + (int64_t)bh * p.Tk * HD;
-  const bf16_t* V = p.v + (int64_t)bh * p.Tk * HD;
+  const bf16_t* Q = p.q + head_base(p.bthd, bh, p.H, p.Tq, HD);
+  const int64_t RS = row_stride(p.bthd, p.H, HD);
+  const bf16_t* DO = p.dout + head_base(p.bthd, bh, p.H, p.Tq, HD);
+  const bf16_t* K = p.k + head_base(p.bthd, bh, p.H, p.Tk, HD);
+  const bf16_t* V = p.v + head_base(p.bthd, bh, p.H, p.Tk, HD);
 
   bf16x8_t kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     s16x8 t = {0, 0, 0, 0, 0, 0, 0, 0}, u = {0, 0, 0, 0, 0, 0, 0, 0};
     if (kj < p.Tk) {
-      t = *reinterpret_cast<const s16x8*>(K + (int64_t)kj * HD + ks * 16 + lh * 8);
-      u = *reinterpret_cast<const s16x8*>(V + (int64_t)kj * HD + ks * 16 + lh * 8);
+      t = *reinterpret_cast<const s16x8*>(K + (int64_t)kj * RS + ks * 16 + lh * 8);
+      u = *reinterpret_cast<const s16x8*>(V + (int64_t)kj * RS + ks * 16 + lh * 8);
     }
     kf[ks] = __builtin_bit_cast(bf16x8_t, t);
     vf[ks] = __builtin_bit_cast(bf16x8_t, u);
@@ -471,8 +485,8 @@ __global__ void __launch_bounds__(256) sdpa_bwd_dkv_kernel(const AttnBwdP p) {
       const int qr = qs + row;
       s16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, ov = {0, 0, 0, 0, 0, 0, 0, 0};
       if (qr < p.Tq) {
-        qv = *reinterpret_cast<const s16x8*>(Q + (int64_t)qr * HD + chunk * 8);
-        ov = *reinterpret_cast<const s16x8*>(DO + (int64_t)qr * HD + chunk * 8);
+        qv = *reinterpret_cast<const s16x8*>(Q + (int64_t)qr * RS + chunk * 8);
+        ov = *reinterpret_cast<const s16x8*>(DO + (int64_t)qr * RS + chunk * 8);
       }
       const int ro = row * PITCH + ((chunk ^ ((row >> 1) & 7)) << 4), to = row * PITCH + ((chunk ^ tr_swz<PITCH>(row)) << 4);
       *reinterpret_cast<s16x8*>(sQ + ro) = qv;
@@ -532,8 +546,8 @@ __global__ void __launch_bounds__(256) sdpa_bwd_dkv_kernel(const AttnBwdP p) {
   }
 
   if (kj >= p.Tk) return;
-  bf16_t* DK = p.dk + ((int64_t)bh * p.Tk + kj) * HD;
-  bf16_t* DV = p.dv + ((int64_t)bh * p.Tk + kj) * HD;
+  bf16_t* DK = p.dk + head_base(p.bthd, bh, p.H, p.Tk, HD) + (int64_t)kj * RS;
+  bf16_t* DV = p.dv + head_base(p.bthd, bh, p.H, p.Tk, HD) + (int64_t)kj * RS;
 #pragma unroll
   for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -549,13 +563,14 @@ __global__ void __launch_bounds__(256) sdpa_bwd_dkv_kernel(const AttnBwdP p) {
 }  // namespace
 
 // q,k,v,o: bf16 [B*H, T, HD] contiguous; kmask: fp32 [B, Tk] or null; lse: fp32 [B*H, Tq] or null. HD in {64, 128}.
-DL4J_API int dl4j_sdpa_fwd(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse, int B, int H, int Tq,
-                           int Tk, int HD, float scale, int causal, hipStream_t st) {
+// bthd = 1: q / k / v / o are [B][T][H][HD] (see AttnP).
+DL4J_API int dl4j_sdpa_fwd_l(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse, int B, int H, int Tq,
+                             int Tk, int HD, float scale, int causal, int bthd, hipStream_t st) {
   if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
   if (HD != 64 && HD != 128) return -2;
   AttnP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.kmask = kmask; p.o = (bf16_t*)o; p.lse = lse;
-  p.H = H; p.Tq = Tq; p.Tk = Tk; p.scale_log2e = scale * 1.4426950408889634f; p.causal = causal;
+  p.H = H; p.Tq = Tq; p.Tk = Tk; p.scale_log2e = scale * 1.4426950408889634f; p.causal = causal; p.bthd = bthd ? 1 : 0;
   p.nbh = B * H; p.nqb = (Tq + 127) / 128;
   const dim3 grid((unsigned)(((p.nbh + 7) / 8) * 8 * p.nqb));
   if (HD == 64) hipLaunchKernelGGL(sdpa_fwd_kernel<64>, grid, dim3(256), 0, st, p);
@@ -565,16 +580,16 @@ DL4J_API int dl4j_sdpa_fwd(const void* q, const void* k, const void* v, const fl
 
 // Backward of dl4j_sdpa_fwd. o / lse are the forward outputs, dout = dL/do; delta_ws: fp32 [B*H*Tq] scratch.
 // dq [B*H, Tq, HD], dk / dv [B*H, Tk, HD] are fully written.
-DL4J_API int dl4j_sdpa_bwd(const void* q, const void* k, const void* v, const float* kmask, const void* o, const float* lse,
-                           const void* dout, void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Tq, int Tk, int HD,
-                           float scale, int causal, hipStream_t st) {
+DL4J_API int dl4j_sdpa_bwd_l(const void* q, const void* k, const void* v, const float* kmask, const void* o, const float* lse,
+                             const void* dout, void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Tq, int Tk, int HD,
+                             float scale, int causal, int bthd, hipStream_t st) {
   if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
   if (HD != 64 && HD != 128) return -2;
   if (!lse || !delta_ws) return -3;
   AttnBwdP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.kmask = kmask; p.dout = (const bf16_t*)dout;
   p.lse = lse; p.delta = delta_ws; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
-  p.H = H; p.Tq = Tq; p.Tk = Tk; p.nbh = B * H; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f; p.causal = causal;
+  p.H = H; p.Tq = Tq; p.Tk = Tk; p.nbh = B * H; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f; p.causal = causal; p.bthd = bthd ? 1 : 0;
   const int64_t rows = (int64_t)B * H * Tq;
   const int64_t dthreads = rows * (HD / 8);
   const unsigned dgrid = (unsigned)((dthreads + 255) / 256);
@@ -583,13 +598,24 @@ DL4J_API int dl4j_sdpa_bwd(const void* q, const void* k, const void* v, const fl
   pq.nblk = (Tq + 127) / 128;
   pk.nblk = (Tk + 127) / 128;
   if (HD == 64) {
-    hipLaunchKernelGGL(sdpa_delta_kernel<64>, dim3(dgrid), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout, delta_ws, rows);
+    hipLaunchKernelGGL(sdpa_delta_kernel<64>, dim3(dgrid), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout, delta_ws, rows, H, Tq, bthd);
     hipLaunchKernelGGL(sdpa_bwd_dq_kernel<64>, dim3((unsigned)(bh8 * pq.nblk)), dim3(256), 0, st, pq);
     hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<64, 2>), dim3((unsigned)(bh8 * pk.nblk)), dim3(256), 0, st, pk);
   } else {
-    hipLaunchKernelGGL(sdpa_delta_kernel<128>, dim3(dgrid), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout, delta_ws, rows);
+    hipLaunchKernelGGL(sdpa_delta_kernel<128>, dim3(dgrid), dim3(256), 0, st, (const bf16_t*)o, (const bf16_t*)dout, delta_ws, rows, H, Tq, bthd);
     hipLaunchKernelGGL(sdpa_bwd_dq_kernel<128>, dim3((unsigned)(bh8 * pq.nblk)), dim3(256), 0, st, pq);
     hipLaunchKernelGGL((sdpa_bwd_dkv_kernel<128, 1>), dim3((unsigned)(bh8 * pk.nblk)), dim3(256), 0, st, pk);
   }
   DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_sdpa_fwd(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse, int B, int H, int Tq,
+                           int Tk, int HD, float scale, int causal, hipStream_t st) {
+  return dl4j_sdpa_fwd_l(q, k, v, kmask, o, lse, B, H, Tq, Tk, HD, scale, causal, 0, st);
+}
+
+DL4J_API int dl4j_sdpa_bwd(const void* q, const void* k, const void* v, const float* kmask, const void* o, const float* lse,
+                           const void* dout, void* dq, void* dk, void* dv, float* delta_ws, int B, int H, int Tq, int Tk, int HD,
+                           float scale, int causal, hipStream_t st) {
+  return dl4j_sdpa_bwd_l(q, k, v, kmask, o, lse, dout, dq, dk, dv, delta_ws, B, H, Tq, Tk, HD, scale, causal, 0, st);
 }

@@ -10,7 +10,7 @@ import torch
 
 from ...native import lib as L
 from ...ops import helpers as H
-from .custom import platform
+from .custom import op, platform
 
 _F = (torch.float32, torch.bfloat16)
 
@@ -724,3 +724,35 @@ def _bgemm_ok(ins, i, t, b, d):
 def _matmul_batched_hip(ins, i, t, b, d):
     from ...ops import gemm as G
     return G.bgemm_nt(ins[0], ins[1], alpha=float(t[0]) if t else 1.0)
+
+
+# ----------------------------------------------------------------------------- fused_dense (MI355X graph-fusion target, not a reference op)
+# inputs [x, W [K, N], (bias), (residual)]; iArgs [act id (ops/linear.ACT_IDS), has_bias, has_residual].
+def _fd_split(ins, i):
+    ia = [int(v) for v in (i or [])] + [0, 0, 0]
+    act, hb, hr = ia[0], ia[1], ia[2]
+    bias = ins[2] if hb else None
+    res = ins[2 + hb] if hr else None
+    return ins[0], ins[1], bias, res, act
+
+
+@op("fused_dense")
+def _fused_dense_generic(ins, i, t, b, d):
+    from ...ops import linear as LIN
+    x, w, bias, res, act = _fd_split(ins, i)
+    return LIN.fused_dense_reference(x, w, bias, res, act)
+
+
+def _fd_ok(ins, i, t, b, d):
+    from ...ops import linear as LIN
+    x, w, bias, res, act = _fd_split(ins, i)
+    if not LIN.usable(x, w) or (bias is not None and bias.numel() != w.shape[1]):
+        return False
+    return res is None or (res.dtype == x.dtype and res.numel() == (x.numel() // w.shape[0]) * w.shape[1])
+
+
+@platform("fused_dense", _fd_ok, differentiable=True)
+def _fused_dense_hip(ins, i, t, b, d):
+    from ...ops import linear as LIN
+    x, w, bias, res, act = _fd_split(ins, i)
+    return LIN.fused_dense(x, w, bias, res, act)

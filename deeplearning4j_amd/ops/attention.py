@@ -25,21 +25,39 @@ def _hip_ok(q, k, v, mask, dropout_p, training):
     return mask is None or (mask.dim() == 2 and mask.shape == (q.shape[0], k.shape[2]))
 
 
+def _is_bthd(t):
+    """[B, H, T, D] tensor that is a permuted view of a contiguous [B, T, H, D] buffer (the per-head view of a linear op's
+    [B*T, H*D] output): the kernels read / write this layout directly, so no permute copy is made in either direction."""
+    B, H, T, D = t.shape
+    return t.stride() == (T * H * D, D, H * D, 1) and t.data_ptr() % 16 == 0 and H > 1
+
+
+def _empty_like_layout(t, bthd):
+    B, H, T, D = t.shape
+    if bthd:
+        return torch.empty(B, T, H, D, device=t.device, dtype=t.dtype).permute(0, 2, 1, 3)
+    return torch.empty(B, H, T, D, device=t.device, dtype=t.dtype)
+
+
 class _FlashSDPA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, scale, causal):
         from ..native import lib as L
+        from . import linear as LIN
         B, H, Tq, D = q.shape
         Tk = k.shape[2]
-        qc, kc, vc = q.contiguous(), k.contiguous(), v.contiguous()
-        mk = mask.float().contiguous() if mask is not None else None
-        o = torch.empty_like(qc)
+        bthd = _is_bthd(q) and _is_bthd(k) and _is_bthd(v)
+        qc, kc, vc = (q, k, v) if bthd else (q.contiguous(), k.contiguous(), v.contiguous())
+        mk = None
+        if mask is not None:
+            mk = mask if (mask.dtype == torch.float32 and mask.is_contiguous()) else mask.float().contiguous()
+        o = _empty_like_layout(qc, bthd)
         lse = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
-        L.check(L.hip().dl4j_sdpa_fwd(L.ptr(qc), L.ptr(kc), L.ptr(vc), L.ptr(mk), L.ptr(o), L.ptr(lse), L.c_int(B), L.c_int(H),
-                                      L.c_int(Tq), L.c_int(Tk), L.c_int(D), L.c_float(scale), L.c_int(1 if causal else 0), L.stream()),
-                "sdpa_fwd")
+        L.check(L.hip().dl4j_sdpa_fwd_l(L.ptr(qc), L.ptr(kc), L.ptr(vc), L.ptr(mk), L.ptr(o), L.ptr(lse), L.c_int(B), L.c_int(H),
+                                        L.c_int(Tq), L.c_int(Tk), L.c_int(D), L.c_float(scale), L.c_int(1 if causal else 0),
+                                        L.c_int(1 if bthd else 0), L.stream()), "sdpa_fwd")
         ctx.save_for_backward(qc, kc, vc, o, lse, mk)
-        ctx.scale, ctx.causal = scale, causal
+        ctx.scale, ctx.causal, ctx.bthd = scale, causal, bthd
         return o
 
     @staticmethod
@@ -49,12 +67,19 @@ class _FlashSDPA(torch.autograd.Function):
         q, k, v, o, lse, mk = ctx.saved_tensors
         B, H, Tq, D = q.shape
         Tk = k.shape[2]
-        dof = do.to(q.dtype).contiguous()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        bthd = ctx.bthd
+        dof = do if do.dtype == q.dtype else do.to(q.dtype)
+        if bthd:
+            if not _is_bthd(dof):
+                dof = dof.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+        else:
+            dof = dof.contiguous()
+        dq, dk, dv = _empty_like_layout(q, bthd), _empty_like_layout(k, bthd), _empty_like_layout(v, bthd)
         delta = torch.empty(B, H, Tq, device=q.device, dtype=torch.float32)
-        L.check(L.hip().dl4j_sdpa_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mk), L.ptr(o), L.ptr(lse), L.ptr(dof), L.ptr(dq), L.ptr(dk),
-                                      L.ptr(dv), L.ptr(delta), L.c_int(B), L.c_int(H), L.c_int(Tq), L.c_int(Tk), L.c_int(D),
-                                      L.c_float(ctx.scale), L.c_int(1 if ctx.causal else 0), L.stream()), "sdpa_bwd")
+        L.check(L.hip().dl4j_sdpa_bwd_l(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mk), L.ptr(o), L.ptr(lse), L.ptr(dof), L.ptr(dq), L.ptr(dk),
+                                        L.ptr(dv), L.ptr(delta), L.c_int(B), L.c_int(H), L.c_int(Tq), L.c_int(Tk), L.c_int(D),
+                                        L.c_float(ctx.scale), L.c_int(1 if ctx.causal else 0), L.c_int(1 if bthd else 0), L.stream()),
+                "sdpa_bwd")
         return dq, dk, dv, None, None, None
 
 

@@ -23,7 +23,11 @@ def ok(t, dtypes=_F):
 
 
 def _f32(t):
-    return None if t is None else t.reshape(-1).float().contiguous()
+    """fp32 image of a parameter operand; a compute-precision leaf linked to its fp32 master (ops/linear.py Links) costs no launch."""
+    if t is None:
+        return None
+    from . import linear as LIN
+    return LIN.f32_operand(t)
 
 
 def _idx_ok(i):
@@ -62,8 +66,9 @@ def layer_norm(x, gamma=None, beta=None, eps=1e-5, want_stats=False):
     return (y, mean, rstd) if want_stats else y
 
 
-def layer_norm_bwd(x, g, gamma, mean, rstd, want_param_grads=True):
-    """Returns (dx, dgamma, dbeta) — dgamma/dbeta fp32 [cols] (None unless want_param_grads)."""
+def layer_norm_bwd(x, g, gamma, mean, rstd, want_param_grads=True, sums_out=None):
+    """Returns (dx, dgamma, dbeta) — dgamma/dbeta fp32 [cols] (None unless want_param_grads). ``sums_out``: fp32 [2 * cols] the
+    finishing kernel writes [dgamma | dbeta] into (adjacent views of a flat gradient vector)."""
     cols = x.shape[-1]
     rows = x.numel() // cols
     dx = torch.empty_like(x)
@@ -72,7 +77,7 @@ def layer_norm_bwd(x, g, gamma, mean, rstd, want_param_grads=True):
     gy = int(L.hip().dl4j_layer_norm_bwd_rows(L.c_int64(rows)))
     if want_param_grads:
         partial = torch.empty(gy * 2 * cols, device=x.device, dtype=torch.float32)
-        sums = torch.empty(2 * cols, device=x.device, dtype=torch.float32)
+        sums = sums_out if sums_out is not None else torch.empty(2 * cols, device=x.device, dtype=torch.float32)
     L.check(L.hip().dl4j_layer_norm_bwd(L.ptr(x), L.ptr(g), L.ptr(ga), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(partial),
                                         L.c_int64(rows), L.c_int(cols), L.c_int(L.dtype_code(x)), L.stream()), "layer_norm_bwd")
     if not want_param_grads:
@@ -418,12 +423,24 @@ class LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(xc, gamma, mean, rstd)
         ctx.has_beta = beta is not None
         ctx.bdt = None if beta is None else beta.dtype
+        from . import linear as LIN
+        ctx.links = (LIN.link_of(gamma), LIN.link_of(beta))
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, gamma, mean, rstd = ctx.saved_tensors
         need_p = ctx.needs_input_grad[1] or (ctx.has_beta and ctx.needs_input_grad[2])
+        gl, bl = ctx.links
+        cols = x.shape[-1]
+        if (need_p and gl is not None and bl is not None and gl.hits == 0 and bl.hits == 0 and ctx.needs_input_grad[1]
+                and ctx.needs_input_grad[2] and bl.grad.data_ptr() == gl.grad.data_ptr() + 4 * cols):
+            # gain and bias gradients are adjacent in the flat gradient vector: the finishing kernel writes them in place
+            gl.hits += 1
+            bl.hits += 1
+            dx, _, _ = layer_norm_bwd(x, g.to(x.dtype).contiguous(), gamma, mean, rstd, True,
+                                      sums_out=torch.as_strided(gl.grad, (2 * cols,), (1,)))
+            return dx, None, None, None
         dx, dg, db = layer_norm_bwd(x, g.to(x.dtype).contiguous(), gamma, mean, rstd, want_param_grads=need_p)
         dgamma = dg.reshape(gamma.shape).to(gamma.dtype) if (dg is not None and ctx.needs_input_grad[1]) else None
         dbeta = db.reshape(gamma.shape).to(ctx.bdt) if (db is not None and ctx.has_beta and ctx.needs_input_grad[2]) else None

@@ -21,11 +21,15 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="BFLOAT16")
+    ap.add_argument("--no-fuse", action="store_true", help="skip the graph optimizer (LinearFusion: fused_dense ops)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the training step into a HIP graph")
     args = ap.parse_args()
     sd = SameDiff.create("cuda")
     cfg = BertConfig.base()
     build_bert_classifier(sd, cfg, args.seq, 2, computeDataType=args.dtype)
+    if not args.no_fuse:
+        from deeplearning4j_amd.autodiff.optimize import GraphOptimizer
+        GraphOptimizer.optimize(sd)
     sd.setTrainingConfig(TrainingConfig.builder().updater(Adam(2e-5)).build())
     if not args.no_graph:
         sd.enableGraphCapture(True)
