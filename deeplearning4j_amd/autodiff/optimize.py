@@ -323,7 +323,8 @@ class Fusion(Optimization):
                 out.append(i)
         return out
 
-    # matmul(softmax(matmul(q, k^T) [* scale] [+ mask]), v)  ->  dot_product_attention_v2
+    # matmul(softmax(matmul(q, k^T) [* scale] [+ (1 - mask) * -big]), v)  ->  dot_product_attention_v2 (single-output form: nothing
+    # consumes the [.., Tq, Tk] matrices any more, so the GPU runs the fused flash kernels in both directions)
     def _sdpa(self, sd, mm2: SameDiffOp, outputs):
         if not _is(mm2, "matmul") or (mm2.iArgs and any(mm2.iArgs[:3])):
             return False
@@ -331,6 +332,15 @@ class Fusion(Optimization):
         if not (_is(sm, "softmax") and (not sm.iArgs or sm.iArgs[0] == -1) and _single_use(sd, mm2.inputs[0], outputs)):
             return False
         cur = _producer(sd, sm.inputs[0])
+        key_mask = None
+        if _is(cur, "add"):                       # additive padding mask
+            for a_, m_ in (cur.inputs, cur.inputs[::-1]):
+                src = self._additive_key_mask(sd, m_)
+                if src is not None:
+                    key_mask, cur = src, _producer(sd, a_)
+                    break
+            else:
+                return False
         scale = 1.0
         if _is(cur, "multiply", "divide"):
             c = _const_val(sd, cur.inputs[1])
@@ -344,11 +354,36 @@ class Fusion(Optimization):
         if ia[0] or not ia[1] or ia[2]:
             return False                          # need q · kᵀ
         q, k, v = cur.inputs[0], cur.inputs[1], mm2.inputs[1]
-        new = SameDiffOp(mm2.name, "dot_product_attention_v2", [q, v, k], mm2.outputs + [mm2.name + ":scores", mm2.name + ":logits"],
+        ins = [q, v, k] + ([key_mask] if key_mask is not None else [])
+        new = SameDiffOp(mm2.name, "dot_product_attention_v2", ins, mm2.outputs, iArgs=[0, 1 if key_mask is not None else 0],
                          tArgs=[scale, 0.0], bArgs=[False, False])
         _remove_op(sd, mm2)
         sd._add_op(new)
         return True
+
+    def _additive_key_mask(self, sd, name) -> Optional[str]:
+        """``name`` = (1 - M) * c with c <= -1000 and M a reshape / expand_dims / cast image of a [batch, Tk] array: returns that array."""
+        mul = _producer(sd, name)
+        if not _is(mul, "multiply") or len(mul.inputs) != 2:
+            return None
+        for s_, c_ in (mul.inputs, mul.inputs[::-1]):
+            c = _const_val(sd, c_)
+            sub = _producer(sd, s_)
+            if c is None or c.numel() != 1 or float(c) > -1000.0 or not _is(sub, "subtract", "rsub"):
+                continue
+            one = _const_val(sd, sub.inputs[0])
+            if one is None or one.numel() != 1 or abs(float(one) - 1.0) > 1e-6:
+                continue
+            m = sub.inputs[1]
+            for _ in range(6):
+                shp = sd.inferShape(m)
+                if shp is not None and len(shp) == 2:
+                    return m
+                pm = _producer(sd, m)
+                if not _is(pm, "reshape", "expand_dims", "cast", "identity"):
+                    break
+                m = pm.inputs[0]
+        return None
 
 
 class LinearFusion(Optimization):
@@ -430,6 +465,57 @@ class LinearFusion(Optimization):
                 continue
             return self._emit(sd, o, parts[0], parts[1], parts[2], r, parts[4])
         return False
+
+
+class MixedPrecision:
+    """fp32 graph -> bf16 compute with fp32 master variables (what models/bert.py builds by hand, as a pass for imported graphs):
+    every float VARIABLE (and float placeholder that feeds math) is consumed through a ``cast`` to the compute type, loss ops get
+    their computed inputs cast back to FLOAT. Attention masks and loss labels / weights stay fp32. Reference counterpart: the network
+    dataType(...) switch of DL4J configurations; SameDiff has no such pass, TF-imported BERT runs fp32 there."""
+
+    _LOSS = ("loss", "cross_entropy")
+    _MASK_OPS = {"dot_product_attention_v2": 3, "dot_product_attention": 3, "multi_head_dot_product_attention": 6}
+
+    @staticmethod
+    def apply(sd: SameDiff, dtype="BFLOAT16") -> SameDiff:
+        def is_loss(o):
+            n = o.opName.lower()
+            return any(k in n for k in MixedPrecision._LOSS)
+
+        def insert_cast(src, dt, consumers):
+            out = sd._op("cast", [sd.variables[src]], dArgs=[dt], name=src + "/" + dt.lower())[0]
+            cast_op = sd._producer[out.name]
+            for cn in consumers:
+                c = sd.ops[cn]
+                c.inputs = [out.name if i == src else i for i in c.inputs]
+                sd._consumers[out.name].append(cn)
+            sd._consumers[src] = [x for x in sd._consumers.get(src, []) if x not in consumers or x == cast_op]
+            return out.name
+
+        for name, v in list(sd.variables.items()):
+            if v.variableType not in (VariableType.VARIABLE, VariableType.PLACEHOLDER):
+                continue
+            dt = v.dtype if v.dtype is not None else (sd._arrays[name].dtype if name in sd._arrays else None)
+            if dt != torch.float32:
+                continue
+            cons = []
+            for cn in list(dict.fromkeys(sd._consumers.get(name, []))):
+                c = sd.ops[cn]
+                if c.opName == "cast" or is_loss(c):
+                    continue
+                mi = MixedPrecision._MASK_OPS.get(c.opName)
+                if mi is not None and name in c.inputs[mi:] and name not in c.inputs[:mi]:
+                    continue
+                cons.append(cn)
+            if cons:
+                insert_cast(name, dtype, cons)
+        for o in list(sd.ops.values()):
+            if not is_loss(o):
+                continue
+            for i in list(dict.fromkeys(o.inputs)):
+                if sd.variables[i].variableType == VariableType.ARRAY and _producer(sd, i) is not None and not _is(_producer(sd, i), "cast"):
+                    insert_cast(i, "FLOAT", [o.name])
+        return sd
 
 
 def _ensure_gelu_udf():

@@ -926,9 +926,10 @@ class SameDiff:
         shadow = torch.empty(max(cur, 8), dtype=torch.bfloat16, device=flat.device)
         views, gviews, links, by_name = {}, {}, {}, {}
         for k, n_ in enumerate(fu["names"]):
-            if n_ not in shadowable:
-                continue
             o0, sz = offs[n_]
+            if n_ not in shadowable:             # fp32 leaf = the flat view itself: linked for direct gradient accumulation only
+                links[flat.data_ptr() + 4 * o0] = by_name[n_] = LIN.Link(flat[o0:o0 + sz], fu["g_views"][k], None, sz, torch.float32)
+                continue
             a = self._arrays[n_]
             v = shadow[o0:o0 + sz]
             views[n_] = v

@@ -133,18 +133,49 @@ def _idx(t):
     return isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.int32, torch.int64) and t.is_contiguous() and t.numel() > 0
 
 
+class _EmbeddingFn(torch.autograd.Function):
+    """Row gather forward; the backward scatter-adds the rows of dy into an fp32 table: directly into the variable's view of the flat
+    gradient vector when the table is linked (ops/linear.py Links) instead of materialising, sorting and copying a dense [V, D] gradient."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        from ...ops import linear as LIN
+        ctx.save_for_backward(idx)
+        ctx.meta = (table.shape, table.dtype, LIN.link_of(table))
+        return H.gather_rows(table, idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        shape, dtype, lk = ctx.meta
+        src = dy if (dy.is_contiguous() and dy.dtype in (torch.float32, torch.bfloat16)) else dy.float().contiguous()
+        if lk is not None:
+            lk.hits += 1
+            H.scatter_add_rows_(lk.grad.view(shape), idx, src)
+            return None, None
+        g = torch.zeros(shape, device=dy.device, dtype=torch.float32)
+        H.scatter_add_rows_(g, idx, src)
+        return g.to(dtype), None
+
+
 @platform("embedding_lookup", lambda ins, i, t, b, d: L.use_hip(ins[0]) and ins[0].dim() == 2 and ins[0].is_contiguous()
-          and ins[0].element_size() in (1, 2, 4, 8) and _idx(ins[1]))
+          and ins[0].element_size() in (1, 2, 4, 8) and _idx(ins[1]) and ins[1].is_contiguous(), differentiable=True)
 def _embedding_lookup(ins, i, t, b, d):
-    return H.gather_rows(ins[0], ins[1])
+    if torch.is_grad_enabled() and ins[0].requires_grad and ins[0].dtype in (torch.float32, torch.bfloat16):
+        return _EmbeddingFn.apply(ins[0], ins[1])
+    return H.gather_rows(ins[0].detach(), ins[1])
 
 
 @platform("gather", lambda ins, i, t, b, d: len(ins) > 1 and L.use_hip(ins[0]) and ins[0].dim() >= 1 and ins[0].is_contiguous()
           and (int(i[0]) if i else 0) % ins[0].dim() == 0 and ins[0].element_size() in (1, 2, 4, 8) and _idx(ins[1])
-          and ins[0].numel() > 0)
+          and ins[0].numel() > 0, differentiable=True)
 def _gather0(ins, i, t, b, d):
     x, idx = ins[0], ins[1]
     V = x.shape[0]
+    if torch.is_grad_enabled() and x.requires_grad:
+        if x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16):
+            return _EmbeddingFn.apply(x, idx)               # row gather = embedding lookup (TF-imported GatherV2 on a table)
+        return x[idx]
     out = H.gather_rows(x.reshape(V, -1), idx)
     return out.reshape(tuple(idx.shape) + tuple(x.shape[1:]))
 

@@ -324,3 +324,48 @@ def test_optimizer_fusions_preserve_numerics():
     sd.setLossVariables(sd.getVariable("out").mean())
     g = sd.calculateGradients({"x": x}, ["gamma"])
     assert torch.isfinite(_t(g["gamma"])).all() and _t(g["gamma"]).abs().sum() > 0
+
+
+def test_bert_tf_graphdef_round_trip_is_refused_into_the_same_fused_graph():
+    """BERT as the reference consumes it (TestBERTGraph.java): frozen TF graph -> TFGraphMapper -> constants to variables -> optimizer.
+    The GraphDef is written by autodiff/export_tf.py in the google-research op vocabulary (decomposed layer norm, erf GELU,
+    BatchMatMul attention with an additive padding mask); the optimizer must rediscover layer_norm / attention (with the key mask)
+    / fused_dense, numerics must match the hand-built graph, and the mixed-precision pass must leave every variable shadowable."""
+    import collections
+    from deeplearning4j_amd.autodiff.export_tf import bert_graphdef
+    from deeplearning4j_amd.autodiff.optimize import MixedPrecision
+    from deeplearning4j_amd.models.bert import BertConfig, build_bert_classifier
+    cfg = BertConfig.tiny()
+    a = SameDiff.create("cpu")
+    build_bert_classifier(a, cfg, 16, 2)
+    weights = {n: a.getArrForVarName(n).tensor() for n in a.trainableVariables()}
+    b = TFGraphMapper.importGraph(bert_graphdef(cfg, 16, 2, weights))
+    raw = collections.Counter(o.opName for o in b.ops.values())
+    assert raw["rsqrt"] == 5 and raw["erf"] == 2 and raw["softmax"] == 2 and raw["matmul"] == 18
+    b.convertToVariables(list(weights))
+    label = b.placeHolder("label", "FLOAT", -1, 2)
+    b.loss.softmaxCrossEntropy(label, b.getVariable("logits"), None, 3, name="loss").markAsLoss()
+    GraphOptimizer.optimize(b, ["logits", "loss"])
+    ops = collections.Counter(o.opName for o in b.ops.values())
+    assert ops["layer_norm"] == 5 and ops["dot_product_attention_v2"] == 2 and ops["fused_dense"] == 7 and ops["xw_plus_b"] == 7, ops
+    assert not any(n in ops for n in ("rsqrt", "erf", "softmax", "matmul", "biasadd"))
+    att = [o for o in b.ops.values() if o.opName == "dot_product_attention_v2"][0]
+    assert len(att.inputs) == 4 and att.inputs[3] == "mask" and list(att.iArgs) == [0, 1]
+    g = torch.Generator().manual_seed(0)
+    mask = torch.ones(4, 16)
+    mask[1, 9:] = 0
+    ids = torch.randint(0, cfg.vocabSize, (4, 16), generator=g)
+    lab = torch.eye(2)[torch.randint(0, 2, (4,), generator=g)]
+    oa = _t(a.output({"tokenIdx": ids, "mask": mask, "label": lab}, ["logits"])["logits"])
+    ob = _t(b.output({"tokenIdx": ids.int(), "mask": mask}, ["logits"])["logits"])
+    assert torch.allclose(oa, ob, atol=1e-4)
+    ga = a.calculateGradients({"tokenIdx": ids, "mask": mask, "label": lab}, list(weights))
+    gb = b.calculateGradients({"tokenIdx": ids.int(), "mask": mask, "label": lab}, list(weights))
+    for n in weights:
+        assert torch.allclose(_t(ga[n]), _t(gb[n]), atol=2e-4), n
+    MixedPrecision.apply(b, "BFLOAT16")
+    assert set(b._bf16_shadowable()) == set(weights)
+    ob16 = _t(b.output({"tokenIdx": ids.int(), "mask": mask}, ["logits"])["logits"])
+    assert ob16.dtype == torch.bfloat16 and (ob16.float() - oa).abs().max() < 0.1
+    loss_in = [o for o in b.ops.values() if "loss" in o.opName][0].inputs
+    assert any(i.endswith("/float") for i in loss_in)

@@ -17,6 +17,8 @@ def main():
     cfg = BertConfig.base()
     cfg.numLayers = layers
     build_bert_classifier(sd, cfg, 128, 2, computeDataType="BFLOAT16")
+    from deeplearning4j_amd.autodiff.optimize import GraphOptimizer
+    GraphOptimizer.optimize(sd)
     sd.setTrainingConfig(TrainingConfig.builder().updater(Adam(2e-5)).build())
     g = torch.Generator().manual_seed(0)
     ph = {"tokenIdx": torch.randint(0, cfg.vocabSize, (32, 128), generator=g).cuda(), "mask": torch.ones(32, 128).cuda(),
