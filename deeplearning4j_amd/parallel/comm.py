@@ -35,6 +35,11 @@ def init_process_group(backend: Optional[str] = None, timeout_s: int = 600):
     kw = {}
     if backend == "nccl" and torch.cuda.is_available():
         kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+    if backend == "nccl":
+        # RCCL error channel (ncclCommGetAsyncError): c10d's own watchdog thread polls the communicator and, in
+        # this mode, tears the process down on an asynchronous error or a collective that exceeds the timeout instead of hanging
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        os.environ.setdefault("TORCH_NCCL_DUMP_ON_TIMEOUT", "0")
     dist.init_process_group(backend=backend, rank=rank, world_size=world,
                             timeout=datetime.timedelta(seconds=timeout_s), **kw)
 
@@ -109,6 +114,81 @@ def reduce_scatter_avg(flat: torch.Tensor) -> torch.Tensor:
     return shard.mul_(1.0 / w)
 
 
+class CommWatchdog:
+    """Host-side failure detector for collective training (both backends): the training loop ``tick()``s once per iteration and
+    registers the async collectives it is waiting on; a daemon thread polls them. A work that reports an exception, or a loop that
+    makes no progress for ``timeout_s`` while collectives are outstanding (a peer died, a link is down), ends THIS process with
+    exit code ``EXIT_CODE`` after printing what it was waiting on — a clean non-zero exit the launcher can act on, instead of a
+    600 s hang per surviving rank. Nothing is re-executed in place (no exec from a process that owns a GPU)."""
+    EXIT_CODE = 75
+
+    def __init__(self, timeout_s: float = 120.0, poll_s: float = 0.5, on_failure=None):
+        import threading
+        import time
+        self.timeout_s, self.poll_s = float(timeout_s), float(poll_s)
+        self.on_failure = on_failure
+        self._last = time.monotonic()
+        self._works = []
+        self._busy = False
+        self._stop = threading.Event()
+        self._lock = threading.Lock()
+        self.failure = None
+        self._thread = threading.Thread(target=self._run, name="dl4j-comm-watchdog", daemon=True)
+        self._thread.start()
+
+    def tick(self):
+        import time
+        self._last = time.monotonic()
+
+    def busy(self, flag: bool):
+        """True while the loop is inside a region that depends on its peers (between iteration start and gradient sync end)."""
+        self._busy = bool(flag)
+        self.tick()
+
+    def watch(self, work):
+        if work is not None:
+            with self._lock:
+                self._works.append(getattr(work, "work", work))
+
+    def clear(self):
+        with self._lock:
+            self._works = []
+
+    def _run(self):
+        import time
+        while not self._stop.wait(self.poll_s):
+            reason = None
+            with self._lock:
+                works = list(self._works)
+            for w in works:
+                try:
+                    exc = w.exception() if w.is_completed() else None
+                except Exception as e:                    # querying a broken communicator may itself raise
+                    exc = e
+                if exc is not None:
+                    reason = "collective failed: %r" % (exc,)
+                    break
+            if reason is None and self._busy and time.monotonic() - self._last > self.timeout_s:
+                reason = "no progress for %.0f s with %d collective(s) outstanding (a peer rank is gone or a link is down)" % (
+                    time.monotonic() - self._last, len(works))
+            if reason is not None:
+                self.failure = reason
+                self._fail(reason)
+                return
+
+    def _fail(self, reason):
+        import sys
+        msg = "[dl4j-comm-watchdog] rank %d/%d: %s -> exiting with code %d" % (rank(), world_size(), reason, self.EXIT_CODE)
+        print(msg, file=sys.stderr, flush=True)
+        if self.on_failure is not None:
+            self.on_failure(reason)
+            return
+        os._exit(self.EXIT_CODE)
+
+    def stop(self):
+        self._stop.set()
+
+
 class GradientBuckets:
     """Contiguous ranges of the flat gradient vector reduced as separate collectives.
 
@@ -116,7 +196,13 @@ class GradientBuckets:
     launched as soon as every parameter at offset >= bucket_start has its gradient — the overlap
     hook calls :meth:`ready` with the lowest finished offset."""
 
-    def __init__(self, flat_grads: torch.Tensor, bucket_bytes: int = 32 << 20, head_bytes: int = 4 << 20):
+    def __init__(self, flat_grads: torch.Tensor, bucket_bytes: int = 32 << 20, head_bytes: int = 4 << 20, wire_dtype=None,
+                 watchdog: Optional["CommWatchdog"] = None):
+        # wire_dtype=torch.bfloat16: the buckets travel as bf16 (half the xGMI bytes; every rank rounds its own gradient once,
+        # RCCL sums in bf16, the average lands back in the fp32 vector) — an option, the default wire format is the vector's own
+        self.wire_dtype = wire_dtype if (wire_dtype is not None and wire_dtype != flat_grads.dtype) else None
+        self._stage = torch.empty(flat_grads.numel(), dtype=self.wire_dtype, device=flat_grads.device) if self.wire_dtype else None
+        self.watchdog = watchdog
         n = flat_grads.numel()
         per = max(1, bucket_bytes // flat_grads.element_size())
         self.flat = flat_grads
@@ -163,19 +249,35 @@ class GradientBuckets:
     def _launch(self, k):
         s, e = self.ranges[k]
         seg = self.flat[s:e]
+        st = self._stage[s:e] if self._stage is not None else None
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                w = all_reduce_avg_(seg, async_op=True)
+                if st is not None:
+                    st.copy_(seg)
+                w = all_reduce_avg_(st if st is not None else seg, async_op=True)
+                if st is not None:
+                    seg.copy_(st)              # stream-ordered after the collective on the comm stream
         else:
-            w = all_reduce_avg_(seg, async_op=True)
+            if st is not None:
+                st.copy_(seg)
+            w = all_reduce_avg_(st if st is not None else seg, async_op=True)
+            if st is not None:                 # host backend (gloo): completion is not stream-ordered
+                if w is not None:
+                    w.wait()
+                    w = None
+                seg.copy_(st)
         if w is not None:
             self._works.append(w)
+            if self.watchdog is not None:
+                self.watchdog.watch(w)
 
     def finish(self):
         self.ready(0)
         for w in self._works:
             w.wait()
+        if self.watchdog is not None:
+            self.watchdog.clear()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.begin()          # self-resetting: the next iteration starts from the tail bucket again
@@ -183,4 +285,10 @@ class GradientBuckets:
     def reduce_all(self):
         """Non-overlapped path: reduce every bucket on the current stream."""
         for s, e in self.ranges:
-            all_reduce_avg_(self.flat[s:e])
+            if self._stage is not None:
+                st = self._stage[s:e]
+                st.copy_(self.flat[s:e])
+                all_reduce_avg_(st)
+                self.flat[s:e].copy_(st)
+            else:
+                all_reduce_avg_(self.flat[s:e])

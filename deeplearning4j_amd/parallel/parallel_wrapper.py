@@ -76,13 +76,22 @@ class ParallelWrapper:
         def overlap(self, b):
             self._kw["overlap"] = b; return self
 
+        def wireDataType(self, dt):
+            """Gradient all-reduce wire format: None (the gradient vector's own type) or "BFLOAT16" (half the xGMI bytes)."""
+            self._kw["wireDataType"] = dt; return self
+
+        def watchdogTimeout(self, seconds):
+            """Seconds without progress (while collectives are outstanding) after which this rank exits with
+            comm.CommWatchdog.EXIT_CODE; 0 disables the watchdog."""
+            self._kw["watchdogTimeout"] = seconds; return self
+
         def build(self):
             return ParallelWrapper(**self._kw)
 
     def __init__(self, model, workers=None, prefetchBuffer=2, averagingFrequency=1, reportScoreAfterAveraging=True,
                  averageUpdaters=True, trainingMode=TrainingMode.SHARED_GRADIENTS, thresholdAlgorithm=None,
                  residualPostProcessor=None, gradientsAccumulator=None, bucketBytes=32 << 20, overlap=True,
-                 modelParamsSupplier=None, updaterParamsSupplier=None, compatEncoding=False):
+                 modelParamsSupplier=None, updaterParamsSupplier=None, compatEncoding=False, wireDataType=None, watchdogTimeout=120.0):
         self.model = model
         self.averagingFrequency = max(1, int(averagingFrequency))
         self.averageUpdaters = averageUpdaters
@@ -111,7 +120,11 @@ class ParallelWrapper:
         comm.broadcast_(model._params, 0)
         comm.broadcast_(model._updater_state, 0)
         model._refresh_replicas()
-        self.buckets = comm.GradientBuckets(model._grads, bucketBytes)
+        wire = None
+        if wireDataType is not None and str(wireDataType).upper() in ("BFLOAT16", "BF16", "TORCH.BFLOAT16"):
+            wire = torch.bfloat16
+        self.watchdog = comm.CommWatchdog(watchdogTimeout) if (watchdogTimeout and (self.world > 1 or comm._forced())) else None
+        self.buckets = comm.GradientBuckets(model._grads, bucketBytes, wire_dtype=wire, watchdog=self.watchdog)
         self._local_iters = 0
         self.accumulator = None
         if compatEncoding or gradientsAccumulator is not None:
@@ -161,8 +174,12 @@ class ParallelWrapper:
             if src.resetSupported():
                 src.reset()
             while src.hasNext() and not self._stop:
+                if self.watchdog is not None:
+                    self.watchdog.busy(True)
                 m.fit(src.next())
                 self._maybe_average_params()
+                if self.watchdog is not None:
+                    self.watchdog.busy(False)
             m.incrementEpochCount()
         return self
 
@@ -173,6 +190,8 @@ class ParallelWrapper:
         self._stop = True
 
     def shutdown(self):
+        if self.watchdog is not None:
+            self.watchdog.stop()
         self.model._grad_sync = None
         self.model._on_backward_progress = None
         self.model._dp_buckets = None

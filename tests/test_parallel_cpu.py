@@ -321,3 +321,86 @@ def test_overlapped_buckets_match_non_overlapped_on_projection_shortcut_block(tm
     r0 = torch.load(tmp_path / "r0.pt", weights_only=True)
     r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
     assert torch.equal(r0["params"], r1["params"])
+
+
+def _wire_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(1)
+    from deeplearning4j_amd.parallel import comm
+    from deeplearning4j_amd.parallel.parallel_wrapper import ParallelWrapper
+    comm.init_process_group("gloo")
+    net = _build(seed=7 + rank)
+    pw = ParallelWrapper.Builder(net).bucketBytes(64).wireDataType("BFLOAT16").build()
+    assert pw.buckets.wire_dtype == torch.bfloat16 and pw.watchdog is not None
+    for step in range(4):
+        x, y = _data(step)
+        h = x.shape[0] // world
+        pw.watchdog.busy(True)
+        net.fit(x[rank * h:(rank + 1) * h], y[rank * h:(rank + 1) * h])
+        pw.watchdog.busy(False)
+    assert pw.params_in_sync() and pw.watchdog.failure is None
+    pw.shutdown()
+    torch.save({"params": net.params().clone()}, os.path.join(out_dir, "r%d.pt" % rank))
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_bf16_wire_format_keeps_ranks_in_sync_and_close_to_fp32(tmp_path):
+    """Gradient buckets all-reduced as bf16: ranks stay bitwise identical, parameters stay within bf16 rounding of the fp32 run."""
+    world, port = 2, _free_port()
+    mp.spawn(_wire_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=True)["params"]
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=True)["params"]
+    assert torch.equal(r0, r1)
+    ref = _build(seed=7)
+    for step in range(4):
+        ref.fit(*_data(step))
+    # bf16 rounding of per-rank gradients: near-cancelling components can flip the sign-normalised update of one element by a full
+    # lr step, so the bound is "a few lr steps at worst, tiny on average"
+    d = (ref.params() - r0).abs()
+    assert d.max() < 4e-2 and d.mean() < 1e-3 and not torch.equal(ref.params(), r0)
+
+
+def _dying_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.set_num_threads(1)
+    from deeplearning4j_amd.parallel import comm
+    from deeplearning4j_amd.parallel.parallel_wrapper import ParallelWrapper
+    comm.init_process_group("gloo", timeout_s=600)
+    net = _build(seed=7)
+    pw = ParallelWrapper.Builder(net).bucketBytes(64).watchdogTimeout(3.0).build()
+    x, y = _data(0)
+    pw.watchdog.busy(True)
+    net.fit(x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4])
+    pw.watchdog.busy(False)
+    if rank == 1:
+        os._exit(0)                                # the peer disappears without a goodbye
+    open(os.path.join(out_dir, "alive"), "w").write("1")
+    pw.watchdog.busy(True)
+    net.fit(x[:4], y[:4])                          # blocks in the all-reduce: only the watchdog can end this process
+    open(os.path.join(out_dir, "unreachable"), "w").write("1")
+
+
+def test_watchdog_ends_the_surviving_rank_with_a_clean_nonzero_exit(tmp_path):
+    """A peer dies between iterations: the survivor must not sit in the collective until the 600 s process-group timeout; the
+    CommWatchdog ends it with EXIT_CODE (or the backend reports the broken connection first — also a prompt non-zero exit)."""
+    import time
+    from deeplearning4j_amd.parallel.comm import CommWatchdog
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_dying_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    procs[0].join(90)
+    took = time.time() - t0
+    alive = procs[0].is_alive()
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert not alive, "surviving rank still blocked after 90 s"
+    assert (tmp_path / "alive").exists() and not (tmp_path / "unreachable").exists()
+    assert procs[0].exitcode not in (0, None) and took < 90
+    assert procs[0].exitcode in (CommWatchdog.EXIT_CODE, 1) or procs[0].exitcode < 0
