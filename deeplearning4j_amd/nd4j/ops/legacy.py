@@ -639,6 +639,29 @@ class LegacyOpExecutioner:
         return exec_random(RANDOM[opNum], rng, z, x, y, extraArguments)
 
 
+def _profiled(fn):
+    """OpProfiler hook of the legacy executioner (OpProfiler.java processOpCall is invoked from DefaultOpExecutioner.exec for
+    EVERY op class, not only custom ops): invocation counts, optional timing / strided-operand penalties, NaN / Inf panics."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(self, name, x, *a, **kw):
+        from ..environment import OpProfiler
+        prof = OpProfiler._inst
+        if prof is None:
+            return fn(self, name, x, *a, **kw)
+        with prof.op(name, x, *[t for t in a[:1] if isinstance(t, torch.Tensor)]):
+            res = fn(self, name, x, *a, **kw)
+        cfg = prof.config
+        if cfg.checkForNAN or cfg.checkForINF:
+            prof.checkOutputs(name, res)
+        return res
+    return run
+
+
+for _m in ("_pairwise", "_transform", "_reduce"):
+    setattr(LegacyOpExecutioner, _m, _profiled(getattr(LegacyOpExecutioner, _m)))
+
 _EXEC = LegacyOpExecutioner()
 
 

@@ -40,7 +40,7 @@ class MirroringPolicy:
 
 
 class LocationPolicy:
-    RAM, MMAP = "RAM", "MMAP"
+    RAM, MMAP, DEVICE_POOL = "RAM", "MMAP", "DEVICE_POOL"        # DEVICE_POOL: private pool of the HIP caching allocator
 
 
 class MemoryKind:
@@ -261,6 +261,74 @@ class _ScopeOut:
         return False
 
 
+class DevicePoolWorkspace(MemoryWorkspace):
+    """Device workspace = a PRIVATE POOL of the HIP caching allocator (torch.cuda.MemPool). While its scope is open every device
+    allocation of the thread — the outputs the op wrappers and HIP launchers allocate themselves, not only explicit ``alloc`` calls
+    — is served from the pool; blocks released inside the scope go back to the pool, never to the global allocator, so the next
+    cycle reuses exactly the same memory. This is the reference's cyclic workspace (one arena per purpose, reused every iteration,
+    nothing freed between iterations: ADR 0024, MultiLayerNetwork.java:1688-1705) expressed with the allocator the kernels already
+    use; the 'learning' of the arena size is the pool keeping its high-water mark. Arrays that must outlive the scope simply stay
+    referenced: their blocks remain owned by the pool until released (the 'leverage / detach' step needs no copy)."""
+
+    def __init__(self, conf: WorkspaceConfiguration, wsId: str, device=None):
+        super().__init__(conf, wsId, device)
+        self._pool = None
+        self._ctx = []
+        self._cycles = 0
+
+    @staticmethod
+    def supported(device) -> bool:
+        return (torch.device(device).type == "cuda" and hasattr(torch.cuda, "MemPool") and hasattr(torch.cuda, "use_mem_pool")
+                and not torch.cuda.is_current_stream_capturing())
+
+    def notifyScopeEntered(self):
+        if self._pool is None:
+            self._pool = torch.cuda.MemPool()
+        dev = self.device if self.device.index is not None else torch.device("cuda", torch.cuda.current_device())
+        cm = torch.cuda.use_mem_pool(self._pool, device=dev)
+        cm.__enter__()
+        self._ctx.append(cm)
+        self._open += 1
+        _stack().append(self)
+        return self
+
+    def notifyScopeLeft(self):
+        cm = self._ctx.pop()
+        cm.__exit__(None, None, None)
+        self._open -= 1
+        st = _stack()
+        if st and st[-1] is self:
+            st.pop()
+        if self._open == 0:
+            self._cycles += 1
+        return self
+
+    __enter__ = notifyScopeEntered
+    close = notifyScopeLeft
+
+    def alloc(self, shape, dtype=torch.float32, initialize=False, device=None) -> torch.Tensor:
+        if not self.isScopeActive():
+            raise RuntimeError("workspace '%s' is not open" % self.id)
+        return (torch.zeros if initialize else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+
+    def _segments(self):
+        return self._pool.snapshot() if self._pool is not None else []
+
+    def getCurrentSize(self, kind=None):
+        """Bytes reserved by the pool (its high-water mark: nothing is returned between cycles)."""
+        return int(sum(seg["total_size"] for seg in self._segments()))
+
+    def getCurrentOffset(self, kind=None):
+        """Bytes currently handed out."""
+        return int(sum(seg["allocated_size"] for seg in self._segments()))
+
+    def getCyclesCount(self):
+        return self._cycles
+
+    def destroyWorkspace(self, extended=True):
+        self._pool = None
+
+
 class DummyWorkspace(MemoryWorkspace):
     def __init__(self):
         super().__init__(WorkspaceConfiguration(policyLearning=LearningPolicy.NONE), "DUMMY")
@@ -284,15 +352,21 @@ class MemoryWorkspaceManager:
     def setDefaultWorkspaceConfiguration(self, conf):
         self._default = conf
 
+    @staticmethod
+    def _make(conf, wsId, device):
+        if conf.policyLocation == LocationPolicy.DEVICE_POOL and device is not None and DevicePoolWorkspace.supported(device):
+            return DevicePoolWorkspace(conf, wsId, device)
+        return MemoryWorkspace(conf, wsId, device)
+
     def createNewWorkspace(self, conf=None, wsId=None, device=None):
-        ws = MemoryWorkspace(conf or self._default, wsId or "WS_%d" % len(self._map()), device)
+        ws = self._make(conf or self._default, wsId or "WS_%d" % len(self._map()), device)
         self._map()[ws.id] = ws
         return ws
 
     def getWorkspaceForCurrentThread(self, conf=None, wsId="DEFAULT", device=None):
         m = self._map()
         if wsId not in m:
-            m[wsId] = MemoryWorkspace(conf or self._default, wsId, device)
+            m[wsId] = self._make(conf or self._default, wsId, device)
         return m[wsId]
 
     def getAndActivateWorkspace(self, conf=None, wsId="DEFAULT", device=None):
@@ -386,8 +460,9 @@ class LayerWorkspaceMgr:
     """Maps ArrayType -> named workspace (reference: nn/workspace/LayerWorkspaceMgr.java; names WS_ALL_LAYERS_ACT,
     WS_LAYER_WORKING_MEM, WS_RNN_LOOP_WORKING_MEM set up at MultiLayerNetwork.java:1688-1705).
 
-    The networks of this framework run on the HIP caching allocator (and, captured, on a static HIP-graph pool), so by default
-    they use ``noWorkspaces()``; the manager exists for API parity and for code that wants arena allocation of scratch."""
+    ``forNetwork`` is what MultiLayerNetwork / ComputationGraph enter around every eager iteration and inference call on the GPU:
+    activations, gradients and scratch come from private allocator pools (DevicePoolWorkspace) that are reused cycle after cycle.
+    Captured (HIP-graph) steps already live in the graph's own static pool and skip the manager."""
     WS_ALL_LAYERS_ACT, WS_LAYER_WORKING_MEM, WS_LAYER_ACT_1, WS_LAYER_ACT_2, WS_RNN_LOOP_WORKING_MEM, WS_OUTPUT_MEM = (
         "WS_ALL_LAYERS_ACT", "WS_LAYER_WORKING_MEM", "WS_LAYER_ACT_1", "WS_LAYER_ACT_2", "WS_RNN_LOOP_WORKING_MEM", "WS_OUTPUT_MEM")
 
@@ -435,6 +510,25 @@ class LayerWorkspaceMgr:
     @staticmethod
     def noWorkspaces():
         return LayerWorkspaceMgr.Builder().defaultNoWorkspace().build()
+
+    @staticmethod
+    def forNetwork(training: bool, device=None):
+        """The manager MultiLayerNetwork.java:1688-1705 builds: activations (+ their gradients when training) in WS_ALL_LAYERS_ACT,
+        per-layer / updater scratch in WS_LAYER_WORKING_MEM, recurrent loop scratch in WS_RNN_LOOP_WORKING_MEM; device pools."""
+        c = WorkspaceConfiguration(policyLocation=LocationPolicy.DEVICE_POOL)
+        b = LayerWorkspaceMgr.Builder()
+        A = ArrayType
+        b.with_(A.INPUT, LayerWorkspaceMgr.WS_ALL_LAYERS_ACT, c).with_(A.ACTIVATIONS, LayerWorkspaceMgr.WS_ALL_LAYERS_ACT, c)
+        b.with_(A.FF_WORKING_MEM, LayerWorkspaceMgr.WS_LAYER_WORKING_MEM, c)
+        b.with_(A.RNN_FF_LOOP_WORKING_MEM, LayerWorkspaceMgr.WS_RNN_LOOP_WORKING_MEM, c)
+        if training:
+            b.with_(A.ACTIVATION_GRAD, LayerWorkspaceMgr.WS_ALL_LAYERS_ACT, c)
+            b.with_(A.BP_WORKING_MEM, LayerWorkspaceMgr.WS_LAYER_WORKING_MEM, c)
+            b.with_(A.RNN_BP_LOOP_WORKING_MEM, LayerWorkspaceMgr.WS_RNN_LOOP_WORKING_MEM, c)
+            b.with_(A.UPDATER_WORKING_MEM, LayerWorkspaceMgr.WS_LAYER_WORKING_MEM, c)
+        m = b.defaultNoWorkspace().build()
+        m.device = device
+        return m
 
     noWorkspacesImmutable = noWorkspaces
 

@@ -402,9 +402,11 @@ class ComputationGraph(BaseNetwork):
                     self._forward(z, False, fmasks=None))], ins)
                 if outs is not None:
                     return outs
-            acts = self._forward(ins, train, fmasks=featureMasks)
+            with self._ws_scope(False):
+                acts = self._forward(ins, train, fmasks=featureMasks)
+                outs = [self._wrap(acts[o]) for o in self.conf.networkOutputs]
         self.clearLayerMaskArrays()
-        return [self._wrap(acts[o]) for o in self.conf.networkOutputs]
+        return outs
 
     def outputSingle(self, *xs, train=False):
         return self.output(*xs, train=train)[0]
@@ -607,8 +609,9 @@ class ComputationGraph(BaseNetwork):
         if self._graph_step is not None and fmasks is None and lmasks is None and len(xs) == 1 and len(ys) == 1:
             self._graph_step.run(xs[0], ys[0])
         else:
-            self.computeGradientAndScore(xs, ys, fmasks, lmasks)
-            self._apply_update(self._last_batch)
+            with self._ws_scope(True):
+                self.computeGradientAndScore(xs, ys, fmasks, lmasks)
+                self._apply_update(self._last_batch)
         self.clearLayerMaskArrays()
         self._after_iteration()
 
@@ -623,8 +626,9 @@ class ComputationGraph(BaseNetwork):
             sy = [y[:, :, s:e] if y.dim() == 3 else y for y in ys]
             fm = [m[:, s:e] if m is not None else None for m in fmasks] if fmasks else None
             lm = [m[:, s:e] if m is not None and m.dim() == 2 and m.shape[1] == T else m for m in lmasks] if lmasks else None
-            self.computeGradientAndScore(sx, sy, fm, lm, mode="tbptt")
-            self._apply_update(self._last_batch)
+            with self._ws_scope(True):
+                self.computeGradientAndScore(sx, sy, fm, lm, mode="tbptt")
+                self._apply_update(self._last_batch)
             self._after_iteration()
         self.rnnClearPreviousState()
         self.clearLayerMaskArrays()

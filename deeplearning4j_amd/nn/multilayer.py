@@ -201,9 +201,10 @@ class MultiLayerNetwork(BaseNetwork):
                 outs = cap.run(lambda z: [self._wrap_out(self._forward(z[0], False, fmask=None))], [x])
                 if outs is not None:
                     return outs[0]
-            y = self._forward(x, train, fmask=self._to_dev(featuresMask))
+            with self._ws_scope(False):
+                y = self._wrap_out(self._forward(x, train, fmask=self._to_dev(featuresMask)))
         self.clearLayerMaskArrays()
-        return self._wrap_out(y)
+        return y
 
     def _wrap_out(self, y):
         if y.dtype != self.ctx.dtype and y.is_floating_point():
@@ -368,8 +369,9 @@ class MultiLayerNetwork(BaseNetwork):
         if self._graph_step is not None and fmask is None and lmask is None:
             self._graph_step.run(x, y)
         else:       # masked / variable-length batches are not part of the captured signature: run them eagerly
-            self.computeGradientAndScore(x, y, fmask, lmask)
-            self._apply_update(self._last_batch)
+            with self._ws_scope(True):
+                self.computeGradientAndScore(x, y, fmask, lmask)
+                self._apply_update(self._last_batch)
         self.clearLayerMaskArrays()
         self._after_iteration()
 
@@ -384,8 +386,9 @@ class MultiLayerNetwork(BaseNetwork):
             ys = y[:, :, s:e] if y.dim() == 3 else y
             fm = fmask[:, s:e] if fmask is not None else None
             lm = lmask[:, s:e] if lmask is not None and lmask.dim() == 2 and lmask.shape[1] == T else lmask
-            self.computeGradientAndScore(xs, ys, fm, lm, mode="tbptt")
-            self._apply_update(self._last_batch)
+            with self._ws_scope(True):
+                self.computeGradientAndScore(xs, ys, fm, lm, mode="tbptt")
+                self._apply_update(self._last_batch)
             self._after_iteration()
         self.rnnClearPreviousState()
         self.clearLayerMaskArrays()

@@ -16,6 +16,8 @@ import math
 import time
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 
 from ..nd4j.learning import IUpdater, NoOp, L1Regularization, L2Regularization, WeightDecay
@@ -448,6 +450,28 @@ class BaseNetwork:
 
     def incrementEpochCount(self):
         self.setEpochCount(self.epochCount + 1)
+
+    def _ws_scope(self, training: bool):
+        """Workspace scope of one eager iteration / inference call (MultiLayerNetwork.java:1688-1705: LayerWorkspaceMgr with
+        WS_ALL_LAYERS_ACT & co. unless the WorkspaceMode is NONE). On the GPU the manager's workspaces are private allocator pools
+        (nd4j/workspace.py DevicePoolWorkspace): everything the iteration allocates is recycled pool memory. CPU runs, captured
+        HIP-graph steps (static graph pool) and WorkspaceMode.NONE get a null scope."""
+        import contextlib
+        from ..nd4j.workspace import ArrayType, DevicePoolWorkspace, LayerWorkspaceMgr
+        from .conf.base import WorkspaceMode
+        mode = self.conf.trainingWorkspaceMode if training else self.conf.inferenceWorkspaceMode
+        if (str(mode).upper() == str(WorkspaceMode.NONE).upper() or not self._initialized
+                or not DevicePoolWorkspace.supported(self.ctx.device) or os.environ.get("DL4J_AMD_WORKSPACES", "1") == "0"):
+            return contextlib.nullcontext()
+        key = "_ws_mgr_train" if training else "_ws_mgr_infer"
+        mgr = getattr(self, key, None)
+        if mgr is None:
+            mgr = LayerWorkspaceMgr.forNetwork(training, self.ctx.device)
+            setattr(self, key, mgr)
+        return mgr.notifyScopeEntered(ArrayType.ACTIVATIONS)
+
+    def getLayerWorkspaceMgr(self, training=True):
+        return getattr(self, "_ws_mgr_train" if training else "_ws_mgr_infer", None)
 
     def _after_iteration(self):
         self.iterationCount += 1

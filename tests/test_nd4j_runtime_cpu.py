@@ -556,3 +556,26 @@ def test_layer_workspace_mgr():
     assert x.shape == (2, 2)
     none = LayerWorkspaceMgr.noWorkspaces()
     assert all(none.isScopedOut(t) for t in ArrayType.ALL)
+
+
+def test_op_profiler_sees_legacy_ops_and_panics_on_nan():
+    """OpProfiler is hooked into the legacy executioner too (every transform / pairwise / reduce call), not only custom ops."""
+    from deeplearning4j_amd.nd4j.environment import OpProfiler, ProfilerConfig
+    from deeplearning4j_amd.nd4j.ops import legacy as LG
+    prof = OpProfiler.getInstance()
+    prof.reset()
+    old = prof.config
+    try:
+        prof.setConfig(ProfilerConfig(checkForNAN=True, notOptimalArguments=True))
+        ex = LG.executioner()
+        x = torch.rand(4, 6) + 0.5
+        ex.execTransformStrict(LG.op_num("transform_strict", "Sin"), x)
+        ex.execPairwiseTransform(LG.op_num("pairwise", "Add"), x, x)
+        ex.execReduceSame(LG.op_num("reduce_same", "Sum"), x.t(), [0])
+        assert prof.getInvocationsCount("Sin") == 1 and prof.getInvocationsCount("Add") == 1 and prof.getInvocationsCount("Sum") == 1
+        assert prof.penalties.get("STRIDED_ACCESS:Sum") == 1
+        with pytest.raises(FloatingPointError):
+            ex.execTransformStrict(LG.op_num("transform_strict", "Log"), -x)
+    finally:
+        prof.setConfig(old)
+        prof.reset()
