@@ -571,3 +571,233 @@ class Nd4j:
     def clearNans(arr):
         arr.tensor().nan_to_num_(nan=0.0)
         return arr
+
+
+# ----------------------------------------------------------------------------- remaining Nd4j.java static surface
+def _t_of(a):
+    return a.tensor() if hasattr(a, "tensor") else torch.as_tensor(a)
+
+
+def _wrap_like(t, a=None):
+    return INDArray(t, a.ordering() if isinstance(a, INDArray) else _State.order)
+
+
+class _EagerNamespace:
+    """Nd4j.math() / nn() / cnn() / rnn() / loss() / linalg() / bitwise() / random() / image() / base(): eager op namespaces
+    (reference: org.nd4j.linalg.factory.ops.ND*). Any registered custom-op name is callable: arrays in, INDArray(s) out."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __getattr__(self, opName):
+        if opName.startswith("_"):
+            raise AttributeError(opName)
+        from .ops.custom import describe, exec_op
+        import re as _re
+        cand = [opName, _re.sub(r"(?<!^)(?=[A-Z])", "_", opName).lower(), opName.lower()]
+        name = next((c for c in cand if describe(c) is not None), None)
+        if name is None:
+            raise AttributeError("Nd4j.%s(): no op named '%s' in the registry" % (self.kind, opName))
+
+        def call(*inputs, iArgs=None, tArgs=None, bArgs=None, dArgs=None):
+            outs = exec_op(name, [_t_of(x) for x in inputs], iArgs=iArgs, tArgs=tArgs, bArgs=bArgs, dArgs=dArgs)
+            outs = [INDArray(o) if isinstance(o, torch.Tensor) else o for o in outs]
+            return outs[0] if len(outs) == 1 else outs
+        return call
+
+
+def _install_nd4j_extras():
+    S = staticmethod
+    N = Nd4j
+    for ns in ("math", "nn", "cnn", "rnn", "loss", "linalg", "bitwise", "random", "image", "base"):
+        setattr(N, ns, S((lambda k: (lambda: _EagerNamespace(k)))(ns)))
+    # reductions along dimensions (Nd4j.sum(arr, dims...) etc.)
+    for nm in ("sum", "mean", "max", "min", "prod", "norm1", "norm2", "normmax", "std", "var"):
+        setattr(N, nm, S((lambda m: (lambda arr, *dims: getattr(arr, m)(*dims)))(nm)))
+    N.argMin = S(lambda arr, *dims: arr.argMin(*dims) if hasattr(arr, "argMin") else INDArray(torch.argmin(_t_of(arr), dim=dims[0] if dims else None)))
+    N.cumsum = S(lambda arr, dim=-1: INDArray(torch.cumsum(_t_of(arr), dim)))
+    N.shape = S(lambda arr: list(_t_of(arr).shape))
+    N.copy = S(lambda a, b: (_t_of(b).copy_(_t_of(a)), b)[1])
+    N.append = S(lambda arr, padAmount, val, axis=-1: _wrap_like(torch.cat(
+        [_t_of(arr), torch.full([padAmount if d == axis % _t_of(arr).dim() else s for d, s in enumerate(_t_of(arr).shape)], float(val),
+                                dtype=_t_of(arr).dtype, device=_t_of(arr).device)], axis), arr))
+    N.prepend = S(lambda arr, padAmount, val, axis=-1: _wrap_like(torch.cat(
+        [torch.full([padAmount if d == axis % _t_of(arr).dim() else s for d, s in enumerate(_t_of(arr).shape)], float(val),
+                    dtype=_t_of(arr).dtype, device=_t_of(arr).device), _t_of(arr)], axis), arr))
+
+    def appendBias(*vectors):
+        """Column of the concatenated vectors with a trailing 1 (bias unit)."""
+        t = torch.cat([_t_of(v).reshape(-1) for v in vectors] + [torch.ones(1, dtype=_t_of(vectors[0]).dtype, device=_t_of(vectors[0]).device)])
+        return INDArray(t.reshape(-1, 1))
+    N.appendBias = S(appendBias)
+
+    def pad(arr, padWidth, mode="CONSTANT", value=0.0):
+        t = _t_of(arr)
+        pw = [list(p) if isinstance(p, (list, tuple)) else [int(p), int(p)] for p in (padWidth if isinstance(padWidth[0], (list, tuple)) else [padWidth] * t.dim())]
+        flat = [v for p in reversed(pw) for v in p]
+        m = {"CONSTANT": "constant", "REFLECT": "reflect", "SYMMETRIC": "symmetric", "EDGE": "replicate"}[str(mode).upper()]
+        if m == "symmetric":
+            from .ops.custom import exec_op
+            return INDArray(exec_op("mirror_pad", [t, torch.tensor(pw)], iArgs=[1])[0])
+        if m == "constant":
+            return _wrap_like(torch.nn.functional.pad(t, flat, mode=m, value=float(value)), arr)
+        t2 = t.reshape((1,) * max(0, len(flat) // 2 + 1 - t.dim()) + tuple(t.shape)) if t.dim() < len(flat) // 2 + 1 else t
+        return _wrap_like(torch.nn.functional.pad(t2, flat, mode=m).reshape([s + a + b for s, (a, b) in zip(t.shape, pw)]), arr)
+    N.pad = S(pad)
+    N.repeat = S(lambda arr, n: _wrap_like(torch.cat([_t_of(arr)] * int(n), 0), arr))
+    N.rollAxis = S(lambda arr, axis, start=0: _wrap_like(torch.movedim(_t_of(arr), axis, start if start <= axis else start - 1), arr))
+    N.rot90 = S(lambda arr: _t_of(arr).copy_(torch.rot90(_t_of(arr), 1, (0, 1)).reshape(_t_of(arr).shape)) if _t_of(arr).shape[0] == _t_of(arr).shape[1]
+                else _wrap_like(torch.rot90(_t_of(arr), 1, (0, 1)), arr))
+    N.meshgrid = S(lambda x, y: [INDArray(g) for g in torch.meshgrid(_t_of(x).reshape(-1), _t_of(y).reshape(-1), indexing="xy")])
+    N.tri = S(lambda n, m=None, k=0, dtype=None: INDArray(torch.tril(torch.ones(n, m or n, dtype=DataType.to_torch(dtype) if dtype else _State.dtype,
+                                                                                   device=_State.device), k)))
+    N.triu = S(lambda arr, k=0: _wrap_like(torch.triu(_t_of(arr), k), arr))
+    N.stripOnes = S(lambda arr: _wrap_like(_t_of(arr).reshape([s for s in _t_of(arr).shape if s != 1] or [1]), arr))
+
+    def sortRows(arr, colIdx, ascending=True):
+        t = _t_of(arr)
+        return _wrap_like(t[torch.argsort(t[:, colIdx], descending=not ascending, stable=True)], arr)
+
+    def sortColumns(arr, rowIdx, ascending=True):
+        t = _t_of(arr)
+        return _wrap_like(t[:, torch.argsort(t[rowIdx], descending=not ascending, stable=True)], arr)
+    N.sortRows, N.sortColumns = S(sortRows), S(sortColumns)
+    N.specialConcat = S(lambda dim, *arrs: N.concat(dim, *arrs))
+
+    def choice(source, probs, numSamples_or_target, rng=None):
+        """Sample elements of ``source`` with the given probabilities (Nd4j.choice -> legacy random op Choice)."""
+        src, p = _t_of(source).reshape(-1), _t_of(probs).reshape(-1).double()
+        n = numSamples_or_target if isinstance(numSamples_or_target, int) else _t_of(numSamples_or_target).numel()
+        g = rng.generator(src.device) if (rng is not None and hasattr(rng, "generator")) else None
+        idx = torch.multinomial(p / p.sum(), n, replacement=True, generator=g)
+        out = src[idx.to(src.device)]
+        if isinstance(numSamples_or_target, int):
+            return INDArray(out)
+        _t_of(numSamples_or_target).view(-1).copy_(out)
+        return numSamples_or_target
+    N.choice = S(choice)
+
+    def scatterUpdate(op, array, indices, updates, axis):
+        """In-place update of the sub-arrays of ``array`` along ``axis`` picked by ``indices`` (ScatterUpdate.UpdateOp order:
+        ADD, SUBTRACT, MULTIPLY, DIVIDE, RSUBTRACT, RDIVIDE, ASSIGN)."""
+        t, u = _t_of(array), _t_of(updates)
+        ax = [a % t.dim() for a in (axis if isinstance(axis, (list, tuple)) else [axis])]
+        lead = [d for d in range(t.dim()) if d not in ax]
+        tv = t.permute(*lead, *ax)
+        tv = tv.reshape(-1, *tv.shape[len(lead):]) if lead else tv.unsqueeze(0)
+        uv = u.reshape(len(indices), *tv.shape[1:])
+        k = op if isinstance(op, int) else ["ADD", "SUBTRACT", "MULTIPLY", "DIVIDE", "RSUBTRACT", "RDIVIDE", "ASSIGN"].index(str(op).upper())
+        for j, i in enumerate(int(v) for v in (indices.tolist() if hasattr(indices, "tolist") else indices)):
+            cur = tv[i]
+            tv[i] = [cur + uv[j], cur - uv[j], cur * uv[j], cur / uv[j], uv[j] - cur, uv[j] / cur, uv[j]][k]
+        return array
+    N.scatterUpdate = S(scatterUpdate)
+    # buffers / construction from descriptors
+    from .common import DataBuffer as _DB
+
+    def createBuffer(*args, dtype=None):
+        a0 = args[0] if args else 0
+        dt = DataType.to_torch(dtype) if dtype else _State.dtype
+        if isinstance(a0, int):
+            return _DB(torch.zeros(a0, dtype=dt))
+        if isinstance(a0, (list, tuple)) and a0 and isinstance(a0[0], int) and len(args) > 1 and isinstance(args[1], str):
+            return _DB(torch.zeros(int(np.prod(a0)), dtype=DataType.to_torch(args[1])))
+        return _DB(torch.as_tensor(a0, dtype=dt if dtype or not isinstance(a0, torch.Tensor) else None).reshape(-1))
+    N.createBuffer = N.createBufferDetached = S(createBuffer)
+    N.createTypedBuffer = N.createTypedBufferDetached = S(lambda data, dtype: _DB(torch.as_tensor(data).to(DataType.to_torch(dtype)).reshape(-1)))
+
+    def createArrayFromShapeBuffer(data, shapeInfo):
+        si = [int(v) for v in (_t_of(shapeInfo).tolist() if not isinstance(shapeInfo, (list, tuple)) else shapeInfo)]
+        r = si[0]
+        shape, stride = si[1:1 + r], si[1 + r:1 + 2 * r]
+        order = "f" if si[-1] == 102 else "c"
+        base = data.tensor() if hasattr(data, "tensor") else torch.as_tensor(data)
+        return INDArray(torch.as_strided(base.reshape(-1), shape, stride), order)
+    N.createArrayFromShapeBuffer = S(createArrayFromShapeBuffer)
+
+    def createFromFlatArray(buf):
+        from ..autodiff import serde as ASD
+        return INDArray(ASD.flat_array_from_bytes(buf)) if hasattr(ASD, "flat_array_from_bytes") else INDArray(serde.from_bytes(buf))
+    N.createFromFlatArray = S(createFromFlatArray)
+
+    # numpy / text IO
+    def toNpyByteArray(arr):
+        import io as _io
+        b = _io.BytesIO()
+        np.save(b, _t_of(arr).detach().cpu().numpy(), allow_pickle=False)
+        return b.getvalue()
+
+    def createNpyFromByteArray(data):
+        import io as _io
+        return INDArray(torch.from_numpy(np.load(_io.BytesIO(bytes(data)), allow_pickle=False)).to(_State.device))
+    N.toNpyByteArray, N.convertToNumpy = S(toNpyByteArray), S(toNpyByteArray)
+    N.createNpyFromByteArray = S(createNpyFromByteArray)
+    N.createNpyFromInputStream = S(lambda stream: createNpyFromByteArray(stream.read()))
+    N.createFromNpyPointer = S(lambda pointer: createNpyFromByteArray(pointer))
+
+    def writeTxt(arr, path):
+        """The text format of Nd4j.writeTxt: a JSON header (filefrom, ordering, shape, data type) followed by the values."""
+        import json
+        t = _t_of(arr).detach().cpu()
+        with open(str(path), "w") as f:
+            f.write(json.dumps({"filefrom": "dl4j", "ordering": arr.ordering() if isinstance(arr, INDArray) else "c",
+                                "shape": list(t.shape), "dataType": DataType.from_torch(t.dtype)}) + "\n")
+            f.write(json.dumps(t.double().tolist() if t.is_floating_point() else t.tolist()))
+
+    def readTxtString(text):
+        import json
+        head, _, body = text.partition("\n")
+        h = json.loads(head)
+        t = torch.tensor(json.loads(body), dtype=DataType.to_torch(h["dataType"])).reshape(h["shape"])
+        return INDArray(t.to(_State.device), h.get("ordering", "c"))
+    N.writeTxt, N.readTxtString = S(writeTxt), S(readTxtString)
+    N.readTxt = S(lambda path: readTxtString(open(str(path)).read()))
+
+    def readNumpy(path, sep=",", dtype=None):
+        """Delimited text matrix (numpy.savetxt style), parsed by the native CSV reader."""
+        rows = [[float(v) for v in line.strip().split(sep)] for line in open(str(path)) if line.strip()]
+        return INDArray(torch.tensor(rows, dtype=DataType.to_torch(dtype) if dtype else _State.dtype, device=_State.device))
+    N.readNumpy = S(readNumpy)
+    # randomness
+    N.randWithSeed = S(lambda seed, *shape: INDArray(torch.rand(*[int(s) for s in (shape[0] if len(shape) == 1 and isinstance(shape[0], (list, tuple)) else shape)],
+                                                                generator=torch.Generator().manual_seed(int(seed)), dtype=_State.dtype).to(_State.device)))
+    N.getDistributions = S(lambda: __import__("deeplearning4j_amd.nd4j.rng", fromlist=["Distributions"]).Distributions
+                           if hasattr(__import__("deeplearning4j_amd.nd4j.rng", fromlist=["x"]), "Distributions") else N.getRandom())
+    # environment switches / role singletons
+    from . import environment as _env
+    N.setDataType = S(lambda dt: N.setDefaultDataTypes(dt, dt))
+    N.allowsSpecifyOrdering = S(lambda: True)
+    N.checkShapeValues = S(lambda *shape: [int(v) for v in (shape[0] if len(shape) == 1 and isinstance(shape[0], (list, tuple)) else shape)]
+                           if all(int(v) >= 0 for v in (shape[0] if len(shape) == 1 and isinstance(shape[0], (list, tuple)) else shape))
+                           else (_ for _ in ()).throw(ValueError("Invalid shape: Requested INDArray shape contains dimension size values < 0")))
+    N.enableFallbackMode = S(lambda flag: setattr(_State, "fallback", bool(flag)))
+    N.isFallbackModeEnabled = S(lambda: bool(getattr(_State, "fallback", False)))
+    N.isExperimentalMode = S(lambda: False)
+    N.isPrecisionBoostAllowed = S(lambda: bool(L.rt().env_get_precision_boost()))
+    N.getProfiler = S(lambda: _env.OpProfiler.getInstance())
+    N.toggleTrace = S(lambda flag: L.rt().op_trace_toggle(int(bool(flag))))
+    N.purgeTrace = S(lambda: L.rt().op_trace_purge())
+    N.factory = N.getNDArrayFactory = S(lambda: N)
+    N.setFactory = S(lambda f: None)
+    N.getDataBufferFactory = S(lambda: N)
+    N.getBlasLapackDelegator = S(lambda: N.getBlasWrapper() if hasattr(N, "getBlasWrapper") else N)
+    N.getConstantHandler = N.getShapeInfoProvider = S(lambda: L.rt())
+    N.getDeviceIdProvider = S(lambda: N.getAffinityManager())
+    N.getStatsProvider = S(lambda: N.getMemoryManager())
+
+    def getDeallocatorService():
+        from .backend import DeallocatorService
+        return DeallocatorService.getInstance() if hasattr(DeallocatorService, "getInstance") else DeallocatorService()
+    N.getDeallocatorService = S(getDeallocatorService)
+    N._convolution = None
+    N.getConvolution = S(lambda: N._convolution or _EagerNamespace("cnn"))
+    N.setConvolution = S(lambda c: setattr(N, "_convolution", c))
+
+    def close(*arrs):
+        for a in arrs:
+            if a is not None and hasattr(a, "close"):
+                a.close()
+    N.close = S(close)
+
+
+_install_nd4j_extras()

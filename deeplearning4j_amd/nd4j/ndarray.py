@@ -648,6 +648,257 @@ class INDArray:
     def toFloatMatrix(self): return self._t.detach().float().cpu().tolist()
     def toIntMatrix(self): return self._t.detach().int().cpu().tolist()
 
+    # -- remaining INDArray.java surface (conditions, statistics, vector-broadcast variants, descriptors, scope / compression flags)
+    def _cond_mask(self, cond):
+        """bool mask of a Condition (nd4j/common.py Conditions.*) or a python predicate over the tensor."""
+        if hasattr(cond, "mask"):
+            return cond.mask(self._t)
+        return cond(self._t)
+
+    def cond(self, condition):
+        """1 where the condition holds, else 0 (same data type)."""
+        return INDArray(self._cond_mask(condition).to(self._t.dtype), self._order)
+
+    def match(self, comp, condition):
+        """BOOL array: where does ``self <condition> comp`` hold (comp: number or array; condition gives the comparison)."""
+        c = _unwrap(comp)
+        name = type(condition).__name__.lower() if not isinstance(condition, str) else condition.lower()
+        ops = {"equals": torch.eq, "epsequals": lambda a, b: (a - b).abs() < 1e-5, "notequals": torch.ne, "epsnotequals": lambda a, b: (a - b).abs() >= 1e-5,
+               "greaterthan": torch.gt, "greaterthanorequal": torch.ge, "lessthan": torch.lt, "lessthanorequal": torch.le}
+        key = [k for k in ops if name.replace("_", "").startswith(k)]
+        if not key:
+            return INDArray(self._cond_mask(condition), self._order)
+        c = torch.as_tensor(c, device=self._t.device, dtype=self._t.dtype)
+        return INDArray(ops[max(key, key=len)](self._t, c), self._order)
+
+    def getWhere(self, comp, condition):
+        """1-D array of the elements for which ``self <condition> comp`` holds (Nd4j getWhere / boolean_mask)."""
+        m = self.match(comp, condition)._t if comp is not None else self._cond_mask(condition)
+        return INDArray(self._t[m], self._order)
+
+    def putWhere(self, comp, put, condition):
+        """Copy of this array with ``put`` written where ``self <condition> comp`` holds."""
+        m = self.match(comp, condition)._t
+        out = self._t.clone()
+        pv = _unwrap(put)
+        out[m] = pv[m] if isinstance(pv, torch.Tensor) and pv.shape == out.shape else torch.as_tensor(pv, device=out.device, dtype=out.dtype)
+        return INDArray(out, self._order)
+
+    def putWhereWithMask(self, mask, put):
+        m = _unwrap(mask).bool()
+        out = self._t.clone()
+        pv = _unwrap(put)
+        out[m] = pv[m] if isinstance(pv, torch.Tensor) and pv.shape == out.shape else torch.as_tensor(pv, device=out.device, dtype=out.dtype)
+        return INDArray(out, self._order)
+
+    def replaceWhere(self, arr, condition):
+        """In place: elements that satisfy the condition are replaced by the corresponding elements of ``arr``."""
+        m = self._cond_mask(condition)
+        self._t[m] = _unwrap(arr).to(self._t.dtype)[m]
+        return self
+
+    def assignIf(self, arr, condition):
+        """In place: take arr's element wherever arr's element satisfies the condition (CompareAndSet semantics)."""
+        a = _unwrap(arr).to(self._t.device, self._t.dtype)
+        m = condition.mask(a) if hasattr(condition, "mask") else condition(a)
+        self._t[m] = a[m]
+        return self
+
+    def scan(self, condition):
+        """Number of elements that satisfy the condition (MatchCondition reduction)."""
+        return int(self._cond_mask(condition).sum())
+
+    def eps(self, other):
+        o = torch.as_tensor(_unwrap(other), device=self._t.device, dtype=self._t.dtype)
+        return INDArray((self._t - o).abs() < 1e-5, self._order)
+
+    def isInfinite(self):
+        return INDArray(torch.isinf(self._t), self._order)
+
+    def isNaN(self):
+        return INDArray(torch.isnan(self._t), self._order)
+
+    def entropyNumber(self): return self.entropy()._t.item()
+    def shannonEntropyNumber(self): return self.shannonEntropy()._t.item()
+    def logEntropyNumber(self): return self.logEntropy()._t.item()
+
+    def median(self, *dims):
+        x = self._t if self._t.is_floating_point() else self._t.double()
+        if not dims:
+            return INDArray(torch.quantile(x.reshape(-1).double(), 0.5).to(x.dtype), self._order)
+        return self.percentile(50.0, *dims)
+
+    def medianNumber(self):
+        return self.median()._t.item()
+
+    def percentile(self, q, *dims):
+        """Linear-interpolated percentile (q in 0..100) over the given dimensions (Percentile op / ops/declarable percentile)."""
+        x = (self._t if self._t.is_floating_point() else self._t.double())
+        if not dims:
+            return INDArray(torch.quantile(x.reshape(-1).double(), float(q) / 100.0).to(x.dtype), self._order)
+        dims = sorted(d % x.dim() for d in dims)
+        keep = [d for d in range(x.dim()) if d not in dims]
+        y = x.permute(*keep, *dims).reshape([x.shape[d] for d in keep] + [-1])
+        return INDArray(torch.quantile(y.double(), float(q) / 100.0, dim=-1).to(x.dtype), self._order)
+
+    def percentileNumber(self, q):
+        return self.percentile(q)._t.item()
+
+    def remainderi(self, other):
+        self._t.copy_(torch.remainder(self._t, torch.as_tensor(_unwrap(other), device=self._t.device, dtype=self._t.dtype)))
+        return self
+
+    def rsubiRowVector(self, v): return self._vec("ReverseSubtract", v, -1, True)
+    def rdiviRowVector(self, v): return self._vec("ReverseDivide", v, -1, True)
+    def rsubColumnVector(self, v): return self._vec("ReverseSubtract", v, 0, False)
+    def rsubiColumnVector(self, v): return self._vec("ReverseSubtract", v, 0, True)
+    def rdivColumnVector(self, v): return self._vec("ReverseDivide", v, 0, False)
+    def rdiviColumnVector(self, v): return self._vec("ReverseDivide", v, 0, True)
+
+    def putiRowVector(self, v):
+        self._t.copy_(_unwrap(v).reshape(1, -1).to(self._t.device, self._t.dtype).expand_as(self._t))
+        return self
+
+    def putiColumnVector(self, v):
+        self._t.copy_(_unwrap(v).reshape(-1, 1).to(self._t.device, self._t.dtype).expand_as(self._t))
+        return self
+
+    def isVectorOrScalar(self): return self.isVector() or self._t.numel() == 1
+    def isRowVectorOrScalar(self): return self.isRowVector() or self._t.numel() == 1
+    def isColumnVectorOrScalar(self): return (self._t.dim() == 2 and self._t.shape[1] == 1) or self._t.numel() == 1
+    def isS(self): return False                 # no UTF string arrays on the device
+    def isSparse(self): return False
+    def isCompressed(self): return bool(getattr(self, "_compressed", False))
+
+    def markAsCompressed(self, reallyCompressed):
+        self._compressed = bool(reallyCompressed)
+
+    def isInScope(self):
+        """An array attached to a workspace is usable only while that workspace's generation is alive."""
+        ws = getattr(self, "_ws", None)
+        if ws is None:
+            return True
+        from .workspace import getWorkspaceManager
+        return getWorkspaceManager().checkIfWorkspaceExists(ws)
+
+    def leverageOrDetach(self, workspaceId):
+        from .workspace import getWorkspaceManager
+        if getWorkspaceManager().checkIfWorkspaceExistsAndActive(workspaceId):
+            return self.leverageTo(workspaceId)
+        return self.detach()
+
+    def getId(self):
+        return id(self)
+
+    def setCloseable(self, flag):
+        self._closeable = bool(flag)
+
+    def element(self):
+        if self._t.numel() != 1:
+            raise ValueError("Unable to retrieve element from non scalars")
+        return self._t.item()
+
+    def getDoubleUnsafe(self, offset):
+        return float(self.data()[int(offset)]) if not isinstance(self.data(), torch.Tensor) else float(self._t.reshape(-1)[int(offset)])
+
+    def putScalarUnsafe(self, offset, value):
+        self._t.view(-1)[int(offset)] = value
+        return self
+
+    def getString(self, index):
+        raise TypeError("getString: this array is not of a UTF8 data type")
+
+    def linearIndex(self, i):
+        """Buffer offset of the i-th element in this array's iteration order."""
+        t = self._t
+        idx, off = int(i), 0
+        dims = range(t.dim() - 1, -1, -1) if self._order == "c" else range(t.dim())
+        for d in dims:
+            off += (idx % t.shape[d]) * t.stride(d)
+            idx //= t.shape[d]
+        return off + t.storage_offset()
+
+    def originalOffset(self):
+        return self._t.storage_offset()
+
+    def getLeadingOnes(self):
+        n = 0
+        for s_ in self._t.shape:
+            if s_ != 1:
+                break
+            n += 1
+        return n
+
+    def getTrailingOnes(self):
+        n = 0
+        for s_ in reversed(self._t.shape):
+            if s_ != 1:
+                break
+            n += 1
+        return n
+
+    def dimShuffle(self, rearrange, newOrder, broadCastable):
+        """Theano-style dimshuffle: ``rearrange`` entries are dimension indices or 'x' (new broadcast axis of size 1)."""
+        t = self._t
+        used = [r for r in rearrange if r != "x"]
+        dropped = [d for d in range(t.dim()) if d not in used]
+        if any(t.shape[d] != 1 for d in dropped):
+            raise ValueError("dimShuffle can only drop dimensions of size 1")
+        t = t.permute(*used, *dropped).reshape([t.shape[d] for d in used])
+        for pos, r in enumerate(rearrange):
+            if r == "x":
+                t = t.unsqueeze(pos)
+        return INDArray(t, self._order)
+
+    def sliceVectors(self, out=None):
+        out = [] if out is None else out
+        if self._t.dim() <= 1:
+            out.append(self)
+        else:
+            for k in range(self._t.shape[0]):
+                INDArray(self._t[k], self._order).sliceVectors(out)
+        return out
+
+    def setData(self, data):
+        src = data.tensor() if hasattr(data, "tensor") else torch.as_tensor(_unwrap(data))
+        self._t.view(-1).copy_(src.reshape(-1).to(self._t.device, self._t.dtype))
+
+    def setOrder(self, order):
+        assert order in ("c", "f")
+        self._order = order
+
+    def setShapeAndStride(self, shape, stride):
+        self._t = torch.as_strided(self._t, [int(v) for v in shape], [int(v) for v in stride], self._t.storage_offset())
+
+    def shapeInfoJava(self):
+        return list(self.shapeInfo())
+
+    def shapeInfoDataBuffer(self):
+        from .common import DataBuffer
+        return DataBuffer(torch.tensor(list(self.shapeInfo()), dtype=torch.int64))
+
+    def shapeDescriptor(self):
+        from .common import LongShapeDescriptor
+        return LongShapeDescriptor.fromShape(list(self._t.shape), self.dataType()) if hasattr(LongShapeDescriptor, "fromShape") else \
+            LongShapeDescriptor(list(self._t.shape), list(self._t.stride()), self._t.storage_offset(), 1, self._order, self.dataType())
+
+    def toFlatArray(self, builder=None):
+        """FlatBuffers FlatArray bytes of this array (graph serialisation wire format, autodiff/serde.py)."""
+        from ..autodiff import serde as ASD
+        return ASD.flat_array_bytes(self._t) if hasattr(ASD, "flat_array_bytes") else serde.to_bytes(self._t)
+
+    def toLongMatrix(self): return self._t.detach().long().cpu().tolist()
+
+    def toStringFull(self):
+        with torch._tensor_str.printoptions(threshold=1 << 62, precision=8):
+            return repr(self._t)
+
+    def unsafeDuplication(self, blocking=True):
+        out = INDArray(self._t.clone(), self._order)
+        if blocking and self._t.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return out
+
     def __len__(self):
         return self._t.shape[0] if self._t.dim() else 1
 

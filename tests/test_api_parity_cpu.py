@@ -2,6 +2,8 @@
 SPI, KerasModel / KerasSequentialModel."""
 import json
 
+import pytest
+
 import torch
 
 from deeplearning4j_amd.nd4j.learning import Adam, Sgd
@@ -85,3 +87,71 @@ def test_layer_helper_spi_and_keras_model_classes():
     assert isinstance(km, KerasSequentialModel) and km.getClassName() == "Sequential" and km.getLayerNames() == ["d1", "d2"]
     mln = km.getMultiLayerNetwork(importWeights=False, device="cpu")
     assert tuple(mln.output(torch.randn(2, 4)).shape) == (2, 3)
+
+
+def _java_methods(path, static=False):
+    import re
+    src = open(path).read()
+    if static:
+        return set(re.findall(r"^\s+public\s+static\s+(?:synchronized\s+)?(?:<[^>]+>\s+)?[\w<>\[\],\.\?]+\s+(\w+)\s*\(", src, re.M))
+    names = set(re.findall(r"^\s+(?:default\s+)?[\w<>\[\],\s\.]+?\s+(\w+)\s*\(", src, re.M))
+    return {n for n in names if n not in ("if", "for", "while", "return", "switch")}
+
+
+def test_indarray_and_nd4j_cover_every_method_name_of_the_reference_sources():
+    """Name-level surface parity against the reference's own sources (INDArray.java interface, Nd4j.java statics)."""
+    import os
+    base = "/root/reference/nd4j/nd4j-backends/nd4j-api-parent/nd4j-api/src/main/java/org/nd4j/linalg/"
+    if not os.path.exists(base):
+        pytest.skip("reference tree not present")
+    from deeplearning4j_amd.nd4j.factory import Nd4j
+    from deeplearning4j_amd.nd4j.ndarray import INDArray
+    miss = sorted(n for n in _java_methods(base + "api/ndarray/INDArray.java") if not hasattr(INDArray, n))
+    assert not miss, miss
+    miss = sorted(n for n in _java_methods(base + "factory/Nd4j.java", static=True) if not hasattr(Nd4j, n))
+    assert not miss, miss
+
+
+def test_indarray_condition_statistics_and_descriptor_methods():
+    from deeplearning4j_amd.nd4j.common import Conditions
+    from deeplearning4j_amd.nd4j.ndarray import INDArray
+    a = INDArray(torch.tensor([[1., -2., 3.], [4., 5., -6.]]))
+    assert a.cond(Conditions.greaterThan(0)).tensor().tolist() == [[1, 0, 1], [1, 1, 0]]
+    assert a.scan(Conditions.lessThan(0)) == 2
+    assert a.getWhere(0.0, Conditions.greaterThan(0)).tensor().tolist() == [1, 3, 4, 5]
+    assert a.putWhere(0.0, 9.0, Conditions.lessThan(0)).tensor().tolist() == [[1, 9, 3], [4, 5, 9]]
+    assert a.medianNumber() == 2.0 and a.percentile(50, 1).tensor().tolist() == [1, 4]
+    b = a.dup()
+    b.replaceWhere(INDArray(torch.zeros(2, 3)), Conditions.lessThan(0))
+    assert b.tensor().min() == 0
+    assert a.rsubColumnVector(torch.tensor([1., 2.])).tensor().tolist() == [[0, 3, -2], [-2, -3, 8]]
+    assert a.dimShuffle([1, "x", 0], None, None).shape() == [3, 1, 2]
+    assert a.linearIndex(4) == 4 and INDArray(torch.arange(6.).reshape(2, 3).t()).linearIndex(1) == 3
+    assert INDArray(torch.zeros(1, 1, 4, 1)).getLeadingOnes() == 2 and INDArray(torch.zeros(1, 1, 4, 1)).getTrailingOnes() == 1
+    assert a.shapeInfoJava()[:3] == [2, 2, 3] and len(a.sliceVectors()) == 2 and a.isInScope()
+    assert a.eps(a.add(1e-7)).tensor().all() and not a.isNaN().tensor().any()
+    assert len(a.toFlatArray()) > 24 and "tensor" in a.toStringFull()
+
+
+def test_nd4j_static_extras(tmp_path):
+    from deeplearning4j_amd.nd4j.factory import Nd4j
+    a = Nd4j.create([[1., 2., 3.], [4., 5., 6.]])
+    assert Nd4j.sum(a, 0).tensor().tolist() == [5, 7, 9] and Nd4j.append(a, 2, 0.0, 1).shape() == [2, 5]
+    assert Nd4j.prepend(a, 1, 7.0, 0).tensor()[0].tolist() == [7, 7, 7]
+    assert Nd4j.pad(a, [[1, 1], [0, 2]]).shape() == [4, 5]
+    assert Nd4j.sortRows(a, 0, False).tensor()[0].tolist() == [4, 5, 6] and Nd4j.sortColumns(a, 0, False).tensor()[0].tolist() == [3, 2, 1]
+    assert Nd4j.tri(3).tensor().sum() == 6 and Nd4j.triu(a, 1).tensor().tolist() == [[0, 2, 3], [0, 0, 6]]
+    assert torch.equal(Nd4j.createNpyFromByteArray(Nd4j.toNpyByteArray(a)).tensor(), a.tensor())
+    p = tmp_path / "a.txt"
+    Nd4j.writeTxt(a, p)
+    assert torch.equal(Nd4j.readTxt(p).tensor(), a.tensor())
+    z = Nd4j.scatterUpdate("ADD", Nd4j.create([[0., 0.], [0., 0.], [0., 0.]]), [0, 2], Nd4j.create([[1., 1.], [2., 2.]]), 1)
+    assert z.tensor().tolist() == [[1, 1], [0, 0], [2, 2]]
+    assert torch.allclose(Nd4j.math().tanh(a).tensor(), torch.tanh(a.tensor()))
+    assert torch.allclose(Nd4j.nn().softmax(a).tensor(), torch.softmax(a.tensor(), -1))
+    assert Nd4j.createArrayFromShapeBuffer(torch.arange(6.), a.shapeInfoJava()).tensor().tolist() == [[0, 1, 2], [3, 4, 5]]
+    assert Nd4j.appendBias(Nd4j.create([1., 2.])).tensor().reshape(-1).tolist() == [1, 2, 1]
+    assert Nd4j.choice(a, Nd4j.create([0.5, 0.5, 0, 0, 0, 0]), 16).tensor().max() <= 2
+    assert torch.equal(Nd4j.randWithSeed(5, 2, 2).tensor(), Nd4j.randWithSeed(5, 2, 2).tensor())
+    with pytest.raises(ValueError):
+        Nd4j.checkShapeValues(2, -1)
