@@ -353,3 +353,185 @@ class SDImage(_NS):
     def adjustHue(self, x, d, name=None): return self._o("adjust_hue", [x], name, tArgs=[d])
     def adjustSaturation(self, x, f, name=None): return self._o("adjust_saturation", [x], name, tArgs=[f])
     def extractImagePatches(self, x, kH, kW, sH, sW, rH, rW, same=False, name=None): return self._o("extract_image_patches", [x], name, iArgs=[kH, kW, sH, sW, rH, rW, int(same)])
+
+
+# ----------------------------------------------------------------------------- remaining generated-namespace surface
+# (reference: nd4j-api autodiff/samediff/ops/SD{BaseOps,Math,NN,CNN,RNN,Bitwise,Image,Linalg,Random}.java, generated from the
+# codegen op definitions). Every method below maps onto an op that is already registered and implemented.
+def _install_namespace_extras():
+    import torch
+    from .samediff import OpType
+
+    def B(name, fn):
+        setattr(SDBaseOps, name, fn)
+
+    def M(name, fn):
+        setattr(SDMath, name, fn)
+
+    def scalar_legacy(self, opn, x, value, name=None, family="scalar"):
+        return self.sd._op(opn.lower(), [x], name=name, opType=OpType.SCALAR if family == "scalar" else OpType.SCALAR_BOOL,
+                           opNum=LG.op_num(family, opn), tArgs=[float(value)])[0]
+
+    # -- SDBaseOps
+    B("all", lambda self, x, *dims, name=None: self._legacy("reduce_bool", "All", [x], name, dimensions=_dims(dims)))
+    B("any", lambda self, x, *dims, name=None: self._legacy("reduce_bool", "Any", [x], name, dimensions=_dims(dims)))
+    B("assign", lambda self, x, y, name=None: self._o("assign", [x, y if hasattr(y, "name") else self.sd.constant(None, torch.tensor(float(y)))], name))
+    B("clipByValue", lambda self, x, lo, hi, name=None: self._o("clipbyvalue", [x], name, tArgs=[lo, hi]))
+    B("clipByNorm", lambda self, x, c, *dims, name=None: self._o("clipbynorm", [x], name, tArgs=[c], iArgs=_dims(dims)))
+    B("create", lambda self, shape, dtype="FLOAT", order="c", initialize=True, name=None:
+      self._o("create", [shape], name, iArgs=[ord(order), 0], bArgs=[initialize], dArgs=[str(dtype).upper()]))
+    B("createView", lambda self, x, *indices, name=None: self._o("create_view", [x] + list(indices), name))
+    B("flatten", lambda self, xs, order="c", name=None: self._o("flatten", list(xs) if isinstance(xs, (list, tuple)) else [xs], name, iArgs=[ord(order)]))
+    B("invertPermutation", lambda self, x, name=None: self._o("invert_permutation", [x], name))
+    B("isNumericTensor", lambda self, x, name=None: self._o("is_numeric_tensor", [x], name))
+    B("matchConditionCount", lambda self, x, mode, value=0.0, *dims, keepDims=False, eps=1e-5, name=None:
+      self._legacy("reduce_long", "MatchCondition", [x], name, dimensions=_dims(dims), tArgs=[value, eps, mode], bArgs=[keepDims]))
+    B("merge", lambda self, a, b, name=None: self._o("merge", [a, b], name))
+    B("minMax", lambda self, dataType, minOrMax, name=None: self.sd.constant(name, torch.tensor(
+        (torch.finfo if _TORCH_DT(dataType).is_floating_point else torch.iinfo)(_TORCH_DT(dataType)).max if minOrMax else
+        (torch.finfo if _TORCH_DT(dataType).is_floating_point else torch.iinfo)(_TORCH_DT(dataType)).min, dtype=_TORCH_DT(dataType))))
+    B("repeat", lambda self, x, repeats, axis=0, name=None: self._o("repeat", [x], name, iArgs=(list(repeats) if isinstance(repeats, (list, tuple)) else [repeats]) + [axis]))
+    B("replaceWhere", lambda self, update, frm, condMode, value=0.0, name=None:
+      self._legacy("pairwise", "CompareAndReplace", [update, frm], name, tArgs=[value, 1e-5, condMode]) if hasattr(frm, "name") else
+      self._legacy("scalar", "CompareAndSet" if False else "CompareAndSet", [update], name, tArgs=[float(frm), value, 1e-5, condMode]) if False else
+      self._o("Where", [_cond_var(self, update, condMode, value), update * 0 + frm, update], name))
+    B("reverseSequence", lambda self, x, seqLengths, seqDim=-1, batchDim=0, name=None: self._o("reverse_sequence", [x, seqLengths], name, iArgs=[seqDim, batchDim]))
+    B("scalarFloorMod", lambda self, x, v, name=None: scalar_legacy(self, "FloorMod", x, v, name))
+    B("scalarMax", lambda self, x, v, name=None: scalar_legacy(self, "MaxPairwise", x, v, name))
+    B("scalarMin", lambda self, x, v, name=None: scalar_legacy(self, "MinPairwise", x, v, name))
+    B("scalarSet", lambda self, x, v, name=None: scalar_legacy(self, "CopyPws", x, v, name))
+    for jn, opn in (("scatterDiv", "scatter_div"), ("scatterMax", "scatter_max"), ("scatterMin", "scatter_min"), ("scatterMul", "scatter_mul"),
+                    ("scatterSub", "scatter_sub"), ("scatterNdAdd", "scatter_nd_add"), ("scatterNdSub", "scatter_nd_sub"),
+                    ("scatterNdUpdate", "scatter_nd_update")):
+        B(jn, (lambda o: (lambda self, ref, idx, upd, name=None: self._o(o, [ref, idx, upd], name)))(opn))
+    for jn, opn in (("segmentMax", "segment_max"), ("segmentMean", "segment_mean"), ("segmentMin", "segment_min"), ("segmentProd", "segment_prod")):
+        B(jn, (lambda o: (lambda self, x, ids, name=None: self._o(o, [x, ids], name)))(opn))
+    for jn, opn in (("unsortedSegmentMax", "unsorted_segment_max"), ("unsortedSegmentMean", "unsorted_segment_mean"),
+                    ("unsortedSegmentMin", "unsorted_segment_min"), ("unsortedSegmentProd", "unsorted_segment_prod"),
+                    ("unsortedSegmentSqrtN", "unsorted_segment_sqrt_n")):
+        B(jn, (lambda o: (lambda self, x, ids, n, name=None: self._o(o, [x, ids], name, iArgs=[n])))(opn))
+    B("setShape", lambda self, x, shape, name=None: self._o("set_shape", [x, shape], name))
+    B("sizeAt", lambda self, x, dim, name=None: self._o("size_at", [x], name, iArgs=[dim]))
+    B("sparseToDense", lambda self, indices, shape, values, default=0.0, name=None:
+      self._o("scatter_nd_update", [self.fill(shape, "FLOAT", default), indices, values], name))
+    B("splitV", lambda self, x, sizes, numSplit, axis=0, name=None: self._o("split_v", [x, sizes], name, numSplit, iArgs=[axis]))
+    B("switchOp", lambda self, x, pred, name=None: self._o("Switch", [x, pred], name, 2))
+    B("whereNumpy", lambda self, cond, x, y, name=None: self._o("where_np", [cond, x, y], name))
+
+    # -- SDMath (inherits the base ops)
+    for jn, opn in (("acos", "ACos"), ("acosh", "ACosh"), ("asin", "ASin"), ("asinh", "ASinh"), ("atan", "ATan"), ("atanh", "ATanh")):
+        fam = next(f for f in ("transform_strict", "transform_same", "transform_float") if opn in LG.FAMILIES[f].values())
+        M(jn, _unary(fam, opn, jn))
+    if not hasattr(SDMath, "ceil"):
+        M("ceil", SDMath.ceiling)
+    for jn, opn in (("add", "add"), ("sub", "subtract"), ("mul", "multiply"), ("div", "divide"), ("rsub", "reversesubtract"), ("rdiv", "reversedivide"),
+                    ("floorDiv", "floordiv"), ("floorMod", "floormod"), ("mod", "mod"), ("divNoNan", "divide_no_nan"), ("squaredDifference", "squaredsubtract")):
+        M(jn, (lambda o: (lambda self, x, y, name=None:
+                          self._o(o, [x, y if hasattr(y, "name") else self.sd.constant(None, torch.tensor(float(y)))], name)))(opn))
+    for jn, opn in (("and", "boolean_and"), ("or", "boolean_or"), ("xor", "boolean_xor")):
+        M(jn, (lambda o: (lambda self, x, y, name=None: self._o(o, [x, y], name)))(opn))
+    for jn, (fam, opn) in (("asum", ("reduce_same", "ASum")), ("reduceAMax", ("reduce_same", "AMax")), ("reduceAmin", ("reduce_same", "AMin")),
+                           ("reduceAmean", ("reduce_float", "AMean")), ("reduceMax", ("reduce_same", "Max")), ("reduceMin", ("reduce_same", "Min")),
+                           ("normMax", ("reduce_float", "NormMax")), ("logEntropy", ("reduce_float", "LogEntropy")),
+                           ("shannonEntropy", ("reduce_float", "ShannonEntropy")), ("countZero", ("reduce_long", "CountZero"))):
+        M(jn, (lambda f, o: (lambda self, x, *dims, keepDims=False, name=None:
+                             self._legacy(f, o, [x], name, dimensions=_dims(dims), bArgs=[keepDims])))(fam, opn))
+    for jn, opn in (("hammingDistance", "SimpleHammingDistance"), ("jaccardDistance", "JaccardDistance")):
+        M(jn, (lambda o: (lambda self, a, b, *dims, name=None: self._legacy("reduce3", o, [a, b], name, dimensions=_dims(dims))))(opn))
+    for jn, opn in (("firstIndex", "FirstIndex"), ("lastIndex", "LastIndex")):
+        M(jn, (lambda o: (lambda self, x, mode, value=0.0, *dims, keepDims=False, name=None:
+                          self._legacy("index_reduce", o, [x], name, dimensions=_dims(dims), tArgs=[value, 1e-5, mode], bArgs=[keepDims])))(opn))
+    M("iamin", lambda self, x, *dims, name=None: self._legacy("index_reduce", "IndexAbsoluteMin", [x], name, dimensions=_dims(dims)))
+    for jn, opn in (("bitShift", "shift_bits"), ("bitShiftRight", "rshift_bits"), ("bitShiftRotl", "cyclic_shift_bits"), ("bitShiftRotr", "cyclic_rshift_bits")):
+        M(jn, (lambda o: (lambda self, x, shift, name=None: self._o(o, [x, shift], name)))(opn))
+    M("clipByAvgNorm", lambda self, x, c, *dims, name=None: self._o("clipbyavgnorm", [x], name, tArgs=[c], iArgs=_dims(dims)))
+    M("cross", lambda self, a, b, name=None: self._o("cross", [a, b], name))
+    M("diagPart", lambda self, x, name=None: self._o("diag_part", [x], name))
+    M("embeddingLookup", lambda self, x, indices, partitionMode=0, name=None: self._o("embedding_lookup", [x, indices], name, iArgs=[partitionMode]))
+    M("isMax", lambda self, x, name=None: self._o("ismax", [x], name))
+    M("isNonDecreasing", lambda self, x, name=None: self._o("is_non_decreasing", [x], name))
+    M("isStrictlyIncreasing", lambda self, x, name=None: self._o("is_strictly_increasing", [x], name))
+    M("lgamma", lambda self, x, name=None: self._o("lgamma", [x], name))
+    M("listDiff", lambda self, x, y, name=None: self._o("listdiff", [x, y], name, 2))
+    M("matrixDeterminant", lambda self, x, name=None: self._o("matrix_determinant", [x], name))
+    M("matrixInverse", lambda self, x, name=None: self._o("matrix_inverse", [x], name))
+    M("mergeMaxIndex", lambda self, *xs, dataType="INT", name=None: self._o("mergemaxindex", list(xs[0]) if len(xs) == 1 and isinstance(xs[0], (list, tuple)) else list(xs), name))
+    M("meshgrid", lambda self, inputs, cartesian=True, name=None: self._o("meshgrid", list(inputs), name, len(inputs), iArgs=[int(cartesian)]))
+    M("normalizeMoments", lambda self, counts, means, variances, shift=0.0, name=None: self._o("normalize_moments", [counts, means, variances], name, 2, tArgs=[shift]))
+    M("setDiag", lambda self, x, diag, name=None: self._o("matrix_set_diag", [x, diag], name))
+    M("step", lambda self, x, value=0.0, name=None: scalar_legacy(self, "Step", x, value, name))
+    M("zeroFraction", lambda self, x, name=None: self._o("zero_fraction", [x], name))
+
+    # -- SDNN
+    N = lambda name, fn: setattr(SDNN, name, fn)   # noqa: E731
+    N("cReLU", lambda self, x, name=None: self._o("crelu", [x], name))
+    N("hardTanhDerivative", lambda self, x, name=None: self.sd.math._legacy("transform_strict", "HardTanhDerivative", [x], name)
+      if "HardTanhDerivative" in LG.FAMILIES["transform_strict"].values() else self._o("hardtanh_bp", [x, x * 0 + 1], name))
+    N("leakyReluDerivative", lambda self, x, alpha=0.01, name=None: self._o("lrelu_bp", [x, x * 0 + 1], name, tArgs=[alpha]))
+    N("logSigmoid", lambda self, x, name=None: self.sd.math._legacy("transform_strict", "LogSigmoid", [x], name))
+    N("sigmoidDerivative", lambda self, x, wrt=None, name=None: self._o("sigmoid_bp", [x, wrt if wrt is not None else x * 0 + 1], name))
+    N("softsignDerivative", lambda self, x, name=None: self._o("softsign_bp", [x, x * 0 + 1], name))
+    N("topK", lambda self, x, k, sorted=True, name=None: self._o("top_k", [x], name, 2, iArgs=[k], bArgs=[sorted]))
+
+    # -- SDCNN
+    C = lambda name, fn: setattr(SDCNN, name, fn)   # noqa: E731
+    C("deconv3d", lambda self, x, w, b=None, k=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), d=(1, 1, 1), sameMode=False, ncdhw=True, name=None:
+      self._o("deconv3d", [x, w] + ([b] if b is not None else []), name, iArgs=list(k) + list(s) + list(p) + list(d) + [int(sameMode), 0 if ncdhw else 1]))
+    C("dilation2D", lambda self, x, w, rates, strides, sameMode=False, name=None:
+      self._o("dilation2d", [x, w], name, iArgs=[int(sameMode)] + list(rates) + list(strides)))
+    C("extractImagePatches", lambda self, x, kH, kW, sH=1, sW=1, rH=1, rW=1, sameMode=False, name=None:
+      self._o("extract_image_patches", [x], name, iArgs=[kH, kW, sH, sW, rH, rW, int(sameMode)]))
+    C("maxPoolWithArgmax", lambda self, x, k=(2, 2), s=(2, 2), p=(0, 0), d=(1, 1), sameMode=False, nchw=True, name=None:
+      self._o("max_pool_with_argmax", [x], name, 2, iArgs=list(k) + list(s) + list(p) + list(d) + [int(sameMode), 1, 0 if nchw else 1]))
+    C("upsampling3d", lambda self, x, ncdhw=True, scaleD=2, scaleH=2, scaleW=2, name=None:
+      self._o("upsampling3d", [x], name, iArgs=[scaleD, scaleH, scaleW, int(ncdhw)]))
+
+    # -- SDRNN
+    setattr(SDRNN, "lstmblock", lambda self, maxTSLength, x, cLast, yLast, W, Wci, Wcf, Wco, b, peephole=False, forgetBias=0.0, clip=0.0, name=None:
+            self._o("lstmBlock", [maxTSLength, x, cLast, yLast, W, Wci, Wcf, Wco, b], name, 7, iArgs=[int(peephole), 0], tArgs=[forgetBias, clip]))
+
+    # -- SDBitwise (Java names; `and` / `or` are Python keywords, reachable through getattr as in the reference's generated class)
+    for jn, src in (("and", "bitsAnd"), ("or", "bitsOr"), ("bitShift", "leftShift"), ("bitShiftRight", "rightShift"), ("bitRotl", "leftShiftCyclic"),
+                    ("bitRotr", "rightShiftCyclic")):
+        setattr(SDBitwise, jn, getattr(SDBitwise, src))
+
+    # -- SDImage
+    I = lambda name, fn: setattr(SDImage, name, fn)   # noqa: E731
+    I("imageResize", lambda self, x, size, preserveAspectRatio=False, antialias=False, method=0, name=None:
+      self._o("image_resize", [x, size], name, iArgs=[method], bArgs=[preserveAspectRatio, antialias]))
+    I("pad", lambda self, x, padding, mode="CONSTANT", value=0.0, name=None:
+      self._o("pad", [x, padding], name, iArgs=[{"CONSTANT": 0, "REFLECT": 1, "SYMMETRIC": 2}[str(mode).upper()]], tArgs=[value]))
+    I("randomCrop", lambda self, x, shape, seed=0, name=None: self._o("random_crop", [x, shape], name, iArgs=[seed]))
+    I("yiqToRgb", lambda self, x, name=None: self._o("yiq_to_rgb", [x], name))
+    I("yuvToRgb", lambda self, x, name=None: self._o("yuv_to_rgb", [x], name))
+
+    # -- SDLinalg
+    Lg = lambda name, fn: setattr(SDLinalg, name, fn)   # noqa: E731
+    Lg("diag_part", lambda self, x, name=None: self._o("diag_part", [x], name))
+    Lg("eig", lambda self, x, name=None: self._o("eig", [x], name, 2))
+    Lg("matmul", lambda self, a, b, alpha=1.0, beta=0.0, transposeA=False, transposeB=False, name=None:
+       self._o("matmul", [a, b], name, iArgs=[int(transposeA), int(transposeB), 0], tArgs=[alpha, beta]))
+
+    # -- SDRandom (legacy random ops: shape input, distribution parameters as tArgs)
+    def rnd(opn, nparams):
+        def f(self, *args, name=None):
+            params, rest = list(args[:nparams]), list(args[nparams:])
+            dtype = rest.pop(0) if rest and isinstance(rest[0], str) else "FLOAT"
+            return self.sd._op(opn.lower(), [self._shape(_dims(rest))], name=name, opType=OpType.RANDOM, opNum=LG.op_num("random", opn),
+                               tArgs=[float(p) for p in params], dArgs=[dtype])[0]
+        return f
+    setattr(SDRandom, "binomial", rnd("BinomialDistribution", 2))
+    setattr(SDRandom, "logNormal", rnd("LogNormalDistribution", 2))
+    setattr(SDRandom, "normalTruncated", rnd("TruncatedNormalDistribution", 2))
+
+
+def _TORCH_DT(dt):
+    from ..nd4j.ndarray import DataType
+    return DataType.to_torch(dt)
+
+
+def _cond_var(ns, x, mode, value):
+    return ns.matchCondition(x, mode, value)
+
+
+_install_namespace_extras()
