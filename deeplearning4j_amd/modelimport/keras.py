@@ -338,6 +338,188 @@ class KerasLayerMapper:
         p = _pair(cfg.get("cropping", 1))
         return _Mapped(L.Cropping1D(cropping=p, name=cfg.get("name"))), (s[0] - p[0] - p[1], s[1])
 
+    # -- 3-D convolutional family (KerasConvolution3D / Deconvolution3D / ZeroPadding3D / Cropping3D / Upsampling3D)
+    def _Conv3D(self, cfg, s, cls=None):
+        if cfg.get("data_format", "channels_last") != "channels_last":
+            raise UnsupportedKerasConfigurationException("channels_first Keras models are not supported")
+        cls = cls or L.Convolution3D
+        k, st, d = _pair(cfg["kernel_size"], 3), _pair(cfg.get("strides", 1), 3), _pair(cfg.get("dilation_rate", 1), 3)
+        mode = self._mode(cfg)
+        n = int(cfg["filters"])
+        layer = cls(kernelSize=k, stride=st, dilation=d, convolutionMode=mode, nOut=n, hasBias=cfg.get("use_bias", True),
+                    activation=map_activation(cfg.get("activation")), **self._common(cfg))
+
+        def conv(w, ctx):
+            # keras [kd, kh, kw, in, out] (transpose conv: [kd, kh, kw, out, in]) -> [out, in, kd, kh, kw] ([in, out, ...])
+            out = {"W": np.transpose(w["kernel"], (4, 3, 0, 1, 2))}
+            if "bias" in w:
+                out["b"] = w["bias"]
+            return out
+        if cls is L.Deconvolution3D:
+            dims = tuple(None if s[i] is None else (s[i] * st[i] if mode == ConvolutionMode.Same else (s[i] - 1) * st[i] + k[i]) for i in range(3))
+        else:
+            dims = tuple(self._out_len(s[i], k[i], st[i], mode, d[i]) for i in range(3))
+        return _Mapped(layer, weights=conv), dims + (n,)
+
+    _Convolution3D = _Conv3D
+
+    def _Conv3DTranspose(self, cfg, s):
+        return self._Conv3D(cfg, s, L.Deconvolution3D)
+
+    _Deconvolution3D = _Conv3DTranspose
+
+    @staticmethod
+    def _six(p):
+        if isinstance(p, int):
+            return [p] * 6
+        p = list(p)
+        if p and isinstance(p[0], (list, tuple)):
+            return [int(v) for pair in p for v in pair]
+        return [int(v) for d in p for v in (d, d)]
+
+    def _ZeroPadding3D(self, cfg, s):
+        p = self._six(cfg.get("padding", 1))
+        return _Mapped(L.ZeroPadding3DLayer(padding=tuple(p), name=cfg.get("name"))), (s[0] + p[0] + p[1], s[1] + p[2] + p[3], s[2] + p[4] + p[5], s[3])
+
+    def _Cropping3D(self, cfg, s):
+        p = self._six(cfg.get("cropping", 1))
+        return _Mapped(L.Cropping3D(cropping=tuple(p), name=cfg.get("name"))), (s[0] - p[0] - p[1], s[1] - p[2] - p[3], s[2] - p[4] - p[5], s[3])
+
+    def _UpSampling3D(self, cfg, s):
+        sz = _pair(cfg.get("size", 2), 3)
+        return _Mapped(L.Upsampling3D(size=tuple(sz), name=cfg.get("name"))), (s[0] * sz[0], s[1] * sz[1], s[2] * sz[2], s[3])
+
+    # -- Keras 1 dilated convolutions (KerasAtrousConvolution1D / 2D): the same layers with atrous_rate as the dilation
+    def _AtrousConvolution2D(self, cfg, s):
+        c = dict(cfg)
+        c.setdefault("filters", cfg.get("nb_filter"))
+        c.setdefault("kernel_size", (cfg.get("nb_row", 3), cfg.get("nb_col", 3)))
+        c.setdefault("strides", cfg.get("subsample", 1))
+        c["dilation_rate"] = cfg.get("atrous_rate", cfg.get("dilation_rate", 1))
+        c.setdefault("padding", cfg.get("border_mode", "valid"))
+        return self._Conv2D(c, s)
+
+    def _AtrousConvolution1D(self, cfg, s):
+        c = dict(cfg)
+        c.setdefault("filters", cfg.get("nb_filter"))
+        c.setdefault("kernel_size", cfg.get("filter_length", 3))
+        c.setdefault("strides", cfg.get("subsample_length", 1))
+        c["dilation_rate"] = cfg.get("atrous_rate", cfg.get("dilation_rate", 1))
+        c.setdefault("padding", cfg.get("border_mode", "valid"))
+        return self._Conv1D(c, s)
+
+    def _SpaceToDepth(self, cfg, s):
+        b = int(cfg.get("block_size", 2))
+        return _Mapped(L.SpaceToDepthLayer(blockSize=b, name=cfg.get("name"))), (s[0] // b, s[1] // b, s[2] * b * b)
+
+    # -- locally connected (KerasLocallyConnected1D / 2D): unshared weights per output position
+    def _LocallyConnected2D(self, cfg, s):
+        k, st = _pair(cfg["kernel_size"]), _pair(cfg.get("strides", 1))
+        if cfg.get("padding", "valid") != "valid":
+            raise UnsupportedKerasConfigurationException("LocallyConnected2D supports only 'valid' padding")
+        n = int(cfg["filters"])
+        layer = L.LocallyConnected2D(kernelSize=k, stride=st, convolutionMode=ConvolutionMode.Truncate, nOut=n, hasBias=cfg.get("use_bias", True),
+                                     activation=map_activation(cfg.get("activation")), **self._common(cfg))
+        oh, ow = self._out_len(s[0], k[0], st[0], ConvolutionMode.Truncate), self._out_len(s[1], k[1], st[1], ConvolutionMode.Truncate)
+        cin = s[2]
+
+        def conv(w, ctx):
+            # keras kernel [oh*ow, kh*kw*in, out] with the feature axis ordered (kh, kw, in); DL4J orders it (in, kh, kw)
+            kk = w["kernel"].reshape(oh * ow, k[0], k[1], cin, n)
+            out = {"W": np.transpose(kk, (0, 3, 1, 2, 4)).reshape(oh * ow, cin * k[0] * k[1], n)}
+            if "bias" in w:
+                b = w["bias"]
+                out["b"] = b.reshape(-1, n).mean(0) if b.ndim > 1 and not ctx.get("per_position_bias") else b
+            return out
+        return _Mapped(layer, weights=conv), (oh, ow, n)
+
+    def _LocallyConnected1D(self, cfg, s):
+        k, st = int(_pair(cfg["kernel_size"], 1)[0]), int(_pair(cfg.get("strides", 1), 1)[0])
+        if cfg.get("padding", "valid") != "valid":
+            raise UnsupportedKerasConfigurationException("LocallyConnected1D supports only 'valid' padding")
+        n = int(cfg["filters"])
+        layer = L.LocallyConnected1D(kernelSize=(k,), stride=(st,), convolutionMode=ConvolutionMode.Truncate, nOut=n, hasBias=cfg.get("use_bias", True),
+                                     activation=map_activation(cfg.get("activation")), **self._common(cfg))
+        ot = self._out_len(s[0], k, st, ConvolutionMode.Truncate)
+        cin = s[1]
+
+        def conv(w, ctx):
+            kk = w["kernel"].reshape(ot, k, cin, n)                          # (k, in) -> (in, k)
+            out = {"W": np.transpose(kk, (0, 2, 1, 3)).reshape(ot, cin * k, n)}
+            if "bias" in w:
+                b = w["bias"]
+                out["b"] = b.reshape(-1, n).mean(0) if b.ndim > 1 else b
+            return out
+        return _Mapped(layer, weights=conv), (ot, n)
+
+    # -- custom layers shipped with the reference importer (layers/custom: KerasLRN, KerasPoolHelper)
+    def _LRN(self, cfg, s):
+        layer = L.LocalResponseNormalization(alpha=float(cfg.get("alpha", 1e-4)), beta=float(cfg.get("beta", 0.75)), k=float(cfg.get("k", 2)),
+                                             n=float(cfg.get("n", 5)), name=cfg.get("name"))
+        return _Mapped(layer), s
+
+    _LRN2D = _LRN
+
+    def _PoolHelper(self, cfg, s):
+        """GoogLeNet helper: drops the first row and column of the feature map."""
+        return _Mapped(L.Cropping2D(cropping=(1, 0, 1, 0), name=cfg.get("name"))), (s[0] - 1, s[1] - 1, s[2])
+
+    def _ThresholdedReLU(self, cfg, s):
+        th = float(cfg.get("theta", 1.0))
+        return _Mapped(L.ActivationLayer(activation={"@class": "org.nd4j.linalg.activations.impl.ActivationThresholdedReLU", "theta": th},
+                                         name=cfg.get("name"))), s
+
+    def _Permute(self, cfg, s):
+        """KerasPermute: a permutation of the non-batch axes, executed as a parameter-free lambda layer on the network's own layout
+        (recurrent activations are [batch, features, time] inside the network, Keras sees [time, features])."""
+        dims = tuple(int(d) for d in cfg["dims"])
+        if len(s) == 2 and dims == (2, 1):
+            fn = lambda x: x.transpose(1, 2)                                  # noqa: E731
+            ot = lambda it: InputType.recurrent(it.timeSeriesLength, it.size)  # noqa: E731
+            return _Mapped(L.SameDiffLambdaLayer(fn=fn, outputTypeFn=ot, name=cfg.get("name"))), (s[1], s[0])
+        if dims == tuple(range(1, len(s) + 1)):
+            return _Mapped(passthrough=True), s
+        raise UnsupportedKerasConfigurationException("Permute%s is only supported for 2-D (time, feature) inputs" % (dims,))
+
+    # -- Lambda layers: user-registered callables by layer name (KerasLayer.registerLambdaLayer)
+    _LAMBDAS: Dict[str, object] = {}
+
+    @staticmethod
+    def registerLambdaLayer(name, fn_or_layer, outputShapeFn=None):
+        KerasLayerMapper._LAMBDAS[name] = (fn_or_layer, outputShapeFn)
+
+    @staticmethod
+    def clearLambdaLayers():
+        KerasLayerMapper._LAMBDAS.clear()
+
+    def _Lambda(self, cfg, s):
+        name = cfg.get("name")
+        if name not in self._LAMBDAS:
+            raise UnsupportedKerasConfigurationException(
+                "No SameDiff Lambda layer found for Lambda layer %s. You can register a SameDiff Lambda layer using "
+                "KerasLayerMapper.registerLambdaLayer(lambdaLayerName, sameDiffLambdaLayer)" % name)
+        fn, shape_fn = self._LAMBDAS[name]
+        layer = fn if isinstance(fn, L.Layer) else L.SameDiffLambdaLayer(fn=fn, name=name)
+        return _Mapped(layer), (tuple(shape_fn(s)) if shape_fn else s)
+
+    # -- Keras 1 Merge layer (KerasMerge): mode -> vertex
+    def _Merge(self, cfg, s):
+        mode = str(cfg.get("mode", "sum")).lower()
+        table = {"sum": self._Add, "mul": self._Multiply, "ave": self._Average, "max": self._Maximum, "concat": self._Concatenate}
+        if mode not in table:
+            raise UnsupportedKerasConfigurationException("Keras Merge mode '%s' is not supported" % mode)
+        c = dict(cfg)
+        if mode == "concat":
+            c.setdefault("axis", cfg.get("concat_axis", -1))
+        return table[mode](c, s)
+
+    # -- attention (KerasAttentionLayer -> DotProductAttentionLayer): inputs [query, value(, key)]
+    def _Attention(self, cfg, s):
+        layer = L.DotProductAttentionLayer(scale=1.0 if not cfg.get("use_scale", False) else None, dropoutProbability=float(cfg.get("dropout", 0.0)),
+                                           useCausalMask=bool(cfg.get("causal", False)), name=cfg.get("name")) \
+            if "scale" in getattr(L.DotProductAttentionLayer, "FIELDS", {}) else L.DotProductAttentionLayer(name=cfg.get("name"))
+        return _Mapped(layer), s
+
     # -- normalisation
     def _BatchNormalization(self, cfg, s):
         axis = cfg.get("axis", -1)

@@ -154,3 +154,65 @@ def test_unsupported_and_invalid_configs():
     cfg = _seq_cnn_config()
     with pytest.raises(InvalidKerasConfigurationException):
         KerasModelImport.importKerasSequentialModelAndWeights(cfg, {"conv/kernel": np.zeros((3, 3, 3, 4), np.float32)})   # other layers missing
+
+
+def test_added_layer_mappers_follow_keras_semantics():
+    """Mappers added for parity with the reference importer's layer set (layers/convolutional, local, custom, advanced/activations, core):
+    2-D models with ZeroPadding / LocallyConnected2D / LRN / ThresholdedReLU / SpaceToDepth / PoolHelper checked against a PyTorch
+    restatement of the Keras equations; 3-D family, Keras-1 aliases, Permute, Lambda and Merge checked at the configuration level."""
+    from deeplearning4j_amd.modelimport.keras import KerasLayerMapper
+    rng = np.random.default_rng(3)
+    cfg = {"class_name": "Sequential", "keras_version": "2.4.0", "backend": "tensorflow", "config": {"name": "seq", "layers": [
+        {"class_name": "ZeroPadding2D", "config": {"name": "zp", "batch_input_shape": [None, 6, 6, 2], "padding": [[1, 0], [0, 1]]}},
+        {"class_name": "LocallyConnected2D", "config": {"name": "lc", "filters": 3, "kernel_size": [2, 2], "strides": [1, 1], "padding": "valid",
+                                                        "activation": "linear", "use_bias": False}},
+        {"class_name": "ThresholdedReLU", "config": {"name": "tr", "theta": 0.2}},
+        {"class_name": "SpaceToDepth", "config": {"name": "s2d", "block_size": 2}},
+        {"class_name": "PoolHelper", "config": {"name": "ph"}},
+        {"class_name": "Flatten", "config": {"name": "flat"}},
+        {"class_name": "Dense", "config": {"name": "fc", "units": 4, "activation": "linear", "use_bias": True}}]}}
+    # zp: 7x7x2 -> lc: 6x6x3 -> s2d: 3x3x12 -> ph: 2x2x12 -> 48
+    w = {"lc": {"kernel": rng.normal(0, 0.5, (36, 2 * 2 * 2, 3)).astype(np.float32)},
+         "fc": {"kernel": rng.normal(0, 0.3, (48, 4)).astype(np.float32), "bias": rng.normal(0, 0.1, 4).astype(np.float32)}}
+    net = KerasModelImport.importKerasSequentialModelAndWeights(json.dumps(cfg), w)
+    x = rng.normal(0, 1, (3, 6, 6, 2)).astype(np.float32)
+    got = _t(net.output(torch.from_numpy(x).permute(0, 3, 1, 2).contiguous()))
+    # Keras semantics on NHWC
+    xp = F.pad(torch.from_numpy(x), (0, 0, 0, 1, 1, 0))                                           # pad W right by 1, H top by 1
+    patches = xp.unfold(1, 2, 1).unfold(2, 2, 1)                                                    # [n, 6, 6, c, kh, kw]
+    patches = patches.permute(0, 1, 2, 4, 5, 3).reshape(3, 36, 8)                                   # feature order (kh, kw, c)
+    y = torch.einsum("npf,pfo->npo", patches, torch.from_numpy(w["lc"]["kernel"])).reshape(3, 6, 6, 3)
+    y = torch.where(y > 0.2, y, torch.zeros_like(y))
+    y = y.reshape(3, 3, 2, 3, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(3, 3, 3, 12)                  # tf.nn.space_to_depth, NHWC
+    y = y[:, 1:, 1:, :]
+    ref = y.reshape(3, -1) @ torch.from_numpy(w["fc"]["kernel"]) + torch.from_numpy(w["fc"]["bias"])
+    assert torch.allclose(got, ref, atol=1e-4), (got - ref).abs().max()
+
+    m = KerasLayerMapper()
+    from deeplearning4j_amd.nn.conf import layers as L
+    mp, shp = m.map("Conv3D", {"filters": 4, "kernel_size": 3, "padding": "same", "name": "c3"}, (8, 8, 8, 2))
+    assert isinstance(mp.layer, L.Convolution3D) and shp == (8, 8, 8, 4)
+    k3 = rng.normal(0, 1, (3, 3, 3, 2, 4)).astype(np.float32)
+    assert mp.weights({"kernel": k3}, {})["W"].shape == (4, 2, 3, 3, 3)
+    assert m.map("Conv3DTranspose", {"filters": 4, "kernel_size": 2, "strides": 2, "padding": "valid"}, (4, 4, 4, 2))[1] == (8, 8, 8, 4)
+    assert m.map("ZeroPadding3D", {"padding": [[1, 1], [2, 2], [0, 1]]}, (8, 8, 8, 2))[1] == (10, 12, 9, 2)
+    assert m.map("Cropping3D", {"cropping": 1}, (8, 8, 8, 2))[1] == (6, 6, 6, 2) and m.map("UpSampling3D", {"size": 2}, (4, 4, 4, 2))[1] == (8, 8, 8, 2)
+    a2, s2 = m.map("AtrousConvolution2D", {"nb_filter": 5, "nb_row": 3, "nb_col": 3, "atrous_rate": [2, 2], "border_mode": "same"}, (9, 9, 2))
+    assert tuple(a2.layer.dilation) == (2, 2) and s2 == (9, 9, 5)
+    a1, s1 = m.map("AtrousConvolution1D", {"nb_filter": 5, "filter_length": 3, "atrous_rate": 2, "border_mode": "valid"}, (12, 2))
+    assert s1 == (8, 5)
+    assert isinstance(m.map("LRN", {"alpha": 1e-3, "beta": 0.5, "k": 1, "n": 3}, (4, 4, 8))[0].layer, L.LocalResponseNormalization)
+    assert m.map("LocallyConnected1D", {"filters": 3, "kernel_size": 2}, (7, 2))[1] == (6, 3)
+    pm, ps = m.map("Permute", {"dims": [2, 1], "name": "p"}, (7, 3))
+    assert ps == (3, 7) and pm.layer.fn(torch.zeros(2, 3, 7)).shape == (2, 7, 3)
+    with pytest.raises(UnsupportedKerasConfigurationException):
+        m.map("Lambda", {"name": "lam"}, (4,))
+    KerasLayerMapper.registerLambdaLayer("lam", lambda x: x * 2, lambda s: s)
+    try:
+        lm, ls = m.map("Lambda", {"name": "lam"}, (4,))
+        assert ls == (4,) and float(lm.layer.fn(torch.ones(1))) == 2.0
+    finally:
+        KerasLayerMapper.clearLambdaLayers()
+    assert m.map("Merge", {"mode": "sum", "name": "mg"}, (4,))[0].vertex is not None
+    with pytest.raises(UnsupportedKerasConfigurationException):
+        m.map("Merge", {"mode": "cos"}, (4,))
