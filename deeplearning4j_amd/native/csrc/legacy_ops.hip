@@ -359,6 +359,31 @@ __device__ __forceinline__ bool un_op_f32(int f, float x, float& out) {
     case U_ONEMINUS: out = 1.f - x; return true;
     case U_SIN: out = sinf(x); return true;
     case U_COS: out = cosf(x); return true;
+    case U_SIGN: out = (float)((x > 0.f) - (x < 0.f)); return true;
+    case U_CUBE: out = x * x * x; return true;
+    case U_CEIL: out = ceilf(x); return true;
+    case U_FLOOR: out = floorf(x); return true;
+    case U_ROUND: out = roundf(x); return true;
+    case U_RINT: out = rintf(x); return true;
+    case U_TIMESONEMINUS: out = x * (1.f - x); return true;
+    case U_SOFTPLUS: out = x > 30.f ? x : log1pf(__expf(x)); return true;
+    case U_SOFTSIGN: out = x / (1.f + fabsf(x)); return true;
+    case U_HARDTANH: out = x < -1.f ? -1.f : (x > 1.f ? 1.f : x); return true;
+    case U_HARDSIGMOID: out = fminf(1.f, fmaxf(0.f, 0.2f * x + 0.5f)); return true;
+    case U_SWISH: out = x / (1.f + __expf(-x)); return true;
+    case U_GELU: out = x / (1.f + __expf(-1.702f * x)); return true;
+    case U_PGELU: { const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); out = 0.5f * x * (1.f + tanhf(u)); return true; }
+    case U_SELU: out = x > 0.f ? 1.0507009873554805f * x : 1.0507009873554805f * 1.6732632423543772f * (__expf(x) - 1.f); return true;
+    case U_LOG1P: out = log1pf(x); return true;
+    case U_EXPM1: out = expm1f(x); return true;
+    case U_ERF: out = erff(x); return true;
+    case U_TANHD: { const float t = tanhf(x); out = 1.f - t * t; return true; }
+    case U_SIGMOIDD: { const float sg = 1.f / (1.f + __expf(-x)); out = sg * (1.f - sg); return true; }
+    case U_LOGSIGMOID: out = -(x < -30.f ? -x : log1pf(__expf(-x))); return true;
+    case U_SINH: out = sinhf(x); return true;
+    case U_COSH: out = coshf(x); return true;
+    case U_TAN: out = tanf(x); return true;
+    case U_ATAN: out = atanf(x); return true;
   }
   return false;
 }
@@ -421,6 +446,132 @@ __global__ void transform_kernel(const T* __restrict__ x, Z* __restrict__ z, int
     if (sizeof(A) == 4 && un_op_f32(f, (float)a, fo)) stv<Z, A>(z, oz, (A)fo);
     else stv<Z, A>(z, oz, (A)un_op(f, (double)a, ex.e));
   }
+}
+
+
+// ---- 16-byte vector fast paths ----------------------------------------------------------------------
+// The generic kernels above move one element per thread per iteration (2- or 4-byte accesses) and recompute rank-8 offsets for every
+// element of a broadcast; measured on MI355X that is 0.8-3.8 TB/s where the same math through 16-byte accesses reaches ~5.5 TB/s
+// (profiles/r2_legacy_bandwidth.md). For fp32 / bf16 operands that are dense, 16-byte aligned and either the same shape, a scalar, a
+// row vector (y index = i % mid) or a "one y per 16 bytes" broadcast (column vector, per-channel: y index = (i / inner) % mid with
+// inner a multiple of the vector width) a thread moves whole 16-byte vectors; the functor id stays a (wave-uniform) runtime switch.
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+};
+template <> struct VecIO<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+    const s16x8 t = *reinterpret_cast<const s16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = bf2f((bf16_t)t[i]);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+    s16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (short)f2bf(v[i]);
+    *reinterpret_cast<s16x8*>(p) = t;
+  }
+};
+
+enum { YM_SAME = 0, YM_SCALAR = 1, YM_ONE_PER_VEC = 2, YM_ROW = 3 };
+
+// F >= 0: the functor id is a compile-time constant (the switch folds away: hot functors); F < 0: runtime id `f`
+template <typename T, int F>
+__global__ void __launch_bounds__(256) pairwise_vec_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ z,
+                                                           int64_t nvec, int f_rt, Extra ex, int ymode, float scalar, int64_t inner,
+                                                           int64_t mid) {
+  constexpr int N = VecIO<T>::N;
+  const int f = F >= 0 ? F : f_rt;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    const int64_t i0 = v * N;
+    float a[N], b[N], r[N];
+    VecIO<T>::ld(x + i0, a);
+    if (ymode == YM_SAME) VecIO<T>::ld(y + i0, b);
+    else if (ymode == YM_ROW) VecIO<T>::ld(y + (i0 % mid), b);
+    else {
+      const float yv = ymode == YM_SCALAR ? scalar : (float)ldv<T>(y, (i0 / inner) % mid);
+#pragma unroll
+      for (int k = 0; k < N; ++k) b[k] = yv;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = bin_op<float>(f, a[k], b[k], ex.e);
+    VecIO<T>::st(z + i0, r);
+  }
+}
+
+template <typename T, int F>
+__global__ void __launch_bounds__(256) transform_vec_kernel(const T* __restrict__ x, T* __restrict__ z, int64_t nvec, int f_rt, Extra ex) {
+  constexpr int N = VecIO<T>::N;
+  const int f = F >= 0 ? F : f_rt;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    float a[N], r[N];
+    VecIO<T>::ld(x + v * N, a);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (!un_op_f32(f, a[k], r[k])) r[k] = (float)un_op(f, (double)a[k], ex.e);
+    VecIO<T>::st(z + v * N, r);
+  }
+}
+
+#define HOT_BIN(X) X(B_ADD) X(B_SUB) X(B_MUL) X(B_DIV) X(B_RSUB) X(B_RDIV) X(B_COPY) X(B_MAX) X(B_MIN) X(B_SQSUB) X(B_RELU) X(B_LRELU)
+#define HOT_UN(X) X(U_ABS) X(U_NEG) X(U_SQUARE) X(U_SQRT) X(U_RSQRT) X(U_EXP) X(U_LOG) X(U_TANH) X(U_SIGMOID) X(U_IDENTITY) X(U_COPY) \
+  X(U_RECIPROCAL) X(U_ONEMINUS) X(U_SIGN) X(U_CUBE) X(U_FLOOR) X(U_CEIL) X(U_SOFTPLUS) X(U_SWISH) X(U_GELU) X(U_PGELU) X(U_HARDTANH) \
+  X(U_HARDSIGMOID) X(U_SOFTSIGN) X(U_TANHD) X(U_SIGMOIDD) X(U_SIN) X(U_COS) X(U_ERF) X(U_SELU)
+
+template <typename T>
+static void launch_pairwise_vec(int g, hipStream_t st, const T* x, const T* y, T* z, int64_t nvec, int f, const Extra& ex, int ymode,
+                                float scalar, int64_t inner, int64_t mid) {
+  switch (f) {
+#define X(ID) case ID: pairwise_vec_kernel<T, ID><<<g, 256, 0, st>>>(x, y, z, nvec, f, ex, ymode, scalar, inner, mid); return;
+    HOT_BIN(X)
+#undef X
+    default: pairwise_vec_kernel<T, -1><<<g, 256, 0, st>>>(x, y, z, nvec, f, ex, ymode, scalar, inner, mid);
+  }
+}
+
+template <typename T>
+static void launch_transform_vec(int g, hipStream_t st, const T* x, T* z, int64_t nvec, int f, const Extra& ex) {
+  switch (f) {
+#define X(ID) case ID: transform_vec_kernel<T, ID><<<g, 256, 0, st>>>(x, z, nvec, f, ex); return;
+    HOT_UN(X)
+#undef X
+    default: transform_vec_kernel<T, -1><<<g, 256, 0, st>>>(x, z, nvec, f, ex);
+  }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Classifies y's addressing for the vector kernel: returns the ymode or -1 (use the generic kernel).
+static int classify_y(const Strides3& s, int vecn, int64_t& inner, int64_t& mid) {
+  inner = 1; mid = 1;
+  // x and z must be dense in the (coalesced) iteration order
+  int64_t dense = 1;
+  for (int d = s.rank - 1; d >= 0; --d) {
+    if (s.shape[d] != 1 && (s.sx[d] != dense || s.sz[d] != dense)) return -1;
+    dense *= s.shape[d];
+  }
+  // y: a run of dims with dense strides ("mid"), zero strides outside it
+  int lo = -1, hi = -1;
+  for (int d = 0; d < s.rank; ++d)
+    if (s.shape[d] != 1 && s.sy[d] != 0) { if (lo < 0) lo = d; hi = d; }
+  if (lo < 0) return -1;
+  int64_t yd = 1;
+  for (int d = hi; d >= lo; --d) {
+    if (s.shape[d] != 1 && s.sy[d] != yd) return -1;
+    yd *= s.shape[d];
+  }
+  mid = yd;
+  for (int d = s.rank - 1; d > hi; --d) inner *= s.shape[d];
+  if (inner == 1) return (mid % vecn == 0) ? YM_ROW : -1;
+  return (inner % vecn == 0) ? YM_ONE_PER_VEC : -1;
 }
 
 // ---- reductions -----------------------------------------------------------------------------------
@@ -551,14 +702,91 @@ __global__ __launch_bounds__(256) void reduce_kernel(const T* __restrict__ x, Z*
   }
 }
 
+// one wave per TAD: lanes stride over the TAD's partial accumulators (contiguous: coalesced), wave_merge, lane 0 writes the result
 template <typename Z>
-__global__ void reduce_finish_kernel(const double* __restrict__ partial, Z* __restrict__ z, int64_t num_tads, int segs,
-                                     int64_t tad_len, int f, Extra ex) {
+__global__ void __launch_bounds__(256) reduce_finish_kernel(const double* __restrict__ partial, Z* __restrict__ z, int64_t num_tads, int segs,
+                                                            int64_t tad_len, int f, Extra ex) {
   const int kind = red_kind(f);
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < num_tads; t += (int64_t)gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < num_tads; t += (int64_t)gridDim.x * 4) {
     double acc = red_init(kind);
-    for (int s = 0; s < segs; ++s) acc = red_merge(kind, acc, partial[t * segs + s]);
-    stv<Z, double>(z, t, red_post(f, acc, (double)tad_len, ex.e));
+    for (int s = lane; s < segs; s += 64) acc = red_merge(kind, acc, partial[t * segs + s]);
+    acc = wave_merge(kind, acc);
+    if (lane == 0) stv<Z, double>(z, t, red_post(f, acc, (double)tad_len, ex.e));
+  }
+}
+
+// Dense-TAD variant of reduce_kernel for fp32 / bf16: the reduced elements of a TAD are contiguous and every TAD starts on a 16-byte
+// boundary, so a lane moves 16-byte vectors (same grouping / segment scheme, same double accumulators).
+template <typename T, typename Z, int F>
+__global__ __launch_bounds__(256) void reduce_vec_kernel(const T* __restrict__ x, Z* __restrict__ z, double* __restrict__ partial,
+                                                         TadDesc d, int f_rt, Extra ex, int group, int segs) {
+  constexpr int N = VecIO<T>::N;
+  __shared__ double red[4];
+  const int f = F >= 0 ? F : f_rt;
+  const int kind = red_kind(f);
+  const int groups_per_block = 256 / group;
+  const int g_in_block = threadIdx.x / group, lane = threadIdx.x % group;
+  const int64_t total_groups = d.num_tads * segs;
+  const int64_t nvec = d.tad_len / N;
+  for (int64_t g = (int64_t)blockIdx.x * groups_per_block + g_in_block; g < total_groups;
+       g += (int64_t)gridDim.x * groups_per_block) {
+    double acc = red_init(kind);
+    const int64_t t = g / segs, sidx = g % segs;
+    const int64_t seg_len = (nvec + segs - 1) / segs;
+    const int64_t j0 = sidx * seg_len, j1 = (j0 + seg_len < nvec) ? j0 + seg_len : nvec;
+    const T* base = x + tad_base(d.oshape, d.ostride, d.orank, t);
+    for (int64_t j = j0 + lane; j < j1; j += group) {
+      float v[N];
+      VecIO<T>::ld(base + j * N, v);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc = red_merge(kind, acc, red_pre(f, (double)v[k], ex.e));
+    }
+    acc = wave_merge(kind, acc);
+    if (group == 256) {
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+      __syncthreads();
+      acc = red_merge(kind, red_merge(kind, red[0], red[1]), red_merge(kind, red[2], red[3]));
+    }
+    if (lane == 0) {
+      if (segs > 1) partial[g] = acc;
+      else stv<Z, double>(z, t, red_post(f, acc, (double)d.tad_len, ex.e));
+    }
+  }
+}
+
+// Column reduction (the reduced dimension is the SLOW one: x viewed as [rows][cols], one result per column). A block owns 64 * CPT
+// consecutive columns and a slab of rows; lanes run along the columns so every row is read with coalesced accesses, 4 row lanes per
+// block, partial[col * segs + slab] -> reduce_finish_kernel. (One block per TAD would read a 2- or 4-byte element per 16 KB stride.)
+template <typename T, int CPT, int F>
+__global__ __launch_bounds__(256) void reduce_col_kernel(const T* __restrict__ x, double* __restrict__ partial, int64_t rows,
+                                                         int64_t cols, int64_t pitch, int f_rt, Extra ex, int segs, int64_t rows_per_seg) {
+  __shared__ double red[4][64 * CPT];
+  const int f = F >= 0 ? F : f_rt;
+  const int kind = red_kind(f);
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t c0 = ((int64_t)blockIdx.x * 64 + cl) * CPT;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_seg;
+  const int64_t r1 = r0 + rows_per_seg < rows ? r0 + rows_per_seg : rows;
+  double acc[CPT];
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) acc[k] = red_init(kind);
+  if (c0 < cols) {
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const T* p = x + r * pitch + c0;
+#pragma unroll
+      for (int k = 0; k < CPT; ++k)
+        if (c0 + k < cols) acc[k] = red_merge(kind, acc[k], red_pre(f, (double)ldv<T>(p, k), ex.e));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) red[rl][cl * CPT + k] = acc[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 64 * CPT; c += 256) {
+    const int64_t col = (int64_t)blockIdx.x * 64 * CPT + c;
+    if (col < cols)
+      partial[col * segs + blockIdx.y] = red_merge(kind, red_merge(kind, red[0][c], red[1][c]), red_merge(kind, red[2][c], red[3][c]));
   }
 }
 
@@ -589,32 +817,59 @@ __device__ __forceinline__ Tri tri_shfl(Tri v, int o) {
   return Tri{__shfl_xor(v.a, o, 64), __shfl_xor(v.b, o, 64), __shfl_xor(v.c, o, 64)};
 }
 
-template <typename T, typename Z>
+__device__ __forceinline__ Tri tri_pre(int f, double a, double b, int64_t j, const Extra& ex) {
+  switch (f) {
+    case R3_MANHATTAN: return Tri{fabs(a - b), 0, 0};
+    case R3_EUCLID: return Tri{(a - b) * (a - b), 0, 0};
+    case R3_COSSIM: case R3_COSDIST: return Tri{a * b, a * a, b * b};
+    case R3_DOT: return Tri{a * b, 0, 0};
+    case R3_EQEPS: return Tri{fabs(a - b) > (ex.e[0] > 0 ? ex.e[0] : 1e-5) ? 1.0 : 0.0, 0, 0};
+    case R3_JACCARD: return Tri{fmin(a, b), fmax(a, b), 0};
+    case R3_HAMMING: return Tri{a != b ? 1.0 : 0.0, 0, 0};
+    case RS_VAR: case RS_STD: return Tri{1.0, a, 0.0};
+    case RI_MAX: case RI_MIN: return Tri{a, (double)j, 0};
+    case RI_AMAX: case RI_AMIN: return Tri{fabs(a), (double)j, 0};
+    default: return Tri{a, match_cond<double>(a, ex.e[0], ex.e[1], (int)ex.e[2]) ? (double)j : -1.0, 0};   // FIRST / LAST
+  }
+}
+__device__ __forceinline__ Tri tri_init(int f) { return (f >= RI_MAX) ? Tri{0.0, -1.0, 0.0} : Tri{0.0, 0.0, 0.0}; }
+__device__ __forceinline__ double tri_post(int f, Tri acc, double tad_len, const Extra& ex) {
+  switch (f) {
+    case R3_EUCLID: return sqrt(acc.a);
+    case R3_COSSIM: return acc.a / (sqrt(acc.b) * sqrt(acc.c));
+    case R3_COSDIST: return 1.0 - acc.a / (sqrt(acc.b) * sqrt(acc.c));
+    case R3_JACCARD: return acc.b != 0.0 ? 1.0 - acc.a / acc.b : 0.0;
+    case R3_HAMMING: return acc.a / tad_len;
+    case RS_VAR: case RS_STD: {
+      double den = ex.e[0] != 0.0 ? acc.a - 1.0 : acc.a;     // e[0] = biasCorrected
+      double var = den > 0.0 ? acc.c / den : 0.0;
+      return f == RS_STD ? sqrt(var) : var;
+    }
+    case RI_MAX: case RI_MIN: case RI_AMAX: case RI_AMIN: case RI_FIRST: case RI_LAST: return acc.b;
+    default: return acc.a;
+  }
+}
+
+// reduce3 / summarystats / indexreduce: a 256-thread block per (TAD, segment) with three running values. segs > 1 (few, long TADs —
+// a full reduction of a large array used to run in ONE block) writes Tri partials that reduce_tri_finish_kernel merges; tri_merge is
+// associative for every family (sums, Chan's variance merge, value/index pairs with index tie-breaks).
+template <typename T, typename Z, int F>
 __global__ __launch_bounds__(256) void reduce_tri_kernel(const T* __restrict__ x, const T* __restrict__ y, Z* __restrict__ z,
-                                                         TadDesc d, int f, Extra ex) {
+                                                         TadDesc d, int f_rt, Extra ex, int segs, double* __restrict__ partial) {
   __shared__ Tri red[4];
-  for (int64_t t = blockIdx.x; t < d.num_tads; t += gridDim.x) {
+  const int f = F >= 0 ? F : f_rt;
+  const int64_t total = d.num_tads * segs;
+  const int64_t seg_len = (d.tad_len + segs - 1) / segs;
+  for (int64_t g = blockIdx.x; g < total; g += gridDim.x) {
+    const int64_t t = g / segs, sidx = g - t * segs;
+    const int64_t j0 = sidx * seg_len, j1 = (j0 + seg_len < d.tad_len) ? j0 + seg_len : d.tad_len;
     const int64_t bx = tad_base(d.oshape, d.ostride, d.orank, t);
     const int64_t by = y ? tad_base(d.oshape, d.oystride, d.orank, t) : 0;
-    Tri acc = (f >= RI_MAX) ? Tri{0.0, -1.0, 0.0} : Tri{0.0, 0.0, 0.0};
-    for (int64_t j = threadIdx.x; j < d.tad_len; j += 256) {
+    Tri acc = tri_init(f);
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
       double a = (double)ldv<T>(x, bx + inner_off(d.ishape, d.istride, d.irank, j));
       double b = y ? (double)ldv<T>(y, by + inner_off(d.ishape, d.iystride, d.irank, j)) : 0.0;
-      Tri v;
-      switch (f) {
-        case R3_MANHATTAN: v = Tri{fabs(a - b), 0, 0}; break;
-        case R3_EUCLID: v = Tri{(a - b) * (a - b), 0, 0}; break;
-        case R3_COSSIM: case R3_COSDIST: v = Tri{a * b, a * a, b * b}; break;
-        case R3_DOT: v = Tri{a * b, 0, 0}; break;
-        case R3_EQEPS: v = Tri{fabs(a - b) > (ex.e[0] > 0 ? ex.e[0] : 1e-5) ? 1.0 : 0.0, 0, 0}; break;
-        case R3_JACCARD: v = Tri{fmin(a, b), fmax(a, b), 0}; break;
-        case R3_HAMMING: v = Tri{a != b ? 1.0 : 0.0, 0, 0}; break;
-        case RS_VAR: case RS_STD: v = Tri{1.0, a, 0.0}; break;
-        case RI_MAX: case RI_MIN: v = Tri{a, (double)j, 0}; break;
-        case RI_AMAX: case RI_AMIN: v = Tri{fabs(a), (double)j, 0}; break;
-        default: v = Tri{a, match_cond<double>(a, ex.e[0], ex.e[1], (int)ex.e[2]) ? (double)j : -1.0, 0}; break;   // FIRST/LAST
-      }
-      acc = tri_merge(f, acc, v);
+      acc = tri_merge(f, acc, tri_pre(f, a, b, j, ex));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc = tri_merge(f, acc, tri_shfl(acc, o));
@@ -623,23 +878,29 @@ __global__ __launch_bounds__(256) void reduce_tri_kernel(const T* __restrict__ x
     __syncthreads();
     if (threadIdx.x == 0) {
       acc = tri_merge(f, tri_merge(f, red[0], red[1]), tri_merge(f, red[2], red[3]));
-      double r;
-      switch (f) {
-        case R3_EUCLID: r = sqrt(acc.a); break;
-        case R3_COSSIM: r = acc.a / (sqrt(acc.b) * sqrt(acc.c)); break;
-        case R3_COSDIST: r = 1.0 - acc.a / (sqrt(acc.b) * sqrt(acc.c)); break;
-        case R3_JACCARD: r = acc.b != 0.0 ? 1.0 - acc.a / acc.b : 0.0; break;
-        case R3_HAMMING: r = acc.a / (double)d.tad_len; break;
-        case RS_VAR: case RS_STD: {
-          double den = ex.e[0] != 0.0 ? acc.a - 1.0 : acc.a;     // e[0] = biasCorrected
-          double var = den > 0.0 ? acc.c / den : 0.0;
-          r = f == RS_STD ? sqrt(var) : var;
-        } break;
-        case RI_MAX: case RI_MIN: case RI_AMAX: case RI_AMIN: case RI_FIRST: case RI_LAST: r = acc.b; break;
-        default: r = acc.a;
+      if (segs > 1) {
+        partial[g * 3 + 0] = acc.a; partial[g * 3 + 1] = acc.b; partial[g * 3 + 2] = acc.c;
+      } else {
+        stv<Z, double>(z, t, tri_post(f, acc, (double)d.tad_len, ex));
       }
-      stv<Z, double>(z, t, r);
     }
+  }
+}
+
+// one wave per TAD (see reduce_finish_kernel)
+template <typename Z>
+__global__ void __launch_bounds__(256) reduce_tri_finish_kernel(const double* __restrict__ partial, Z* __restrict__ z, int64_t num_tads,
+                                                                int segs, int64_t tad_len, int f, Extra ex) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < num_tads; t += (int64_t)gridDim.x * 4) {
+    Tri acc = tri_init(f);
+    for (int s = lane; s < segs; s += 64) {
+      const double* p = partial + (t * segs + s) * 3;
+      acc = tri_merge(f, acc, Tri{p[0], p[1], p[2]});
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc = tri_merge(f, acc, tri_shfl(acc, o));
+    if (lane == 0) stv<Z, double>(z, t, tri_post(f, acc, (double)tad_len, ex));
   }
 }
 
@@ -659,6 +920,25 @@ DL4J_API int dl4j_legacy_pairwise(int f, const void* x, const void* y, void* z, 
                                   int use_scalar, double scalar, int dtype, int zbool, hipStream_t st) {
   if (n <= 0) return 0;
   Extra ex{{extra ? extra[0] : 0, extra ? extra[1] : 0, extra ? extra[2] : 0, extra ? extra[3] : 0}};
+  if (!zbool && (dtype == 0 || dtype == 1) && aligned16(x) && aligned16(z) && (use_scalar || aligned16(y))) {
+    const int vecn = dtype == 0 ? 4 : 8;
+    int64_t inner = 1, mid = 1;
+    int ymode = -1;
+    if (n % vecn == 0) {
+      if (use_scalar) ymode = s->contiguous ? YM_SCALAR : -1;
+      else if (s->contiguous) ymode = YM_SAME;
+      else ymode = classify_y(*s, vecn, inner, mid);
+    }
+    if (ymode >= 0) {
+      const int64_t nvec = n / vecn;
+      const int gv = launch_grid(LS_PAIRWISE, grid_for(nvec, 256 * 2));
+      if (dtype == 0)
+        launch_pairwise_vec<float>(gv, st, (const float*)x, (const float*)y, (float*)z, nvec, f, ex, ymode, (float)scalar, inner, mid);
+      else
+        launch_pairwise_vec<bf16_t>(gv, st, (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)z, nvec, f, ex, ymode, (float)scalar, inner, mid);
+      DL4J_RET_LAST();
+    }
+  }
   const int blk = launch_block(LS_PAIRWISE, 256);
   int g = launch_grid(LS_PAIRWISE, grid_for(n, blk * 4));
   if (zbool) {
@@ -673,6 +953,13 @@ DL4J_API int dl4j_legacy_transform(int f, const void* x, void* z, int64_t n, con
                                    int zbool, hipStream_t st) {
   if (n <= 0) return 0;
   Extra ex{{extra ? extra[0] : 0, extra ? extra[1] : 0, extra ? extra[2] : 0, extra ? extra[3] : 0}};
+  if (!zbool && (dtype == 0 || dtype == 1) && s->contiguous && aligned16(x) && aligned16(z) && n % (dtype == 0 ? 4 : 8) == 0) {
+    const int64_t nvec = n / (dtype == 0 ? 4 : 8);
+    const int gv = launch_grid(LS_TRANSFORM, grid_for(nvec, 256 * 2));
+    if (dtype == 0) launch_transform_vec<float>(gv, st, (const float*)x, (float*)z, nvec, f, ex);
+    else launch_transform_vec<bf16_t>(gv, st, (const bf16_t*)x, (bf16_t*)z, nvec, f, ex);
+    DL4J_RET_LAST();
+  }
   const int blk = launch_block(LS_TRANSFORM, 256);
   int g = launch_grid(LS_TRANSFORM, grid_for(n, blk * 4));
   if (zbool) {
@@ -684,24 +971,91 @@ DL4J_API int dl4j_legacy_transform(int f, const void* x, void* z, int64_t n, con
 }
 
 DL4J_API int64_t dl4j_legacy_reduce_segs(int64_t num_tads, int64_t tad_len) {
-  if (num_tads >= 512 || tad_len < (1 << 16)) return 1;
-  int64_t want = 1024 / num_tads;
-  int64_t maxs = tad_len / (1 << 13);
+  // few, long TADs: split each into segments so that ~8k blocks (32 per CU: enough waves in flight to hide HBM latency behind
+  // 16-byte loads) share the work; measured: a 64M-element full reduction went from 1.9 to >4 TB/s moving from 1k to 8k segments
+  if (num_tads >= 2048 || tad_len < (1 << 15)) return 1;
+  int64_t want = 8192 / num_tads;
+  int64_t maxs = tad_len / (1 << 12);
   int64_t s = want < maxs ? want : maxs;
   return s < 1 ? 1 : s;
 }
 
+#define HOT_RED(X) X(R_SUM) X(R_MEAN) X(R_MAX) X(R_MIN) X(R_NORM2) X(R_NORM1) X(R_SQNORM) X(R_ASUM) X(R_AMAX) X(R_PROD)
+
+template <typename T> struct HasVec { static constexpr bool value = false; };
+template <> struct HasVec<float> { static constexpr bool value = true; };
+template <> struct HasVec<bf16_t> { static constexpr bool value = true; };
+
+// rows-per-slab choice of the column reduction: enough (column block, slab) pairs to fill the chip, slabs of at least 64 rows
+static int col_segs(int64_t rows, int64_t col_blocks) {
+  int64_t want = (4 * DL4J_NUM_CU + col_blocks - 1) / col_blocks;
+  const int64_t maxs = (rows + 63) / 64;
+  if (want > maxs) want = maxs;
+  if (want > 256) want = 256;
+  return (int)(want < 1 ? 1 : want);
+}
+
+static bool col_path(const TadDesc& d) {
+  return d.irank == 1 && d.orank == 1 && d.ostride[0] == 1 && d.istride[0] >= d.num_tads && d.tad_len >= 8 && d.num_tads >= 64;
+}
+
+// number of double accumulators dl4j_legacy_reduce needs in `partial` for this descriptor (0: none)
+DL4J_API int64_t dl4j_legacy_reduce_partial_len(const TadDesc* d, int elem_size) {
+  if (col_path(*d)) {
+    const int cpt = elem_size == 2 ? 2 : 1;
+    const int64_t col_blocks = (d->num_tads + 64 * cpt - 1) / (64 * cpt);
+    return d->num_tads * col_segs(d->tad_len, col_blocks);
+  }
+  const int64_t segs = dl4j_legacy_reduce_segs(d->num_tads, d->tad_len);
+  return segs > 1 ? d->num_tads * segs : 0;
+}
+
 template <typename T, typename Z>
 static int run_reduce(const void* x, void* z, double* partial, const TadDesc& d, int f, const Extra& ex, hipStream_t st) {
+  // column reduction: reduced dim strided, kept dim dense
+  if (partial && col_path(d)) {
+    constexpr int CPT = sizeof(T) == 2 ? 2 : 1;
+    const int64_t col_blocks = (d.num_tads + 64 * CPT - 1) / (64 * CPT);
+    const int segs = col_segs(d.tad_len, col_blocks);
+    const int64_t rps = (((d.tad_len + segs - 1) / segs) + 3) / 4 * 4;
+    const int gy = (int)((d.tad_len + rps - 1) / rps);
+    if (col_blocks <= 65535 * 16) {
+      const dim3 cg((unsigned)col_blocks, (unsigned)gy);
+      switch (f) {
+#define X(ID) case ID: reduce_col_kernel<T, CPT, ID><<<cg, 256, 0, st>>>((const T*)x, partial, d.tad_len, d.num_tads, d.istride[0], f, ex, gy, rps); break;
+        HOT_RED(X)
+#undef X
+        default: reduce_col_kernel<T, CPT, -1><<<cg, 256, 0, st>>>((const T*)x, partial, d.tad_len, d.num_tads, d.istride[0], f, ex, gy, rps);
+      }
+      reduce_finish_kernel<Z><<<grid_for((d.num_tads + 3) / 4, 1), 256, 0, st>>>(partial, (Z*)z, d.num_tads, gy, d.tad_len, f, ex);
+      return (int)hipGetLastError();
+    }
+  }
   int64_t segs = dl4j_legacy_reduce_segs(d.num_tads, d.tad_len);
   if (segs > 1 && !partial) segs = 1;
   int group = d.tad_len <= 512 ? 64 : 256;
   int64_t groups = d.num_tads * segs;
   int per_block = 256 / group;
   int g = grid_for((groups + per_block - 1) / per_block, 1);
-  reduce_kernel<T, Z><<<g, 256, 0, st>>>((const T*)x, (Z*)z, partial, d, f, ex, group, (int)segs);
+  bool vec = false;
+  if constexpr (HasVec<T>::value) {
+    constexpr int N = VecIO<T>::N;
+    vec = d.irank == 1 && d.istride[0] == 1 && d.tad_len % N == 0 && d.tad_len >= 4 * N * group && aligned16(x);
+    for (int k = 0; vec && k < d.orank; ++k) vec = d.ostride[k] % N == 0;
+    if (vec && groups % per_block == 0 && (int64_t)g * per_block <= groups) {
+      switch (f) {
+#define X(ID) case ID: reduce_vec_kernel<T, Z, ID><<<g, 256, 0, st>>>((const T*)x, (Z*)z, partial, d, f, ex, group, (int)segs); break;
+        HOT_RED(X)
+#undef X
+        default: reduce_vec_kernel<T, Z, -1><<<g, 256, 0, st>>>((const T*)x, (Z*)z, partial, d, f, ex, group, (int)segs);
+      }
+    } else {
+      vec = false;
+    }
+  }
+  if (!vec) reduce_kernel<T, Z><<<g, 256, 0, st>>>((const T*)x, (Z*)z, partial, d, f, ex, group, (int)segs);
   if (segs > 1)
-    reduce_finish_kernel<Z><<<grid_for(d.num_tads, 256), 256, 0, st>>>(partial, (Z*)z, d.num_tads, (int)segs, d.tad_len, f, ex);
+    reduce_finish_kernel<Z><<<grid_for((d.num_tads + 3) / 4, 1), 256, 0, st>>>(partial, (Z*)z, d.num_tads, (int)segs, d.tad_len, f, ex);
   return (int)hipGetLastError();
 }
 
@@ -720,17 +1074,37 @@ DL4J_API int dl4j_legacy_reduce(int f, const void* x, void* z, double* partial, 
   return 1;
 }
 
-DL4J_API int dl4j_legacy_reduce_tri(int f, const void* x, const void* y, void* z, const TadDesc* d, const double* extra, int dtype,
-                                    int zkind, hipStream_t st) {
+template <typename T, typename Z>
+static int run_tri(const void* x, const void* y, void* z, double* partial, const TadDesc& d, int f, const Extra& ex, hipStream_t st) {
+  int64_t segs = partial ? dl4j_legacy_reduce_segs(d.num_tads, d.tad_len) : 1;
+  if (segs < 1) segs = 1;
+  const int g = grid_for(d.num_tads * segs, 1);
+  switch (f) {
+#define X(ID) case ID: reduce_tri_kernel<T, Z, ID><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (Z*)z, d, f, ex, (int)segs, partial); break;
+    X(R3_COSSIM) X(R3_DOT) X(R3_EUCLID) X(R3_MANHATTAN) X(RS_VAR) X(RS_STD) X(RI_MAX) X(RI_MIN)
+#undef X
+    default: reduce_tri_kernel<T, Z, -1><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (Z*)z, d, f, ex, (int)segs, partial);
+  }
+  if (segs > 1)
+    reduce_tri_finish_kernel<Z><<<grid_for((d.num_tads + 3) / 4, 1), 256, 0, st>>>(partial, (Z*)z, d.num_tads, (int)segs, d.tad_len, f, ex);
+  return (int)hipGetLastError();
+}
+
+// partial: >= 3 * num_tads * dl4j_legacy_reduce_segs(num_tads, tad_len) doubles, or null (one block per TAD)
+DL4J_API int dl4j_legacy_reduce_tri_p(int f, const void* x, const void* y, void* z, double* partial, const TadDesc* d,
+                                      const double* extra, int dtype, int zkind, hipStream_t st) {
   if (d->num_tads <= 0) return 0;
   Extra ex{{extra ? extra[0] : 0, extra ? extra[1] : 0, extra ? extra[2] : 0, extra ? extra[3] : 0}};
-  int g = grid_for(d->num_tads, 1);
   switch (zkind) {
-    case 0: DISPATCH_T(dtype, (reduce_tri_kernel<T, T><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (T*)z, *d, f, ex))) break;
-    case 2: DISPATCH_T(dtype, (reduce_tri_kernel<T, int64_t><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (int64_t*)z, *d, f, ex))) break;
-    case 3: DISPATCH_T(dtype, (reduce_tri_kernel<T, float><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (float*)z, *d, f, ex))) break;
-    case 4: DISPATCH_T(dtype, (reduce_tri_kernel<T, double><<<g, 256, 0, st>>>((const T*)x, (const T*)y, (double*)z, *d, f, ex))) break;
-    default: return 1;
+    case 0: DISPATCH_T(dtype, return (run_tri<T, T>(x, y, z, partial, *d, f, ex, st))) break;
+    case 2: DISPATCH_T(dtype, return (run_tri<T, int64_t>(x, y, z, partial, *d, f, ex, st))) break;
+    case 3: DISPATCH_T(dtype, return (run_tri<T, float>(x, y, z, partial, *d, f, ex, st))) break;
+    case 4: DISPATCH_T(dtype, return (run_tri<T, double>(x, y, z, partial, *d, f, ex, st))) break;
   }
-  DL4J_RET_LAST();
+  return 1;
+}
+
+DL4J_API int dl4j_legacy_reduce_tri(int f, const void* x, const void* y, void* z, const TadDesc* d, const double* extra, int dtype,
+                                    int zkind, hipStream_t st) {
+  return dl4j_legacy_reduce_tri_p(f, x, y, z, nullptr, d, extra, dtype, zkind, st);
 }

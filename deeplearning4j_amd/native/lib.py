@@ -37,7 +37,7 @@ def hip():
     if _HIP is None:
         try:
             _HIP = _load(HERE / "libdl4j_hip.so")
-            for _n in ("dl4j_bn_ws_floats", "dl4j_threshold_ws_ints", "dl4j_legacy_reduce_segs"):
+            for _n in ("dl4j_bn_ws_floats", "dl4j_threshold_ws_ints", "dl4j_legacy_reduce_segs", "dl4j_legacy_reduce_partial_len"):
                 getattr(_HIP, _n).restype = ctypes.c_int64
         except Exception as e:  # pragma: no cover - depends on box
             _HIP_ERR = e

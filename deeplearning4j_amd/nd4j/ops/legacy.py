@@ -519,12 +519,15 @@ class LegacyOpExecutioner:
                 z = torch.empty(out_shape, device=x.device, dtype=zdtype)
                 zz = z.view(torch.uint8) if zdtype == torch.bool else z
                 if tri:
-                    L.check(L.hip().dl4j_legacy_reduce_tri(L.c_int(RED[name]), L.ptr(x), L.ptr(y), L.ptr(zz), ctypes.byref(d),
-                                                           _extra(extra), L.c_int(L.dtype_code_all(x)), L.c_int(zk), L.stream()),
+                    segs = int(L.hip().dl4j_legacy_reduce_segs(L.c_int64(d.num_tads), L.c_int64(d.tad_len)))
+                    part = torch.empty(3 * d.num_tads * segs, device=x.device, dtype=torch.float64) if segs > 1 else None
+                    L.check(L.hip().dl4j_legacy_reduce_tri_p(L.c_int(RED[name]), L.ptr(x), L.ptr(y), L.ptr(zz), L.ptr(part), ctypes.byref(d),
+                                                             _extra(extra), L.c_int(L.dtype_code_all(x)), L.c_int(zk), L.stream()),
                             "legacy_reduce_tri(%s)" % name)
                 else:
-                    segs = int(L.hip().dl4j_legacy_reduce_segs(L.c_int64(d.num_tads), L.c_int64(d.tad_len)))
-                    part = torch.empty(d.num_tads * segs, device=x.device, dtype=torch.float64) if segs > 1 else None
+                    L.hip().dl4j_legacy_reduce_partial_len.restype = ctypes.c_int64
+                    plen = int(L.hip().dl4j_legacy_reduce_partial_len(ctypes.byref(d), L.c_int(x.element_size())))
+                    part = torch.empty(plen, device=x.device, dtype=torch.float64) if plen > 0 else None
                     L.check(L.hip().dl4j_legacy_reduce(L.c_int(RED[name]), L.ptr(x), L.ptr(zz), L.ptr(part), ctypes.byref(d),
                                                        _extra(extra), L.c_int(L.dtype_code_all(x)), L.c_int(zk), L.stream()),
                             "legacy_reduce(%s)" % name)
