@@ -618,3 +618,4 @@ class TFGraphMapper:
                     sd._consumers[old].remove(o.name)
                 sd._consumers[v.name].append(o.name)
         return sd
+from . import import_tf_ext  # noqa: E402,F401  (registers the second tranche of rules)

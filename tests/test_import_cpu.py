@@ -369,3 +369,96 @@ def test_bert_tf_graphdef_round_trip_is_refused_into_the_same_fused_graph():
     assert ob16.dtype == torch.bfloat16 and (ob16.float() - oa).abs().max() < 0.1
     loss_in = [o for o in b.ops.values() if "loss" in o.opName][0].inputs
     assert any(i.endswith("/float") for i in loss_in)
+
+
+def test_tf_rule_coverage_matches_reference_ruleset():
+    """Every inputFrameworkOpName of the reference's tensorflow-mapping-ruleset.pbtxt has an import rule."""
+    import os
+    import re
+    p = REF + "/nd4j/samediff-import/samediff-import-tensorflow/src/main/resources/tensorflow-mapping-ruleset.pbtxt"
+    if not os.path.exists(p):
+        pytest.skip("reference tree not present")
+    names = set(re.findall(r'inputFrameworkOpName:\s*"([^"]+)"', open(p).read()))
+    have = set(TFGraphMapper.supportedOps())
+    assert len(names) > 300 and not sorted(names - have), sorted(names - have)
+
+
+def _run_tf(build, feeds, outs):
+    from deeplearning4j_amd.autodiff.export_tf import GraphDefBuilder
+    g = GraphDefBuilder()
+    build(g)
+    sd = TFGraphMapper.importGraph(g.build())
+    res = sd.output(feeds, outs)
+    return [_t(res[o]) for o in outs]
+
+
+def test_tf_second_tranche_rules_execute_with_tf_semantics():
+    T = ("type", 1)
+    x = torch.tensor([[1., -2., 3.], [4., 0., -6.]])
+    # linear algebra / element-wise renames
+    (o,) = _run_tf(lambda g: g.node("MatrixBandPart", [g.const(torch.arange(16.).reshape(4, 4), "x"), g.const(torch.tensor(1), "lo"),
+                                                     g.const(torch.tensor(0), "hi")], name="y", T=T), {}, ["y"])
+    assert torch.equal(o, torch.tril(torch.triu(torch.arange(16.).reshape(4, 4), -1)))
+    (o,) = _run_tf(lambda g: g.node("DivNoNan", [g.const(x, "x"), g.const(torch.tensor([[1., 0., 2.], [0., 1., 3.]]), "d")], name="y", T=T), {}, ["y"])
+    assert torch.equal(o, torch.tensor([[1., 0., 1.5], [0., 0., -2.]]))
+    (o,) = _run_tf(lambda g: g.node("ApproximateEqual", [g.const(x, "x"), g.const(x + 1e-7, "z")], name="y", T=T, tolerance=1e-5), {}, ["y"])
+    assert o.all()
+    (o,) = _run_tf(lambda g: g.node("BitwiseXor", [g.const(torch.tensor([5, 12], dtype=torch.int32), "a"), g.const(torch.tensor([3, 10], dtype=torch.int32), "b")],
+                                    name="y", T=("type", 3)), {}, ["y"])
+    assert o.tolist() == [6, 6]
+    s, ld = _run_tf(lambda g: g.node("LogMatrixDeterminant", [g.const(torch.tensor([[2., 0.], [0., 3.]]), "a")], name="y", T=T), {}, ["y", "y:1"])
+    assert float(s) == 1.0 and abs(float(ld) - math.log(6.0)) < 1e-6
+    # scatter / segment / partition families
+    (o,) = _run_tf(lambda g: g.node("ScatterNd", [g.const(torch.tensor([[1], [3]], dtype=torch.int32), "i"), g.const(torch.tensor([5., 6.]), "u"),
+                                                  g.const(torch.tensor([4], dtype=torch.int32), "s")], name="y", T=T, Tindices=("type", 3)), {}, ["y"])
+    assert o.tolist() == [0, 5, 0, 6]
+    (o,) = _run_tf(lambda g: g.node("TensorScatterAdd", [g.const(torch.ones(4), "t"), g.const(torch.tensor([[0], [0]], dtype=torch.int32), "i"),
+                                                         g.const(torch.tensor([2., 3.]), "u")], name="y", T=T), {}, ["y"])
+    assert o.tolist() == [6, 1, 1, 1]
+    (o,) = _run_tf(lambda g: g.node("UnsortedSegmentMax", [g.const(torch.tensor([1., 5., 2., 7.]), "x"), g.const(torch.tensor([1, 0, 1, 0], dtype=torch.int32), "s"),
+                                                           g.const(torch.tensor(2, dtype=torch.int32), "n")], name="y", T=T), {}, ["y"])
+    assert o.tolist() == [7, 2]
+    p0, p1 = _run_tf(lambda g: g.node("DynamicPartition", [g.const(torch.tensor([10., 20., 30., 40.]), "x"), g.const(torch.tensor([0, 1, 0, 1], dtype=torch.int32), "p")],
+                                      name="y", T=T, num_partitions=2), {}, ["y", "y:1"])
+    assert p0.tolist() == [10, 30] and p1.tolist() == [20, 40]
+    u, idx = _run_tf(lambda g: g.node("Unique", [g.const(torch.tensor([3., 1., 3., 2., 1.]), "x")], name="y", T=T), {}, ["y", "y:1"])
+    assert u.tolist() == [3, 1, 2] and idx.tolist() == [0, 1, 0, 2, 1]
+    (o,) = _run_tf(lambda g: g.node("ReverseSequence", [g.const(x, "x"), g.const(torch.tensor([2, 3], dtype=torch.int32), "l")], name="y", T=T, seq_dim=1, batch_dim=0), {}, ["y"])
+    assert o.tolist() == [[-2, 1, 3], [-6, 0, 4]]
+    (o,) = _run_tf(lambda g: g.node("Roll", [g.const(x, "x"), g.const(torch.tensor([1], dtype=torch.int32), "s"), g.const(torch.tensor([1], dtype=torch.int32), "a")], name="y", T=T), {}, ["y"])
+    assert torch.equal(o, torch.roll(x, 1, 1))
+    v, ix = _run_tf(lambda g: g.node("TopK", [g.const(x, "x")], name="y", T=T, k=2, sorted=True), {}, ["y", "y:1"])
+    assert v.tolist() == [[3, 1], [4, 0]]
+    (o,) = _run_tf(lambda g: g.node("HistogramFixedWidth", [g.const(torch.tensor([0.1, 0.4, 0.6, 0.9, 0.95]), "x"), g.const(torch.tensor([0., 1.]), "r"),
+                                                            g.const(torch.tensor(2, dtype=torch.int32), "n")], name="y", T=T), {}, ["y"])
+    assert o.tolist() == [2, 3]
+    # pooling / conv in NDHWC
+    vol = torch.arange(2 * 4 * 4 * 4 * 1, dtype=torch.float32).reshape(2, 4, 4, 4, 1)
+    (o,) = _run_tf(lambda g: g.node("MaxPool3D", [g.const(vol, "x")], name="y", T=T, ksize=[1, 2, 2, 2, 1], strides=[1, 2, 2, 2, 1], padding="VALID",
+                                    data_format="NDHWC"), {}, ["y"])
+    ref = F.max_pool3d(vol.permute(0, 4, 1, 2, 3), 2).permute(0, 2, 3, 4, 1)
+    assert torch.equal(o, ref)
+    w3 = torch.randn(2, 2, 2, 1, 3, generator=torch.Generator().manual_seed(0))
+    (o,) = _run_tf(lambda g: g.node("Conv3D", [g.const(vol / 100, "x"), g.const(w3, "w")], name="y", T=T, strides=[1, 1, 1, 1, 1], dilations=[1, 1, 1, 1, 1],
+                                    padding="VALID", data_format="NDHWC"), {}, ["y"])
+    ref = F.conv3d((vol / 100).permute(0, 4, 1, 2, 3), w3.permute(4, 3, 0, 1, 2)).permute(0, 2, 3, 4, 1)
+    assert torch.allclose(o, ref, atol=1e-4)
+    img = torch.arange(16.).reshape(1, 4, 4, 1)
+    mp, am = _run_tf(lambda g: g.node("MaxPoolWithArgmax", [g.const(img, "x")], name="y", T=T, ksize=[1, 2, 2, 1], strides=[1, 2, 2, 1], padding="VALID"), {}, ["y", "y:1"])
+    assert mp.reshape(-1).tolist() == [5, 7, 13, 15]
+    # TensorArray -> list ops: write two rows, read one back, gather both
+    def ta(g):
+        size = g.const(torch.tensor(2, dtype=torch.int32), "size")
+        h = g.node("TensorArrayV3", [size], name="ta", dtype=T)
+        w0 = g.node("TensorArrayWriteV3", ["ta", g.const(torch.tensor(0, dtype=torch.int32), "i0"), g.const(torch.tensor([1., 2.]), "v0"), "ta:1"], name="w0", T=T)
+        w1 = g.node("TensorArrayWriteV3", ["ta", g.const(torch.tensor(1, dtype=torch.int32), "i1"), g.const(torch.tensor([3., 4.]), "v1"), w0], name="w1", T=T)
+        g.node("TensorArrayReadV3", ["ta", "i1", w1], name="r", dtype=T)
+        g.node("TensorArrayGatherV3", ["ta", g.const(torch.tensor([1, 0], dtype=torch.int32), "gi"), w1], name="gth", dtype=T)
+        g.node("TensorArraySizeV3", ["ta", w1], name="sz")
+    r, gth, sz = _run_tf(ta, {}, ["r", "gth", "sz"])
+    assert r.tolist() == [3, 4] and gth.tolist() == [[3, 4], [1, 2]] and int(sz) == 2
+    # random ops draw the requested shape; iterators become placeholders
+    (o,) = _run_tf(lambda g: g.node("RandomStandardNormal", [g.const(torch.tensor([64, 8], dtype=torch.int32), "s")], name="y", dtype=T, T=("type", 3)), {}, ["y"])
+    assert o.shape == (64, 8) and abs(float(o.mean())) < 0.5
+    with pytest.raises(NotImplementedError):
+        _run_tf(lambda g: g.node("While", [g.const(torch.tensor(1.), "x")], name="y"), {}, ["y"])
