@@ -556,3 +556,6 @@ class OnnxImporter:
                         sd.renameVariable(v.name, oname)
         sd.onnxOutputs = [o.str(1) for o in g.msgs(12)]
         return sd
+
+
+from . import import_onnx_ext  # noqa: E402,F401  (registers the second tranche of rules)

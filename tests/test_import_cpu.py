@@ -462,3 +462,85 @@ def test_tf_second_tranche_rules_execute_with_tf_semantics():
     assert o.shape == (64, 8) and abs(float(o.mean())) < 0.5
     with pytest.raises(NotImplementedError):
         _run_tf(lambda g: g.node("While", [g.const(torch.tensor(1.), "x")], name="y"), {}, ["y"])
+
+
+def test_onnx_rule_coverage_matches_reference_ruleset():
+    import os
+    import re
+    p = REF + "/nd4j/samediff-import/samediff-import-onnx/src/main/resources/onnx-mapping-ruleset.pbtxt"
+    if not os.path.exists(p):
+        pytest.skip("reference tree not present")
+    names = set(re.findall(r'inputFrameworkOpName:\s*"([^"]+)"', open(p).read()))
+    assert len(names) > 100 and not sorted(names - set(OnnxImporter.supportedOps())), sorted(names - set(OnnxImporter.supportedOps()))
+
+
+def _run_onnx(nodes, inits, inputs, outs, feeds):
+    m = ox_model(nodes, inits, inputs, [ox_value_info(o, []) for o in outs])
+    sd = OnnxImporter.importGraph(m)
+    res = sd.output(feeds, outs)
+    return [_t(res[o]) for o in outs]
+
+
+def test_onnx_second_tranche_rules_execute_with_onnx_semantics():
+    torch.manual_seed(5)
+    # recurrent ops against torch.nn (gate orders: ONNX LSTM i,o,f,c / torch i,f,g,o; ONNX GRU z,r,h / torch r,z,n)
+    T_, B_, I_, H_ = 5, 3, 4, 6
+    lstm = torch.nn.LSTM(I_, H_)
+    x = torch.randn(T_, B_, I_)
+    wi, wh, bi, bh = [p.detach() for p in (lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)]
+    def iofc(w):
+        i_, f_, g_, o_ = w.split(H_, 0)
+        return torch.cat([i_, o_, f_, g_], 0)
+    W, R, Bv = iofc(wi)[None], iofc(wh)[None], torch.cat([iofc(bi), iofc(bh)])[None]
+    y, yh, yc = _run_onnx([ox_node("LSTM", ["x", "W", "R", "B"], ["Y", "Yh", "Yc"], hidden_size=H_, direction="forward")],
+                          [ox_tensor("W", W), ox_tensor("R", R), ox_tensor("B", Bv)], [ox_value_info("x", [T_, B_, I_])], ["Y", "Yh", "Yc"], {"x": x})
+    ry, (rh, rc) = lstm(x)
+    assert torch.allclose(y[:, 0], ry, atol=1e-5) and torch.allclose(yh, rh, atol=1e-5) and torch.allclose(yc, rc, atol=1e-5)
+    gru = torch.nn.GRU(I_, H_)
+    gi, gh, gbi, gbh = [p.detach() for p in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)]
+    def zrh(w):
+        r_, z_, n_ = w.split(H_, 0)
+        return torch.cat([z_, r_, n_], 0)
+    y, yh = _run_onnx([ox_node("GRU", ["x", "W", "R", "B"], ["Y", "Yh"], hidden_size=H_, linear_before_reset=1)],
+                      [ox_tensor("W", zrh(gi)[None]), ox_tensor("R", zrh(gh)[None]), ox_tensor("B", torch.cat([zrh(gbi), zrh(gbh)])[None])],
+                      [ox_value_info("x", [T_, B_, I_])], ["Y", "Yh"], {"x": x})
+    ry, rh = gru(x)
+    assert torch.allclose(y[:, 0], ry, atol=1e-5) and torch.allclose(yh, rh, atol=1e-5)
+    # layout / indexing ops
+    img = torch.randn(2, 8, 3, 3)
+    (o,) = _run_onnx([ox_node("DepthToSpace", ["x"], ["y"], blocksize=2, mode="CRD")], [], [ox_value_info("x", [2, 8, 3, 3])], ["y"], {"x": img})
+    assert torch.equal(o, F.pixel_shuffle(img, 2))
+    (o,) = _run_onnx([ox_node("SpaceToDepth", ["x"], ["y"], blocksize=2), ox_node("DepthToSpace", ["y"], ["z"], blocksize=2, mode="DCR")], [],
+                     [ox_value_info("x", [2, 2, 4, 4])], ["z"], {"x": torch.arange(64.).reshape(2, 2, 4, 4)})
+    assert torch.equal(o, torch.arange(64.).reshape(2, 2, 4, 4))
+    m = torch.tensor([[1., 0., 3.], [0., 5., 0.]])
+    (o,) = _run_onnx([ox_node("NonZero", ["x"], ["y"])], [], [ox_value_info("x", [2, 3])], ["y"], {"x": m})
+    assert o.tolist() == [[0, 0, 1], [0, 2, 1]]
+    v, ix = _run_onnx([ox_node("TopK", ["x", "k"], ["v", "i"], axis=1, largest=0)], [ox_tensor("k", torch.tensor([2]))], [ox_value_info("x", [2, 3])],
+                      ["v", "i"], {"x": m})
+    assert v.tolist() == [[0, 1], [0, 0]]
+    (o,) = _run_onnx([ox_node("ScatterElements", ["x", "i", "u"], ["y"], axis=1, reduction="add")],
+                     [ox_tensor("i", torch.tensor([[0, 0], [2, 1]])), ox_tensor("u", torch.tensor([[1., 2.], [3., 4.]]))], [ox_value_info("x", [2, 3])], ["y"], {"x": m})
+    assert o.tolist() == [[4, 0, 3], [0, 9, 3]]
+    (o,) = _run_onnx([ox_node("CumSum", ["x", "a"], ["y"], reverse=1)], [ox_tensor("a", torch.tensor([1]))], [ox_value_info("x", [2, 3])], ["y"], {"x": m})
+    assert o.tolist() == [[4, 3, 3], [5, 5, 0]]
+    (o,) = _run_onnx([ox_node("Mod", ["x", "d"], ["y"], fmod=1)], [ox_tensor("d", torch.tensor([2., 2., 2.]))], [ox_value_info("x", [2, 3])], ["y"], {"x": -m})
+    assert torch.equal(o, torch.fmod(-m, 2.0))
+    # sequences
+    a, b2 = torch.tensor([1., 2.]), torch.tensor([3., 4.])
+    at, ln = _run_onnx([ox_node("SequenceConstruct", ["a", "b"], ["s"]), ox_node("SequenceInsert", ["s", "a"], ["s2"]),
+                        ox_node("SequenceErase", ["s2", "p0"], ["s3"]), ox_node("SequenceAt", ["s3", "p0"], ["at"]), ox_node("SequenceLength", ["s3"], ["ln"])],
+                       [ox_tensor("p0", torch.tensor(0))], [ox_value_info("a", [2]), ox_value_info("b", [2])], ["at", "ln"], {"a": a, "b": b2})
+    assert at.tolist() == [3, 4] and int(ln) == 2
+    # detection ops
+    boxes = torch.tensor([[[0., 0., 1., 1.], [0., 0.1, 1., 1.1], [0., 2., 1., 3.]]])
+    scores = torch.tensor([[[0.9, 0.8, 0.7]]])
+    (o,) = _run_onnx([ox_node("NonMaxSuppression", ["b", "s", "mx", "iou"], ["y"])], [ox_tensor("mx", torch.tensor([3])), ox_tensor("iou", torch.tensor([0.5]))],
+                     [ox_value_info("b", [1, 3, 4]), ox_value_info("s", [1, 1, 3])], ["y"], {"b": boxes, "s": scores})
+    assert o.tolist() == [[0, 0, 0], [0, 0, 2]]
+    feat = torch.arange(16.).reshape(1, 1, 4, 4)
+    (o,) = _run_onnx([ox_node("RoiAlign", ["x", "r", "bi"], ["y"], output_height=1, output_width=1, sampling_ratio=2, spatial_scale=1.0)],
+                     [ox_tensor("r", torch.tensor([[0., 0., 4., 4.]])), ox_tensor("bi", torch.tensor([0]))], [ox_value_info("x", [1, 1, 4, 4])], ["y"], {"x": feat})
+    assert o.shape == (1, 1, 1, 1) and abs(float(o) - 10.0) < 1e-4         # samples at (1,1) (1,3) (3,1) (3,3): 5, 7, 13, 15
+    (o,) = _run_onnx([ox_node("RandomUniform", [], ["y"], shape=[16, 4], low=2.0, high=3.0)], [], [], ["y"], {})
+    assert o.shape == (16, 4) and float(o.min()) >= 2.0 and float(o.max()) <= 3.0
