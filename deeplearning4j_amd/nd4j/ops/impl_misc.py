@@ -283,8 +283,11 @@ def _resize(mode):
             iw = torch.clamp(((torch.arange(w, device=x.device) + off) * sw).round().long() if align else
                              torch.floor((torch.arange(w, device=x.device) + off) * sw).long(), 0, W - 1)
             y = xf[:, :, ih][:, :, :, iw]
-        elif mode == "area":
-            y = F.adaptive_avg_pool2d(xf, (h, w)) if (xf.shape[2] % h == 0 and xf.shape[3] % w == 0) else F.interpolate(xf, (h, w), mode="area")
+        elif mode in ("area", "bicubic"):
+            # TensorFlow semantics (quantised Keys cubic taps / exact fractional footprint), not torch's: ops/misc_kernels.py
+            from ...ops.misc_kernels import resize_tf_reference
+            y = resize_tf_reference(xf.permute(0, 2, 3, 1), h, w, mode, align, half)
+            return y.squeeze(0) if squeeze else y
         elif mode == "bilinear" and not align and not half:
             # TF1 legacy sampling: src = dst * scale (no half-pixel shift)
             H, W = xf.shape[2], xf.shape[3]
@@ -713,6 +716,9 @@ op("While", "Scope", "Conditional", "Return")(lambda ins, i, t, b, d: tuple(ins)
 
 
 # ----------------------------------------------------------------------------- NLP: skipgram / cbow
+_SG_MAX_EXP = 6.0
+
+
 def _sg_step(syn0, syn1, syn1neg, exp_table, neg_table, target, ngram_starter, indices, codes, alpha, rnd, n_neg, neu1=None,
              update_syn0=True):
     """One skip-gram/cbow training step on rows of syn0 (reference: helpers/cuda/sg_cb.cu hSoftmax_/nSampling_).
@@ -723,8 +729,10 @@ def _sg_step(syn0, syn1, syn1neg, exp_table, neg_table, target, ngram_starter, i
         idx = torch.as_tensor(indices, dtype=torch.int64, device=syn0.device)
         cd = torch.as_tensor(codes, dtype=syn0.dtype, device=syn0.device)
         rows = syn1[idx]
-        f = torch.sigmoid(rows @ l1)
+        dot = rows @ l1
+        f = torch.sigmoid(dot)
         g = (1 - cd - f) * alpha
+        g = torch.where((dot < -_SG_MAX_EXP) | (dot >= _SG_MAX_EXP), torch.zeros_like(g), g)      # reference skips saturated code points
         neu1e += g @ rows
         syn1.index_add_(0, idx, g.unsqueeze(1) * l1.unsqueeze(0))
     if n_neg > 0 and syn1neg is not None:
@@ -744,7 +752,8 @@ def _sg_step(syn0, syn1, syn1neg, exp_table, neg_table, target, ngram_starter, i
         lab = torch.zeros(len(tg), dtype=syn0.dtype, device=syn0.device)
         lab[0] = 1
         rows = syn1neg[idx]
-        f = torch.sigmoid(rows @ l1)
+        dot = rows @ l1
+        f = torch.where(dot > _SG_MAX_EXP, torch.ones_like(dot), torch.where(dot < -_SG_MAX_EXP, torch.zeros_like(dot), torch.sigmoid(dot)))
         g = (lab - f) * alpha
         neu1e += g @ rows
         syn1neg.index_add_(0, idx, g.unsqueeze(1) * l1.unsqueeze(0))

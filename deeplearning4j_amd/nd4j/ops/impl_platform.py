@@ -787,3 +787,190 @@ def _fused_dense_hip(ins, i, t, b, d):
     from ...ops import linear as LIN
     x, w, bias, res, act = _fd_split(ins, i)
     return LIN.fused_dense(x, w, bias, res, act)
+
+
+# ----------------------------------------------------------------------------- helpers_misc.hip family
+# order statistics, generators, TF-exact bicubic / area resize, adjust_contrast, draw_bounding_boxes, t-SNE steps, word2vec batch
+from ...ops import misc_kernels as MK  # noqa: E402
+
+
+@platform("nth_element", lambda ins, i, t, b, d: len(ins) > 1 and _fx(ins[0]) and ins[0].dim() >= 1 and 0 <= int(ins[1]) < ins[0].shape[-1])
+def _nth_element(ins, i, t, b, d):
+    return MK.nth_element(ins[0], int(ins[1]), bool(i[0]) if i else False)
+
+
+def _pct_ok(ins, i, t, b, d):
+    return _fx(ins[0]) and bool(t) and ins[0].numel() > 0 and (not i or len(set(k % ins[0].dim() for k in i)) == len(i))
+
+
+@platform("percentile", _pct_ok)
+def _percentile(ins, i, t, b, d):
+    x = ins[0]
+    interp = int(t[1]) if len(t) > 1 else 2
+    keep = bool(t[2]) if len(t) > 2 else False
+    dims = sorted(k % x.dim() for k in i) if i else list(range(x.dim()))
+    others = [k for k in range(x.dim()) if k not in dims]
+    xp = x.permute(*others, *dims).reshape([x.shape[k] for k in others] + [-1]).contiguous()
+    r = MK.nth_element(xp, MK.percentile_positions(float(t[0]), xp.shape[-1], interp))
+    if keep:
+        r = r.reshape([1 if k in dims else x.shape[k] for k in range(x.dim())])
+    return r
+
+
+def _range_args(ins, i, t):
+    if ins:
+        vals = [x.item() for x in ins]
+        dt, dev = ins[0].dtype, ins[0].device
+    elif t:
+        vals, dt, dev = list(t), torch.float32, None
+    else:
+        vals, dt, dev = list(i), torch.int64, None
+    if len(vals) == 1:
+        vals = [0, vals[0], 1]
+    elif len(vals) == 2:
+        vals = vals + [1]
+    return vals, dt, dev
+
+
+def _range_ok(ins, i, t, b, d):
+    return bool(ins) and all(x.numel() == 1 for x in ins) and L.use_hip(ins[0]) and L.dtype_code_all(ins[0]) >= 0
+
+
+@platform("range", _range_ok)
+def _range(ins, i, t, b, d):
+    import math
+    from .impl_core import dtype_arg
+    (s, e, st), dt, dev = _range_args(ins, i, t)
+    if st == 0:
+        raise ValueError("range: step must not be 0")
+    n = max(int(math.ceil((e - s) / st)), 0)
+    out_dt = dtype_arg(d, None, 0, dt)
+    if L.dtype_code_all(torch.empty(0, dtype=out_dt)) < 0:
+        return torch.arange(s, e, st, dtype=out_dt, device=dev)
+    return MK.fill_range(s, st, n, out_dt, dev)
+
+
+@platform("lin_space", lambda ins, i, t, b, d: len(ins) >= 3 and L.use_hip(ins[0]) and int(ins[2]) >= 1)
+def _lin_space(ins, i, t, b, d):
+    from .impl_core import dtype_arg
+    s, e, n = float(ins[0]), float(ins[1]), int(ins[2])
+    out_dt = dtype_arg(d, None, 0, torch.float32)
+    if L.dtype_code_all(torch.empty(0, dtype=out_dt)) < 0:
+        return torch.linspace(s, e, n, dtype=out_dt, device=ins[0].device)
+    return MK.fill_range(s, (e - s) / (n - 1) if n > 1 else 0.0, n, out_dt, ins[0].device)
+
+
+def _bytes_ok(x):
+    return L.use_hip(x) and x.element_size() in (1, 2, 4, 8) and not x.is_complex()
+
+
+@platform("diag", lambda ins, i, t, b, d: _bytes_ok(ins[0]) and ins[0].numel() > 0)
+def _diag(ins, i, t, b, d):
+    x = ins[0]
+    m = MK.diag(x)
+    return m.reshape(list(x.shape) * 2) if x.dim() > 1 else m
+
+
+@platform("diag_part", lambda ins, i, t, b, d: _bytes_ok(ins[0]) and ins[0].numel() > 0 and ins[0].dim() % 2 == 0)
+def _diag_part(ins, i, t, b, d):
+    x = ins[0]
+    return MK.diag_part(x).reshape(x.shape[:x.dim() // 2])
+
+
+@platform("meshgrid", lambda ins, i, t, b, d: len(ins) >= 1 and all(_bytes_ok(x) and x.numel() > 0 for x in ins))
+def _meshgrid(ins, i, t, b, d):
+    return MK.meshgrid(ins, xy=(not i or bool(i[0])))
+
+
+def _resize_tf(mode):
+    def f(ins, i, t, b, d):
+        x = ins[0]
+        if len(ins) > 1:
+            h, w = [int(v) for v in ins[1].reshape(-1).tolist()]
+        else:
+            h, w = int(i[0]), int(i[1])
+        return MK.resize_tf(x, h, w, mode, bool(b[0]) if b else False, bool(b[1]) if len(b) > 1 else False)
+    return f
+
+
+platform("resize_bicubic", _resize_ok)(_resize_tf("bicubic"))
+platform("resize_area", _resize_ok)(_resize_tf("area"))
+
+
+@platform("adjust_contrast", lambda ins, i, t, b, d: _fx(ins[0]) and ins[0].dim() >= 3 and ins[0].shape[-1] <= 256 and (bool(t) or len(ins) > 1))
+def _adjust_contrast(ins, i, t, b, d):
+    return MK.adjust_contrast(ins[0], t[0] if t else float(ins[1]))
+
+
+platform("adjust_contrast_v2", lambda ins, i, t, b, d: _fx(ins[0]) and ins[0].dim() >= 3 and ins[0].shape[-1] <= 256
+         and (bool(t) or len(ins) > 1))(_adjust_contrast)
+
+
+@platform("draw_bounding_boxes", lambda ins, i, t, b, d: len(ins) >= 3 and _fx(ins[0]) and ins[0].dim() == 4 and L.use_hip(ins[1], ins[2])
+          and ins[1].dim() == 3 and ins[1].shape[0] == ins[0].shape[0] and ins[2].dim() == 2 and ins[2].shape[1] >= ins[0].shape[3]
+          and ins[2].shape[0] > 0)
+def _draw_bb(ins, i, t, b, d):
+    C = ins[0].shape[3]
+    return MK.draw_boxes(ins[0], ins[1], ins[2][:, :C])
+
+
+@platform("barnes_gains", lambda ins, i, t, b, d: len(ins) >= 3 and all(L.use_hip(x) and x.dtype == torch.float32 and x.is_contiguous()
+                                                                         for x in ins[:3]) and ins[0].shape == ins[1].shape == ins[2].shape)
+def _barnes_gains(ins, i, t, b, d):
+    return MK.barnes_gains(ins[0], ins[1], ins[2])
+
+
+@platform("barnes_symmetrized", lambda ins, i, t, b, d: len(ins) >= 3 and L.use_hip(ins[0], ins[1], ins[2]) and ins[2].dtype == torch.float32)
+def _barnes_sym(ins, i, t, b, d):
+    N = int(i[0]) if i else ins[0].numel() - 1
+    return MK.barnes_symmetrize(ins[0], ins[1], ins[2], N)
+
+
+def _sg_tables(syn1, syn1neg):
+    return (syn1 if syn1 is not None and syn1.numel() else None), (syn1neg if syn1neg is not None and syn1neg.numel() else None)
+
+
+def _sg_ok(ins, i, t, b, d):
+    if len(ins) < 11 or not MK.sg_cb_supported(ins[4]):
+        return False
+    if bool(b[0]) if b else False:            # inference: needs the inference vector
+        return len(ins) > 11 and ins[11] is not None and ins[11].is_cuda and ins[11].dtype == torch.float32 and ins[11].is_contiguous()
+    return True
+
+
+@platform("skipgram", _sg_ok)
+def _skipgram_hip(ins, i, t, b, d):
+    target, ngs, indices, codes, syn0, syn1, syn1neg, expT, negT, alpha, rnd = ins[:11]
+    s1, s1n = _sg_tables(syn1, syn1neg)
+    infer = ins[11] if (b and b[0]) else None
+    B = max(int(target.numel()), 1)
+    has_hs = s1 is not None and indices is not None and indices.numel() > 0
+    MK.sg_cb_batch(syn0, s1, s1n, negT, target.reshape(-1), ngs.reshape(-1), None, indices.reshape(B, -1) if has_hs else None,
+                   codes.reshape(B, -1) if has_hs else None, alpha, rnd, int(i[1]) if len(i) > 1 else 0, True, infer)
+    return syn0, syn1, syn1neg
+
+
+platform("skipgram_inference", _sg_ok)(_skipgram_hip)
+
+
+def _cbow_ok(ins, i, t, b, d):
+    if len(ins) < 12 or not MK.sg_cb_supported(ins[5]):
+        return False
+    if bool(b[1]) if len(b) > 1 else False:
+        return len(ins) > 14 and ins[14] is not None and ins[14].is_cuda and ins[14].dtype == torch.float32 and ins[14].is_contiguous()
+    return ins[2] is not None and ins[2].numel() > 0
+
+
+@platform("cbow", _cbow_ok)
+def _cbow_hip(ins, i, t, b, d):
+    target, ngs, context, indices, codes, syn0, syn1, syn1neg, expT, negT, alpha, rnd = ins[:12]
+    s1, s1n = _sg_tables(syn1, syn1neg)
+    infer = ins[14] if (len(b) > 1 and b[1]) else None
+    B = max(int(target.numel()), 1)
+    has_hs = s1 is not None and indices is not None and indices.numel() > 0
+    MK.sg_cb_batch(syn0, s1, s1n, negT, target.reshape(-1), ngs.reshape(-1), context.reshape(B, -1), indices.reshape(B, -1) if has_hs else None,
+                   codes.reshape(B, -1) if has_hs else None, alpha, rnd, int(i[1]) if len(i) > 1 else 0, bool(b[0]) if b else True, infer)
+    return syn0, syn1, syn1neg
+
+
+platform("cbow_inference", _cbow_ok)(_cbow_hip)
