@@ -328,6 +328,11 @@ class StatsListener(TrainingListener):
         mi = {"modelClass": type(model).__name__, "numParams": model.numParams(), "numLayers": len(layers), "paramNames": names,
               "layerNames": [getattr(l.conf, "layerName", None) or str(i) for i, l in enumerate(layers)],
               "configJson": model.conf.toJson() if hasattr(model.conf, "toJson") else None}
+        try:
+            from .modules import buildGraphInfo
+            mi["graph"] = buildGraphInfo(model).toDict()
+        except Exception:          # the model page then falls back to the plain layer list
+            mi["graph"] = None
         now = int(time.time() * 1000)
         self.router.putStorageMetaData(Persistable(self.sessionID, TYPE_ID, self.workerID, now,
                                                    {"initTypeClass": "StatsInitializationReport", "updateTypeClass": "StatsReport"}))
