@@ -11,3 +11,11 @@ from .transform import (ColumnType, Schema, TransformProcess, LocalTransformExec
                         CategoricalColumnCondition, NullWritableColumnCondition, NaNColumnCondition, InvalidValueColumnCondition,
                         BooleanCondition, ConditionFilter, FilterInvalidValues, MathOp, MathFunction, ReduceOp, Reducer, Join, Normalize,
                         NumericalColumnComparator, StringComparator)
+from .transform_ext import (BooleanColumnCondition, FloatColumnCondition, TimeColumnCondition, InfiniteColumnCondition, TrivialColumnCondition,  # noqa: F401,E402
+                            StringRegexColumnCondition, SequenceLengthCondition, InvalidNumColumns, FirstDigitTransform, PivotTransform,
+                            ReplaceEmptyIntegerWithValue, ParseDoubleTransform, Log2Normalizer, MapAllStringsExceptList, StringListToCategoricalSet,
+                            StringListToCountsNDArray, StringListToIndicesNDArray, TextToCharacterIndexTransform, TextToTermIndexSequenceTransform,
+                            BaseSequenceExpansionTransform, DeriveColumnsFromTime, NDArrayScalarOpTransform, NDArrayMathFunctionTransform,
+                            NDArrayColumnsMathOpTransform, NDArrayDistanceTransform, Distance, SequenceDifferenceTransform, SequenceTrimToLength,
+                            ReduceSequenceTransform, SequenceSplitTimeSeparation, TimeWindowFunction, OverlappingTimeWindowFunction,
+                            ReduceSequenceByWindowTransform, SequenceMerge, RandomSplit, StringReduceOp, StringReducer)

@@ -1135,6 +1135,8 @@ class LocalTransformExecutor:
                 data = [r + [LongWritable(ranks[j])] for j, r in enumerate(data)]
             elif isinstance(st, SplitMaxLength):
                 data = [seq[i:i + st.maxLen] for seq in data for i in range(0, len(seq), st.maxLen)]
+            elif hasattr(st, "runAll"):              # steps that change the number of sequences (transform_ext.py)
+                data, is_seq = st.runAll(data, schema, is_seq)
             elif is_seq:
                 out = [st.mapSequence(seq) for seq in data]
                 data = [s for s in out if s]
