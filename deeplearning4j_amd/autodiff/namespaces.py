@@ -11,6 +11,10 @@ from typing import Sequence
 
 from ..nd4j.ops import legacy as LG
 from ..nd4j.ops.custom import describe
+from .generated.sd_bitwise import GenSDBitwise
+from .generated.sd_image import GenSDImage
+from .generated.sd_linalg import GenSDLinalg
+from .generated.sd_random import GenSDRandom
 
 
 class _NS:
@@ -289,7 +293,7 @@ class SDLoss(_NS):
     def weightedCrossEntropyWithLogits(self, targets, logits, weights, name=None): return self._o("weighted_cross_entropy_with_logits", [targets, logits, weights], name)
 
 
-class SDLinalg(_NS):
+class SDLinalg(GenSDLinalg, _NS):       # generated surface (codegen/ops/linalg.py) + the overrides below
     def cholesky(self, x, name=None): return self._o("cholesky", [x], name)
     def lstsq(self, a, b, l2=0.0, fast=True, name=None): return self._o("lstsq", [a, b], name, tArgs=[l2], bArgs=[fast])
     def solve(self, a, b, adjoint=False, name=None): return self._o("solve", [a, b], name, bArgs=[adjoint])
@@ -309,7 +313,7 @@ class SDLinalg(_NS):
     def mmul(self, a, b, transposeA=False, transposeB=False, name=None): return self._o("matmul", [a, b], name, iArgs=[int(transposeA), int(transposeB), 0])
 
 
-class SDBitwise(_NS):
+class SDBitwise(GenSDBitwise, _NS):       # generated surface (codegen/ops/bitwise.py) + the overrides below
     def bitsAnd(self, a, b, name=None): return self._o("bitwise_and", [a, b], name)
     and_ = bitsAnd
     def bitsOr(self, a, b, name=None): return self._o("bitwise_or", [a, b], name)
@@ -323,7 +327,7 @@ class SDBitwise(_NS):
     def bitsHammingDistance(self, a, b, name=None): return self._o("bits_hamming_distance", [a, b], name)
 
 
-class SDRandom(_NS):
+class SDRandom(GenSDRandom, _NS):       # generated surface (codegen/ops/random.py) + the overrides below
     def _shape(self, shape):
         import torch
         return self.sd.constant(None, torch.tensor(list(shape), dtype=torch.int64))
@@ -334,7 +338,7 @@ class SDRandom(_NS):
     def exponential(self, lam, dtype="FLOAT", *shape, name=None): return self._o("random_exponential", [self._shape(_dims(shape))], name, tArgs=[lam])
 
 
-class SDImage(_NS):
+class SDImage(GenSDImage, _NS):       # generated surface (codegen/ops/image.py) + the overrides below
     def resizeBiLinear(self, x, h, w, alignCorners=False, halfPixelCenters=False, name=None):
         return self._o("resize_bilinear", [x], name, iArgs=[h, w], bArgs=[alignCorners, halfPixelCenters])
     def resizeNearestNeighbor(self, x, h, w, alignCorners=False, halfPixelCenters=False, name=None):

@@ -56,6 +56,12 @@ def decode_png_gray(data: bytes) -> torch.Tensor:
     return torch.tensor(rows, dtype=torch.uint8)
 
 
+def _tt(v):
+    """INDArray / tensor -> tensor."""
+    t = getattr(v, "tensor", None)
+    return v if t is None else (t() if callable(t) else t)
+
+
 def tile_activations(acts: List[torch.Tensor], max_channels=64, border=1) -> torch.Tensor:
     """List of [C, H, W] activation maps -> one uint8 image: a row of per-channel tiles for each layer."""
     rows = []
@@ -87,7 +93,7 @@ class ConvolutionalIterationListener(TrainingListener):
     def onForwardPass(self, model, activations):
         """``activations``: list (MultiLayerNetwork) or dict name -> tensor (ComputationGraph) of this iteration's layer outputs."""
         items = activations.items() if isinstance(activations, dict) else enumerate(activations)
-        self._acts = [(str(k), v) for k, v in items if torch.is_tensor(v) and v.dim() == 4]
+        self._acts = [(str(k), _tt(v)) for k, v in items if torch.is_tensor(_tt(v)) and _tt(v).dim() == 4]
 
     def iterationDone(self, model, iteration, epoch):
         if iteration % self.freq != 0:
@@ -97,10 +103,10 @@ class ConvolutionalIterationListener(TrainingListener):
             x = self.probeInput if self.probeInput is not None else getattr(model, "_input", None)
             if x is None or not hasattr(model, "feedForward"):
                 return
-            x = getattr(x, "tensor", x)
+            x = _tt(x)
             outs = model.feedForward(x[:1] if torch.is_tensor(x) else x, False)
             items = outs.items() if isinstance(outs, dict) else enumerate(outs)
-            acts = [(str(k), getattr(v, "tensor", v)) for k, v in items]
+            acts = [(str(k), _tt(v)) for k, v in items]
             acts = [(k, v) for k, v in acts if torch.is_tensor(v) and v.dim() == 4]
         if not acts:
             return

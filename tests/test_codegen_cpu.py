@@ -1,0 +1,113 @@
+"""Op-definition DSL + generators (deeplearning4j_amd/codegen). Reference: codegen/op-codegen tests (OpBuilderTest.kt, DocsGeneratorTest) and
+the generated namespaces' own tests (platform-tests/.../SDLinalgTest, TestNamespaces)."""
+import os
+
+import pytest
+import torch
+
+from deeplearning4j_amd.autodiff.samediff import SameDiff
+from deeplearning4j_amd.codegen import Count, DataType, Namespace, all_namespaces, generate_docs, generate_eager, generate_samediff
+from deeplearning4j_amd.codegen.generator import check_registry, generate_all
+from deeplearning4j_amd.nd4j.factory import Nd4j
+
+def _tensor(x):
+    f = getattr(x, "tensor", None)
+    return x if f is None else (f() if callable(f) else f)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_checked_in_generated_files_are_current_and_ops_exist():
+    nss = all_namespaces()
+    assert {"bitwise", "linalg", "random", "image"} <= set(nss)
+    assert generate_all(ROOT, check=True) == []                 # regenerate == what is committed
+    for ns in nss.values():
+        if ns.name.startswith("_test"):
+            continue
+        assert check_registry(ns) == [], ns.name
+
+
+def test_dsl_validation_and_generated_source_shape():
+    ns = Namespace("_test_ns", doc="scratch", className="Scratch")
+    (ns.op("clip", libnd4j="clipbyvalue", doc="Clip values.").input("x", DataType.NUMERIC, "input").arg("lo", DataType.FLOATING_POINT, "lower bound")
+       .arg("hi", DataType.FLOATING_POINT, "upper bound", default=1.0).output("out", DataType.NUMERIC, "clipped"))
+    (ns.op("sumAlong", libnd4j="reduce_sum", doc="Sum over dimensions.").input("x", DataType.NUMERIC, "input")
+       .arg("keepDims", DataType.BOOL, "keep reduced dimensions", default=False).arg("dims", DataType.INT, "dimensions", count=Count.AtLeast(0))
+       .output("out", DataType.NUMERIC, "sums").alias("total"))
+    (ns.op("pick", libnd4j="Where", doc="Select.").input("cond", DataType.BOOL, "condition").input("a", DataType.NUMERIC, "if true", optional=True)
+       .input("b", DataType.NUMERIC, "if false", optional=True).output("out", DataType.NUMERIC, "selection"))
+    src = generate_samediff(ns)
+    assert "class GenSDScratch:" in src and "def clip(self, x, lo, hi=1.0, name=None):" in src and "tArgs=[lo, hi]" in src
+    assert "def sumAlong(self, x, keepDims=False, *dims, name=None):" in src and "iArgs=[v for v in _dims(dims)]" in src and "bArgs=[keepDims]" in src
+    assert "total = sumAlong" in src and "[cond] + ([a] if a is not None else []) + ([b] if b is not None else [])" in src
+    compile(src, "gen_sd", "exec")
+    compile(generate_eager(ns), "gen_nd", "exec")
+    md = generate_docs(ns)
+    assert "## clip" in md and "* **hi** (FLOATING_POINT) - upper bound - default = 1.0" in md and "aliases: `total`" in md
+    bad = Namespace("_test_bad")
+    bad.op("noOutput").input("x", DataType.NUMERIC, "x")
+    with pytest.raises(ValueError, match="at least one output"):
+        bad.validate()
+    bad2 = Namespace("_test_bad2")
+    bad2.op("order").arg("a", DataType.INT, "a", default=1).arg("b", DataType.INT, "b").output("o", DataType.INT, "o")
+    with pytest.raises(ValueError, match="follows one with a default"):
+        bad2.validate()
+    with pytest.raises(ValueError):
+        Namespace("_test_bad3").op("x").arg("mode", DataType.ENUM, "no values")
+    with pytest.raises(ValueError):
+        Namespace("_test_bad4").op("x").input("not an identifier", DataType.INT, "")
+    for n in ("_test_ns", "_test_bad", "_test_bad2", "_test_bad3", "_test_bad4"):
+        Namespace._ALL.pop(n, None)
+
+
+def test_generated_samediff_namespaces_build_and_run_graphs():
+    sd = SameDiff.create()
+    a = sd.constant("a", torch.tensor([[4.0, 1.0], [1.0, 3.0]]))
+    b = sd.constant("b", torch.tensor([[1.0], [2.0]]))
+    la = sd.linalg
+    x = la.solve(a, b)                                   # hand-written override
+    band = la.matrixBandPart(a, 0, 0)                    # generated only in name order (minLower, maxUpper)
+    tri = la.tri(3, 4, -1)
+    s, u, v = la.svd(a, False, True)
+    only_s = la.svd(a, computeUV=False)
+    i1 = sd.constant("i1", torch.tensor([0b1100, 0b1010], dtype=torch.int32))
+    i2 = sd.constant("i2", torch.tensor([0b1010, 0b0110], dtype=torch.int32))
+    bw = sd.bitwise
+    r_and, r_tog = bw.and_(i1, i2), bw.toggleBits(i1)
+    assert bw.bitsAnd is not None and type(bw).and_ is not None
+    img = sd.constant("img", torch.arange(1, 10, dtype=torch.float32).reshape(1, 3, 3, 1))
+    area = sd.image.resizeArea(img, 6, 6)
+    rnd = sd.random.uniform(2.0, 3.0, "FLOAT", 4, 5)
+    out = sd.output({}, x.name, band.name, tri.name, s.name, only_s.name, r_and.name, r_tog.name, area.name, rnd.name)
+    t = lambda v_: _tensor(out[v_.name])
+    torch.testing.assert_close(t(x), torch.linalg.solve(torch.tensor([[4.0, 1.0], [1.0, 3.0]]), torch.tensor([[1.0], [2.0]])))
+    torch.testing.assert_close(t(band), torch.tensor([[4.0, 0.0], [0.0, 3.0]]))
+    torch.testing.assert_close(t(tri).float(), torch.tril(torch.ones(3, 4), -1))
+    torch.testing.assert_close(t(s), t(only_s))
+    assert t(r_and).tolist() == [0b1000, 0b0010] and t(r_tog).tolist() == [~0b1100, ~0b1010]
+    assert t(area).shape == (1, 6, 6, 1) and float(t(area)[0, 0, 1, 0]) == 1.0 and float(t(area)[0, 5, 5, 0]) == 9.0
+    r = t(rnd)
+    assert r.shape == (4, 5) and float(r.min()) >= 2.0 and float(r.max()) <= 3.0
+
+
+def test_generated_eager_namespaces():
+    a = Nd4j.create([[4.0, 1.0], [1.0, 3.0]])
+    inv = Nd4j.linalg().matrixInverse(a)
+    torch.testing.assert_close(_tensor(inv), torch.linalg.inv(_tensor(a)))
+    q, r = Nd4j.linalg().qr(a)
+    torch.testing.assert_close(_tensor(q) @ _tensor(r), _tensor(a))
+    mm = Nd4j.linalg().mmul(a, a, transposeB=True)
+    torch.testing.assert_close(_tensor(mm), _tensor(a) @ _tensor(a).t())
+    x = torch.tensor([1, 2, 4], dtype=torch.int32)
+    assert _tensor(Nd4j.bitwise().leftShift(x, torch.tensor([1, 1, 2], dtype=torch.int32))).tolist() == [2, 4, 16]
+    assert _tensor(Nd4j.bitwise().xor(x, x)).tolist() == [0, 0, 0]
+    n = Nd4j.random().normal(0.0, 1.0, "DOUBLE", [1000])
+    assert _tensor(n).dtype == torch.float64 and _tensor(n).shape == (1000,) and abs(float(_tensor(n).mean())) < 0.2
+    hsv = Nd4j.image().rgbToHsv(torch.tensor([[1.0, 0.0, 0.0]]))
+    torch.testing.assert_close(_tensor(hsv), torch.tensor([[0.0, 1.0, 1.0]]))
+    crop = Nd4j.image().cropAndResize(torch.rand(1, 8, 8, 1), torch.tensor([[0.0, 0.0, 1.0, 1.0]]), torch.tensor([0], dtype=torch.int32),
+                                      torch.tensor([4, 4], dtype=torch.int32), method="NEAREST")
+    assert _tensor(crop).shape == (1, 4, 4, 1)
+    # ops outside the generated surface are still reachable by registry name
+    assert _tensor(Nd4j.math().reduce_sum(torch.tensor([1.0, 2.0]))).tolist() == 3.0
