@@ -1,0 +1,406 @@
+// Persistent LSTM sequence kernels for gfx950: ONE launch runs all T time steps of a layer (bf16 activations / weights, fp32 cell
+// math). The recurrent weights stay resident in LDS for the whole sequence, the cell state stays in registers, and the workgroups
+// hand the hidden state to each other through memory with one grid barrier per step.
+//
+// Reference: the reference has no such kernel — its GPU path is cuDNN's fused RNN (platform/cudnn/lstmLayer.cu:439) and its own code
+// is a per-step loop of mmul + ~20 elementwise ops (helpers/impl/lstmLayer.cpp:200-420, LSTMHelpers.java:211-369). The per-step
+// native loop of rnn_seq.hip (one small GEMM + one cell kernel per step) is launch/latency bound at char-RNN sizes: a [64 x 512] x
+// [512 x 2048] step fills 32 workgroups for ~10 us. Here a step costs one hidden-state broadcast (64 KB through L2), 32 MFMAs per
+// wave and one barrier.
+//
+// Forward decomposition (n hidden units, mb <= 128 rows, DL4J gate order a | f | o | g):
+//   * workgroup w owns hidden units [8w, 8w+8) = 32 gate columns {g*n + 8w + k}; their recurrent weights (32 rows of RW4 [4n, n],
+//     K-contiguous) are loaded into LDS once;
+//   * every step: all 256 threads copy h_{t-1} [mb, n] into LDS (coalesced 16-byte loads), wave v multiplies rows [32v, 32v+32):
+//     gates^T = Wslice (A operand, M = 32 gate columns) x h^T (B operand, N = 32 batch rows), v_mfma_f32_32x32x16_bf16 over K = n.
+//     In the 32x32 accumulator layout lane l then holds, for batch row l%32, ALL FOUR gates (register group i = gate) of units
+//     4*(l/32)+j: the cell update runs in registers with no transpose, c_t never leaves the lane, and h_t leaves as one 8-byte store;
+//   * h_t slices are written with agent-scope (write-through) stores; after s_waitcnt + workgroup barrier one thread adds to the
+//     grid counter and spins (with s_sleep) until all workgroups of the step have arrived; an agent-scope acquire fence then drops
+//     stale L2 lines before the next step's loads (8 XCDs with private L2s). The spin is bounded: on timeout the kernel sets an
+//     abort flag that every workgroup observes, so the grid always drains.
+// Requirements checked on the host: n % 8 == 0, n / 8 <= 256 workgroups (all co-resident on 256 CUs), mb <= 128, LDS fits.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __expf(-2.f * fabsf(x));
+  const float t = (1.f - e) / (1.f + e);
+  return x < 0.f ? -t : t;
+}
+
+struct LstmFwdP {
+  const bf16_t* xw;        // [T, mb, 4n] input projection + bias
+  const bf16_t* rw4;       // [4n, ld_rw] recurrent weights, row = gate column
+  int64_t ld_rw;
+  const bf16_t* h0;        // [mb, n]
+  const bf16_t* c0;        // [mb, n]
+  const float* pf;         // peepholes [n] or null (all three or none)
+  const float* po;
+  const float* pg;
+  const float* maskT;      // [T, mb] or null
+  bf16_t* H;               // [T, mb, n]
+  bf16_t* Cs;              // [T, mb, n]
+  bf16_t* SV;              // [T, mb, 6n] or null
+  unsigned* bar;           // [0] arrival counter, [1] abort flag; zeroed before the launch
+  int T, mb, n, reverse;
+};
+
+#define SPIN_LIMIT (1 << 22)
+
+// one grid barrier; returns false when the kernel must abort. All threads of the block call it.
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1, spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      if (++spins > SPIN_LIMIT) {
+        __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  const bool ok = *s_flag != 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
+}
+
+__device__ __forceinline__ void st_agent_u64(void* p, uint64_t v) {
+  __hip_atomic_store((uint64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t pack4(float a, float b, float c, float d) {
+  return (uint64_t)f2bf(a) | ((uint64_t)f2bf(b) << 16) | ((uint64_t)f2bf(c) << 32) | ((uint64_t)f2bf(d) << 48);
+}
+__device__ __forceinline__ void unpack4(uint64_t v, float o[4]) {
+  o[0] = bf2f((bf16_t)(v & 0xffff)); o[1] = bf2f((bf16_t)((v >> 16) & 0xffff));
+  o[2] = bf2f((bf16_t)((v >> 32) & 0xffff)); o[3] = bf2f((bf16_t)(v >> 48));
+}
+
+__global__ void __launch_bounds__(256) lstm_persist_fwd_kernel(LstmFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_flag;
+  const int n = p.n, mb = p.mb;
+  const int ldw = n + 8;                                // padded LDS row length (elements): rows start 16 bytes apart mod 128
+  bf16_t* Wl = (bf16_t*)smem;                           // [32][ldw]
+  bf16_t* hl = Wl + 32 * ldw;                           // [mbp][ldw], mbp = mb rounded up to 32
+  const int mbp = (mb + 31) & ~31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * 8;
+  const int nch = n >> 3;                               // 16-byte chunks per row
+
+  // recurrent weight slice -> LDS (once); row gc = g*8 + k is gate column g*n + u0 + k
+  for (int i = tid; i < 32 * nch; i += 256) {
+    const int gc = i / nch, ch = i - gc * nch;
+    const int64_t col = (int64_t)(gc >> 3) * n + u0 + (gc & 7);
+    *(uint4*)(Wl + gc * ldw + ch * 8) = *(const uint4*)(p.rw4 + col * p.ld_rw + ch * 8);
+  }
+  // rows beyond mb stay zero for the whole kernel
+  for (int i = tid; i < (mbp - mb) * nch; i += 256) {
+    const int r = mb + i / nch, ch = i % nch;
+    *(uint4*)(hl + r * ldw + ch * 8) = make_uint4(0, 0, 0, 0);
+  }
+
+  const int row = wave * 32 + (lane & 31);              // batch row of this lane (valid when < mb and wave tile in range)
+  const int kq = lane >> 5;                             // 0 / 1: which 8-wide K chunk of a 16-wide MFMA step, and unit quad
+  const int uq = u0 + kq * 4;                           // first of this lane's 4 hidden units
+  const bool tile_on = wave * 32 < mb;
+  const bool row_on = tile_on && row < mb;
+  float c_state[4] = {0.f, 0.f, 0.f, 0.f};
+  if (row_on) unpack4(*(const uint64_t*)(p.c0 + (int64_t)row * n + uq), c_state);
+  float wpf[4] = {0, 0, 0, 0}, wpo[4] = {0, 0, 0, 0}, wpg[4] = {0, 0, 0, 0};
+  if (p.pf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wpf[j] = p.pf[uq + j]; wpo[j] = p.po[uq + j]; wpg[j] = p.pg[uq + j]; }
+  }
+
+  const bf16_t* hprev = p.h0;
+  for (int s = 0; s < p.T; ++s) {
+    const int t = p.reverse ? p.T - 1 - s : s;
+    // (1) issue this lane's input-projection loads early: 4 gates x 4 units
+    uint64_t xwv[4] = {0, 0, 0, 0};
+    float mk = 1.f;
+    if (row_on) {
+      const bf16_t* xr = p.xw + ((int64_t)t * mb + row) * 4 * n + uq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xwv[g] = *(const uint64_t*)(xr + (int64_t)g * n);
+      if (p.maskT) mk = p.maskT[(int64_t)t * mb + row];
+    }
+    // (2) h_{t-1} -> LDS
+    for (int i = tid; i < mb * nch; i += 256) {
+      const int r = i / nch, ch = i - r * nch;
+      *(uint4*)(hl + r * ldw + ch * 8) = *(const uint4*)(hprev + (int64_t)r * n + ch * 8);
+    }
+    __syncthreads();
+    // (3) gates^T tile = Wslice x h^T over K = n
+    if (tile_on) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const bf16_t* ap = Wl + (lane & 31) * ldw + kq * 8;
+      const bf16_t* bp = hl + (wave * 32 + (lane & 31)) * ldw + kq * 8;
+#pragma unroll 4
+      for (int k = 0; k < n; k += 16) {
+        const bf16x8_t a = *(const bf16x8_t*)(ap + k);
+        const bf16x8_t b = *(const bf16x8_t*)(bp + k);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+      // (4) cell update in registers: acc[4*g + j] = pre-activation of gate g, unit uq + j, batch row `row`
+      if (row_on) {
+        float xa[4], xf[4], xo[4], xg[4];
+        unpack4(xwv[0], xa); unpack4(xwv[1], xf); unpack4(xwv[2], xo); unpack4(xwv[3], xg);
+        float hn[4], cn[4], va[4], vf[4], vo[4], vg[4], vac[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float cp = c_state[j];
+          const float za = acc[j] + xa[j];
+          float zf = acc[4 + j] + xf[j], zo = acc[8 + j] + xo[j], zg = acc[12 + j] + xg[j];
+          if (p.pf) { zf += cp * wpf[j]; zg += cp * wpg[j]; }
+          const float a = tanh_fast(za), f = sigm(zf), g = sigm(zg);
+          const float c = f * cp + g * a;
+          if (p.pf) zo += c * wpo[j];
+          const float o = sigm(zo), ac = tanh_fast(c);
+          va[j] = a; vf[j] = f; vo[j] = o; vg[j] = g; vac[j] = ac;
+          cn[j] = c;
+          hn[j] = o * ac * mk;
+          c_state[j] = c * mk;
+        }
+        const int64_t o_idx = ((int64_t)t * mb + row) * n + uq;
+        st_agent_u64(p.H + o_idx, pack4(hn[0], hn[1], hn[2], hn[3]));
+        *(uint64_t*)(p.Cs + o_idx) = pack4(c_state[0], c_state[1], c_state[2], c_state[3]);
+        if (p.SV) {
+          bf16_t* sv = p.SV + ((int64_t)t * mb + row) * 6 * n + uq;
+          *(uint64_t*)(sv) = pack4(va[0], va[1], va[2], va[3]);
+          *(uint64_t*)(sv + n) = pack4(vf[0], vf[1], vf[2], vf[3]);
+          *(uint64_t*)(sv + 2 * (int64_t)n) = pack4(vo[0], vo[1], vo[2], vo[3]);
+          *(uint64_t*)(sv + 3 * (int64_t)n) = pack4(vg[0], vg[1], vg[2], vg[3]);
+          *(uint64_t*)(sv + 4 * (int64_t)n) = pack4(cn[0], cn[1], cn[2], cn[3]);
+          *(uint64_t*)(sv + 5 * (int64_t)n) = pack4(vac[0], vac[1], vac[2], vac[3]);
+        }
+      }
+    }
+    hprev = p.H + (int64_t)t * mb * n;
+    // (5) everybody's h_t slice must be in memory before anybody starts step s+1 (the last step needs no barrier)
+    if (s + 1 < p.T) {
+      if (!grid_barrier(p.bar, (unsigned)(s + 1) * gridDim.x, &s_flag)) return;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------ backward
+// Same ownership (workgroup w = hidden units [8w, 8w+8)). Per step, walking the sequence backwards:
+//   dh_t   = E_t + dG_{t+1} . RW4^T           (recurrent part: K = 4n, streamed from the dG rows every workgroup wrote last step)
+//   dG_t, dc_{t-1} = cell_backward(dh_t, dc_t, saved gate activations)          (registers; dc never leaves the lane)
+// The recurrent product uses v_mfma_f32_16x16x32_bf16 with A = this workgroup's 8 rows of RW4^T [n, 4n] from LDS (rows 8..15 of the
+// MFMA tile repeat them) and B = 16 batch rows of dG_{t+1} loaded straight from global memory (each workgroup has to see all 4n gate
+// gradients, 256 KB per step at n = 512, mb = 64: that L2 stream is the cost of the step). In the 16x16 accumulator layout lane l
+// holds batch row l%16 and units 4*(l/16)+j, so lanes 0..31 of every wave own (row, 4 units) exactly as in the forward kernel.
+struct LstmBwdP {
+  const bf16_t* E;         // [T, mb, n] dL/dh_t from the layers above
+  const bf16_t* rw4t;      // [n, ld_rwt] row j = the 4n gate weights leaving hidden unit j
+  int64_t ld_rwt;
+  const bf16_t* SV;        // [T, mb, 6n] saved a, f, o, g, c, tanh(c)
+  const bf16_t* Cs;        // [T, mb, n]
+  const bf16_t* c0;        // [mb, n]
+  const float* pf;
+  const float* po;
+  const float* pg;
+  const float* maskT;      // [T, mb] or null
+  bf16_t* dG;              // [T, mb, 4n]
+  float* dpeep;            // [3, n] accumulated with atomics, or null
+  unsigned* bar;
+  int T, mb, n, reverse;
+};
+
+#define BWD_TILES 2         // 16-row batch tiles per wave: mb <= 4 waves * 2 * 16 = 128
+
+__global__ void __launch_bounds__(256) lstm_persist_bwd_kernel(LstmBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_flag;
+  const int n = p.n, mb = p.mb, K = 4 * p.n;
+  const int ldw = K + 32;                                 // row stride = 16 banks mod 64
+  bf16_t* Wb = (bf16_t*)smem;                             // [8][ldw]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * 8;
+  const int kch = K >> 3;
+  for (int i = tid; i < 8 * kch; i += 256) {
+    const int r = i / kch, ch = i - r * kch;
+    *(uint4*)(Wb + r * ldw + ch * 8) = *(const uint4*)(p.rw4t + (int64_t)(u0 + r) * p.ld_rwt + ch * 8);
+  }
+  __syncthreads();
+
+  const int bcol = lane & 15, q = lane >> 4;
+  const bool unit_lane = q < 2;                           // lanes 32..63 hold the duplicate MFMA rows
+  const int uq = u0 + (q & 1) * 4;
+  float dc_state[BWD_TILES][4];
+  float apf[4] = {0, 0, 0, 0}, apo[4] = {0, 0, 0, 0}, apg[4] = {0, 0, 0, 0};
+  float wpf[4] = {0, 0, 0, 0}, wpo[4] = {0, 0, 0, 0}, wpg[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int tt = 0; tt < BWD_TILES; ++tt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dc_state[tt][j] = 0.f;
+  if (p.pf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wpf[j] = p.pf[uq + j]; wpo[j] = p.po[uq + j]; wpg[j] = p.pg[uq + j]; }
+  }
+  const bf16_t* ap = Wb + (bcol & 7) * ldw + q * 8;
+
+  for (int s = p.T - 1; s >= 0; --s) {
+    const int t = p.reverse ? p.T - 1 - s : s;
+    const int t_prev = p.reverse ? t + 1 : t - 1;
+    const int t_next = p.reverse ? t - 1 : t + 1;         // the step handled in the previous iteration of this loop
+#pragma unroll
+    for (int tt = 0; tt < BWD_TILES; ++tt) {
+      const int tile = wave + 4 * tt;
+      if (tile * 16 >= mb) continue;
+      const int row = tile * 16 + bcol;
+      const bool row_ok = row < mb;
+      const bool act = unit_lane && row_ok;
+      // saved activations / eps / previous cell state of this lane's (row, 4 units): issued before the recurrent product
+      uint64_t ev = 0, sva = 0, svf = 0, svo = 0, svg = 0, svc = 0, svac = 0, cpv = 0;
+      float mk = 1.f;
+      if (act) {
+        const int64_t hidx = ((int64_t)t * mb + row) * n + uq;
+        ev = *(const uint64_t*)(p.E + hidx);
+        const bf16_t* sv = p.SV + ((int64_t)t * mb + row) * 6 * n + uq;
+        sva = *(const uint64_t*)(sv); svf = *(const uint64_t*)(sv + n); svo = *(const uint64_t*)(sv + 2 * (int64_t)n);
+        svg = *(const uint64_t*)(sv + 3 * (int64_t)n); svc = *(const uint64_t*)(sv + 4 * (int64_t)n);
+        svac = *(const uint64_t*)(sv + 5 * (int64_t)n);
+        cpv = s == 0 ? *(const uint64_t*)(p.c0 + (int64_t)row * n + uq) : *(const uint64_t*)(p.Cs + ((int64_t)t_prev * mb + row) * n + uq);
+        if (p.maskT) mk = p.maskT[(int64_t)t * mb + row];
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (s < p.T - 1) {
+        const bf16_t* bp = p.dG + ((int64_t)t_next * mb + (row_ok ? row : 0)) * K + q * 8;
+        // no divergent branch around MFMAs (they do not honour EXEC): rows beyond mb read row 0 and are zeroed by a select
+        const bf16x8_t zero = {};
+#pragma unroll 8
+        for (int k = 0; k < K; k += 32) {
+          const bf16x8_t a = *(const bf16x8_t*)(ap + k);
+          bf16x8_t b = *(const bf16x8_t*)(bp + k);
+          b = row_ok ? b : zero;
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+        }
+      }
+      if (act) {
+        float e4[4], a4[4], f4[4], o4[4], g4[4], c4[4], ac4[4], cp4[4];
+        unpack4(ev, e4); unpack4(sva, a4); unpack4(svf, f4); unpack4(svo, o4); unpack4(svg, g4); unpack4(svc, c4); unpack4(svac, ac4);
+        unpack4(cpv, cp4);
+        float dza[4], dzf[4], dzo[4], dzg[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d_h = (e4[j] + acc[j]) * mk;
+          const float d_cn = dc_state[tt][j] * mk;
+          const float a = a4[j], f = f4[j], o = o4[j], g = g4[j], ac = ac4[j], cp = cp4[j];
+          dzo[j] = d_h * ac * o * (1.f - o);
+          float dc = d_cn + d_h * o * (1.f - ac * ac);
+          if (p.pf) dc += dzo[j] * wpo[j];
+          dza[j] = dc * g * (1.f - a * a);
+          dzf[j] = dc * cp * f * (1.f - f);
+          dzg[j] = dc * a * g * (1.f - g);
+          float dcp = dc * f;
+          if (p.pf) {
+            dcp += dzf[j] * wpf[j] + dzg[j] * wpg[j];
+            apf[j] += dzf[j] * cp; apo[j] += dzo[j] * c4[j]; apg[j] += dzg[j] * cp;
+          }
+          dc_state[tt][j] = dcp;
+        }
+        bf16_t* dg = p.dG + ((int64_t)t * mb + row) * K + uq;
+        st_agent_u64(dg, pack4(dza[0], dza[1], dza[2], dza[3]));
+        st_agent_u64(dg + n, pack4(dzf[0], dzf[1], dzf[2], dzf[3]));
+        st_agent_u64(dg + 2 * (int64_t)n, pack4(dzo[0], dzo[1], dzo[2], dzo[3]));
+        st_agent_u64(dg + 3 * (int64_t)n, pack4(dzg[0], dzg[1], dzg[2], dzg[3]));
+      }
+    }
+    if (s > 0) {
+      if (!grid_barrier(p.bar, (unsigned)(p.T - s) * gridDim.x, &s_flag)) return;
+    }
+  }
+  // peephole gradients: reduce over the 16 batch columns of the lane group, then one atomic per unit and wave
+  if (p.pf && p.dpeep) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float vf = apf[j], vo = apo[j], vg = apg[j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { vf += __shfl_xor(vf, o, 64); vo += __shfl_xor(vo, o, 64); vg += __shfl_xor(vg, o, 64); }
+      if (unit_lane && bcol == 0) {
+        atomicAdd(p.dpeep + uq + j, vf);
+        atomicAdd(p.dpeep + n + uq + j, vo);
+        atomicAdd(p.dpeep + 2 * n + uq + j, vg);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dl4j_fill_zero_bytes(void* p, size_t bytes, hipStream_t st);
+
+// LDS bytes of the forward kernel; 0 when the shape is not supported
+static int lstm_persist_fwd_lds(int mb, int n) {
+  if (n <= 0 || mb <= 0 || n % 8 != 0 || n / 8 > 256 || mb > 128) return 0;
+  const int mbp = (mb + 31) & ~31;
+  const int64_t bytes = (int64_t)(32 + mbp) * (n + 8) * 2;
+  return bytes <= 156 * 1024 ? (int)bytes : 0;     // leave room for the static LDS of the barrier flag
+}
+
+static int lstm_persist_bwd_lds(int mb, int n);
+DL4J_API int dl4j_lstm_persist_supported(int mb, int n) { return (lstm_persist_fwd_lds(mb, n) > 0 && lstm_persist_bwd_lds(mb, n) > 0) ? 1 : 0; }
+
+// bar: 2 x uint32 device scratch, zeroed here (stream ordered). Returns -2 for an unsupported shape.
+DL4J_API int dl4j_lstm_persist_fwd(const void* xw, const void* rw4, int64_t ld_rw, const void* h0, const void* c0, const float* pf,
+                                   const float* po, const float* pg, const float* maskT, void* H, void* Cs, void* SV, unsigned* bar, int T,
+                                   int mb, int n, int reverse, hipStream_t st) {
+  if (T <= 0) return 0;
+  const int lds = lstm_persist_fwd_lds(mb, n);
+  if (lds == 0 || ld_rw % 8 != 0 || ((uintptr_t)rw4 & 15) || ((uintptr_t)h0 & 15) || ((uintptr_t)H & 15) || ((uintptr_t)xw & 7)) return -2;
+  if ((pf != nullptr) != (po != nullptr) || (pf != nullptr) != (pg != nullptr)) return -2;
+  static DeviceOnceLds lds_attr;
+  lds_attr.ensure((const void*)lstm_persist_fwd_kernel, lds);
+  // a fill kernel, not hipMemsetAsync: memset nodes misbehaved on replay inside captured graphs (see rnn_seq.hip)
+  const int zrc = dl4j_fill_zero_bytes(bar, 2 * sizeof(unsigned), st);
+  if (zrc) return zrc;
+  LstmFwdP p{(const bf16_t*)xw, (const bf16_t*)rw4, ld_rw, (const bf16_t*)h0, (const bf16_t*)c0, pf, po, pg, maskT,
+             (bf16_t*)H, (bf16_t*)Cs, (bf16_t*)SV, bar, T, mb, n, reverse};
+  hipLaunchKernelGGL(lstm_persist_fwd_kernel, dim3(n / 8), dim3(256), lds, st, p);
+  DL4J_RET_LAST();
+}
+
+static int lstm_persist_bwd_lds(int mb, int n) {
+  if (n <= 0 || mb <= 0 || n % 8 != 0 || n / 8 > 256 || mb > 64 * BWD_TILES) return 0;
+  const int64_t bytes = (int64_t)8 * (4 * n + 32) * 2;
+  return bytes <= 156 * 1024 ? (int)bytes : 0;
+}
+
+// dpeep [3, n] fp32 must be zeroed by the caller (accumulated); bar: 2 x uint32 scratch zeroed here.
+DL4J_API int dl4j_lstm_persist_bwd(const void* E, const void* rw4t, int64_t ld_rwt, const void* SV, const void* Cs, const void* c0,
+                                   const float* pf, const float* po, const float* pg, const float* maskT, void* dG, float* dpeep, unsigned* bar,
+                                   int T, int mb, int n, int reverse, hipStream_t st) {
+  if (T <= 0) return 0;
+  const int lds = lstm_persist_bwd_lds(mb, n);
+  if (lds == 0 || ld_rwt % 8 != 0 || ((uintptr_t)rw4t & 15) || ((uintptr_t)dG & 15) || ((uintptr_t)E & 7) || ((uintptr_t)SV & 7) ||
+      ((uintptr_t)Cs & 7) || ((uintptr_t)c0 & 7))
+    return -2;
+  if ((pf != nullptr) != (po != nullptr) || (pf != nullptr) != (pg != nullptr)) return -2;
+  static DeviceOnceLds lds_attr;
+  lds_attr.ensure((const void*)lstm_persist_bwd_kernel, lds);
+  // a fill kernel, not hipMemsetAsync: memset nodes misbehaved on replay inside captured graphs (see rnn_seq.hip)
+  const int zrc = dl4j_fill_zero_bytes(bar, 2 * sizeof(unsigned), st);
+  if (zrc) return zrc;
+  LstmBwdP p{(const bf16_t*)E, (const bf16_t*)rw4t, ld_rwt, (const bf16_t*)SV, (const bf16_t*)Cs, (const bf16_t*)c0, pf, po, pg, maskT,
+             (bf16_t*)dG, dpeep, bar, T, mb, n, reverse};
+  hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(n / 8), dim3(256), lds, st, p);
+  DL4J_RET_LAST();
+}

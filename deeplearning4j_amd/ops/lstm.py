@@ -7,6 +7,8 @@ IActivation (used on CPU, fp64 gradient checks and exotic activations).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ..nd4j.activations import ActivationSigmoid, ActivationTanH
@@ -100,6 +102,15 @@ def native_seq_ok(xw, RW4, n, act, gate_act):
     return n % ch == 0 and RW4.dtype == xw.dtype and RW4.t().is_contiguous() and RW4.data_ptr() % 16 == 0
 
 
+_PERSIST = os.environ.get("DL4J_AMD_LSTM_PERSIST", "1") == "1"
+_PERSIST_CHECK = os.environ.get("DL4J_AMD_LSTM_PERSIST_CHECK", "0") == "1"
+
+
+def persist_ok(xw, RW4, mb, n):
+    """bf16 sequences whose shape the persistent kernel supports (n % 8 == 0, n <= 2048, mb <= 128, weights + hidden state fit LDS)."""
+    return _PERSIST and xw.dtype == torch.bfloat16 and RW4.dtype == torch.bfloat16 and bool(L.hip().dl4j_lstm_persist_supported(L.c_int(mb), L.c_int(n)))
+
+
 def seq_forward(xw, RW4, h0, c0, peep, mask, train, reverse):
     """xw [T, mb, 4n]. Returns (H [T, mb, n], state dict for seq_backward)."""
     T, mb, n4 = xw.shape
@@ -114,6 +125,15 @@ def seq_forward(xw, RW4, h0, c0, peep, mask, train, reverse):
         pf, po, pg = (p.contiguous().float() for p in peep)
     maskT = mask.to(dev).t().contiguous().float() if mask is not None else None
     h0c, c0c = h0.to(dt).contiguous(), c0.to(dt).contiguous()
+    if persist_ok(xw, RW4, mb, n):
+        # one launch for the whole sequence (native/csrc/lstm_persist.hip): weights resident in LDS, cell state in registers
+        bar = torch.empty(2, device=dev, dtype=torch.int32)
+        L.check(L.hip().dl4j_lstm_persist_fwd(L.ptr(xw), L.ptr(RW4), L.c_int64(n), L.ptr(h0c), L.ptr(c0c), L.ptr(pf), L.ptr(po), L.ptr(pg),
+                                              L.ptr(maskT), L.ptr(H), L.ptr(Cs), L.ptr(SV), L.ptr(bar), L.c_int(T), L.c_int(mb), L.c_int(n),
+                                              L.c_int(1 if reverse else 0), L.stream()), "lstm_persist_fwd")
+        if _PERSIST_CHECK and int(bar[1]) != 0:
+            raise RuntimeError("lstm_persist_fwd: grid barrier timed out (workgroups were not co-resident)")
+        return H, {"H": H, "Cs": Cs, "SV": SV, "h0": h0c, "c0": c0c, "peep": (pf, po, pg), "maskT": maskT}
     L.check(L.hip().dl4j_lstm_seq_fwd(L.ptr(xw), L.ptr(RW4), L.c_int64(n), L.ptr(h0c), L.ptr(c0c), L.ptr(pf), L.ptr(po), L.ptr(pg),
                                       L.ptr(maskT), L.ptr(H), L.ptr(Cs), L.ptr(SV), L.ptr(ws), L.c_int(T), L.c_int(mb), L.c_int(n),
                                       L.c_int(L.dtype_code(xw)), L.c_int(1 if reverse else 0), L.stream()), "lstm_seq_fwd")
@@ -129,18 +149,29 @@ def seq_backward(E, RW4, st, reverse):
     dG = torch.empty(T, mb, 4 * n, device=dev, dtype=dt)
     pf, po, pg = st["peep"]
     dpeep = torch.zeros(3, n, device=dev, dtype=torch.float32) if pf is not None else None
+    if persist_ok(E, rw4t, mb, n) and st["SV"] is not None:
+        bar = torch.empty(2, device=dev, dtype=torch.int32)
+        L.check(L.hip().dl4j_lstm_persist_bwd(L.ptr(E), L.ptr(rw4t), L.c_int64(4 * n), L.ptr(st["SV"]), L.ptr(st["Cs"]), L.ptr(st["c0"]),
+                                              L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(bar),
+                                              L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()), "lstm_persist_bwd")
+        if _PERSIST_CHECK and int(bar[1]) != 0:
+            raise RuntimeError("lstm_persist_bwd: grid barrier timed out (workgroups were not co-resident)")
+        return dG, _hprev(st, reverse), (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
     dh_ws = torch.empty(mb, n, device=dev, dtype=dt)
     dc_ws = torch.empty(2, mb, n, device=dev, dtype=dt)
     L.check(L.hip().dl4j_lstm_seq_bwd(L.ptr(E), L.ptr(rw4t), L.c_int64(4 * n), L.ptr(st["SV"]), L.ptr(st["Cs"]), L.ptr(st["c0"]),
                                       L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(dh_ws),
                                       L.ptr(dc_ws), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(L.dtype_code(E)),
                                       L.c_int(1 if reverse else 0), L.stream()), "lstm_seq_bwd")
+    return dG, _hprev(st, reverse), (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
+
+
+def _hprev(st, reverse):
+    """Hidden state that fed every step: H shifted by one step with h0 at the sequence start."""
     H, h0 = st["H"], st["h0"]
     if reverse:
-        Hprev = torch.cat([H[1:], h0.unsqueeze(0)], 0)
-    else:
-        Hprev = torch.cat([h0.unsqueeze(0), H[:-1]], 0)
-    return dG, Hprev, (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
+        return torch.cat([H[1:], h0.unsqueeze(0)], 0)
+    return torch.cat([h0.unsqueeze(0), H[:-1]], 0)
 
 
 # ------------------------------------------------------------------------------------------------------ GRU (libnd4j gru / gruCell)

@@ -88,3 +88,116 @@ def test_gru_op_native_loop_matches_reference_math(dtype):
     gg = torch.autograd.grad(out, ins, dH.to(dtype))
     for a_, r_ in zip(gg, rg):
         assert (a_.float() - r_).abs().max().item() < tol * max(1.0, r_.abs().max().item()) * (1 if dtype == torch.float32 else 4)
+
+
+def _seq_case(T, mb, n, peep, masked, seed):
+    g = torch.Generator().manual_seed(seed)
+    xw = (torch.randn(T, mb, 4 * n, generator=g) * 0.5).bfloat16().cuda()
+    rw4 = (torch.randn(4 * n, n, generator=g) / n ** 0.5).bfloat16().cuda()
+    RW4 = rw4.t()                                   # DL4J 'f'-order [n, 4n] whose memory image is the [4n, n] operand
+    h0 = (torch.randn(mb, n, generator=g) * 0.3).bfloat16().cuda()
+    c0 = (torch.randn(mb, n, generator=g) * 0.3).bfloat16().cuda()
+    pp = [(torch.randn(n, generator=g) * 0.2).cuda() for _ in range(3)] if peep else None
+    mask = (torch.rand(mb, T, generator=g) > 0.2).float().cuda() if masked else None
+    return xw, RW4, h0, c0, pp, mask
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,mb,n,peep,masked,reverse", [(7, 64, 512, False, False, False), (5, 33, 128, True, True, False),
+                                                        (6, 100, 256, True, False, True), (1, 8, 64, False, True, False),
+                                                        (50, 64, 512, False, False, False)])
+def test_lstm_persistent_forward_matches_per_step_kernels(monkeypatch, T, mb, n, peep, masked, reverse):
+    """One-launch persistent sequence kernel (lstm_persist.hip) against the per-step GEMM + cell kernels, and both against fp32 torch math."""
+    from deeplearning4j_amd.ops import lstm as R
+    xw, RW4, h0, c0, pp, mask = _seq_case(T, mb, n, peep, masked, 11)
+    monkeypatch.setattr(R, "_PERSIST", True)
+    monkeypatch.setattr(R, "_PERSIST_CHECK", True)
+    assert R.persist_ok(xw, RW4, mb, n)
+    Hp, stp = R.seq_forward(xw, RW4, h0, c0, pp, mask, True, reverse)
+    monkeypatch.setattr(R, "_PERSIST", False)
+    Hs, sts = R.seq_forward(xw, RW4, h0, c0, pp, mask, True, reverse)
+    # fp32 reference of the recurrence
+    W = RW4.float()
+    h, c = h0.float(), c0.float()
+    Href = torch.zeros(T, mb, n, device="cuda")
+    for s in range(T):
+        t = T - 1 - s if reverse else s
+        z = xw[t].float() + h @ W
+        za, zf, zo, zg = z[:, :n], z[:, n:2 * n], z[:, 2 * n:3 * n], z[:, 3 * n:]
+        if pp:
+            zf, zg = zf + c * pp[0], zg + c * pp[2]
+        a, f, g_ = torch.tanh(za), torch.sigmoid(zf), torch.sigmoid(zg)
+        cn = f * c + g_ * a
+        if pp:
+            zo = zo + cn * pp[1]
+        hn = torch.sigmoid(zo) * torch.tanh(cn)
+        if mask is not None:
+            m = mask[:, t].unsqueeze(1)
+            hn, cn = hn * m, cn * m
+        # the kernels carry h / c between steps in bf16
+        h, c = hn.bfloat16().float(), cn.bfloat16().float()
+        Href[t] = hn
+    tol = dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(Hp.float(), Href, **tol)
+    torch.testing.assert_close(Hs.float(), Href, **tol)
+    torch.testing.assert_close(Hp.float(), Hs.float(), **tol)
+    torch.testing.assert_close(stp["Cs"].float(), sts["Cs"].float(), **tol)
+    torch.testing.assert_close(stp["SV"].float(), sts["SV"].float(), **tol)
+    assert float((Hp.float() - Href).abs().mean()) < 3e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,mb,n,peep,masked,reverse", [(7, 64, 512, False, False, False), (5, 33, 128, True, True, False),
+                                                        (6, 100, 256, True, False, True), (1, 8, 64, False, True, False),
+                                                        (50, 64, 512, True, True, False)])
+def test_lstm_persistent_backward_matches_per_step_kernels_and_autograd(monkeypatch, T, mb, n, peep, masked, reverse):
+    """Persistent backward kernel: gate gradients + peephole gradients against the per-step kernels, and against torch autograd of
+    the fp32 recurrence (same saved forward in both kernel paths)."""
+    from deeplearning4j_amd.ops import lstm as R
+    xw, RW4, h0, c0, pp, mask = _seq_case(T, mb, n, peep, masked, 17)
+    g = torch.Generator().manual_seed(5)
+    E = (torch.randn(T, mb, n, generator=g) * 0.5).bfloat16().cuda()
+    monkeypatch.setattr(R, "_PERSIST_CHECK", True)
+    monkeypatch.setattr(R, "_PERSIST", True)
+    H, st = R.seq_forward(xw, RW4, h0, c0, pp, mask, True, reverse)
+    dGp, Hprev_p, dpp = R.seq_backward(E, RW4, st, reverse)
+    monkeypatch.setattr(R, "_PERSIST", False)
+    dGs, Hprev_s, dps = R.seq_backward(E, RW4, st, reverse)
+    assert torch.equal(Hprev_p, Hprev_s)
+    # autograd reference in fp32 on the same inputs
+    xw32 = xw.float().requires_grad_(True)
+    W = RW4.float()
+    ppr = [q.clone().requires_grad_(True) for q in pp] if pp else None
+    h, c = h0.float(), c0.float()
+    Hs_ = [None] * T
+    for s in range(T):
+        t = T - 1 - s if reverse else s
+        z = xw32[t] + h @ W
+        za, zf, zo, zg = z[:, :n], z[:, n:2 * n], z[:, 2 * n:3 * n], z[:, 3 * n:]
+        if ppr:
+            zf, zg = zf + c * ppr[0], zg + c * ppr[2]
+        a, f, g_ = torch.tanh(za), torch.sigmoid(zf), torch.sigmoid(zg)
+        cn = f * c + g_ * a
+        if ppr:
+            zo = zo + cn * ppr[1]
+        hn = torch.sigmoid(zo) * torch.tanh(cn)
+        if mask is not None:
+            m = mask[:, t].unsqueeze(1)
+            hn, cn = hn * m, cn * m
+        h, c = hn, cn
+        Hs_[t] = hn
+    (torch.stack(Hs_) * E.float()).sum().backward()
+    ref = xw32.grad
+    scale = float(ref.abs().mean())
+    for dG in (dGp, dGs):
+        err = (dG.float() - ref).abs()
+        assert float(err.mean()) < 0.03 * scale + 1e-4, (float(err.mean()), scale)
+        assert float(err.max()) < 0.25 * float(ref.abs().max()) + 1e-2
+    assert float((dGp.float() - dGs.float()).abs().mean()) < 0.02 * scale + 1e-4
+    # the persistent kernel keeps dc / dh in fp32 between steps: it must be at least as close to autograd as the bf16 per-step path
+    assert float((dGp.float() - ref).abs().mean()) <= float((dGs.float() - ref).abs().mean()) * 1.05 + 1e-5
+    if pp:
+        for k, q in enumerate((0, 1, 2)):
+            refp = ppr[q].grad
+            torch.testing.assert_close(dpp[k], refp, rtol=0.08, atol=0.05 * float(refp.abs().max()) + 1e-3)
+            torch.testing.assert_close(dps[k], refp, rtol=0.08, atol=0.05 * float(refp.abs().max()) + 1e-3)
