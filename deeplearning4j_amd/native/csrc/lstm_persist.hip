@@ -21,6 +21,7 @@
 //     abort flag that every workgroup observes, so the grid always drains.
 // Requirements checked on the host: n % 8 == 0, n / 8 <= 256 workgroups (all co-resident on 256 CUs), mb <= 128, LDS fits.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -51,6 +52,7 @@ struct LstmFwdP {
 };
 
 #define SPIN_LIMIT (1 << 22)
+#define LL_BATCH 16           // polled 8-byte words in flight per thread
 
 // one grid barrier; returns false when the kernel must abort. All threads of the block call it.
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int* s_flag) {
@@ -80,6 +82,16 @@ __device__ __forceinline__ void st_agent_u64(void* p, uint64_t v) {
   __hip_atomic_store((uint64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ uint64_t ld_agent_u64(const void* p) {
+  return __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// "Data is its own flag" hand-off (the idea of NCCL's LL protocol without the flag word): the exchange buffer is filled with a
+// bit pattern that valid data never takes (four bf16 NaNs with all bits set), producers publish 8-byte words with single-copy
+// atomic write-through stores, consumers poll the words they need until none of them is the sentinel. One store + one load
+// latency per step instead of store-ack, counter add, counter poll and an L2 invalidate.
+#define LL_SENTINEL 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ uint64_t ll_clean(uint64_t w) { return w == LL_SENTINEL ? 0x7FC07FC07FC07FC0ull : w; }
+
 __device__ __forceinline__ uint64_t pack4(float a, float b, float c, float d) {
   return (uint64_t)f2bf(a) | ((uint64_t)f2bf(b) << 16) | ((uint64_t)f2bf(c) << 32) | ((uint64_t)f2bf(d) << 48);
 }
@@ -88,7 +100,8 @@ __device__ __forceinline__ void unpack4(uint64_t v, float o[4]) {
   o[2] = bf2f((bf16_t)((v >> 32) & 0xffff)); o[3] = bf2f((bf16_t)(v >> 48));
 }
 
-__global__ void __launch_bounds__(256) lstm_persist_fwd_kernel(LstmFwdP p) {
+#define FWD_THREADS 512
+__global__ void __launch_bounds__(FWD_THREADS) lstm_persist_fwd_kernel(LstmFwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_flag;
   const int n = p.n, mb = p.mb;
@@ -101,13 +114,13 @@ __global__ void __launch_bounds__(256) lstm_persist_fwd_kernel(LstmFwdP p) {
   const int nch = n >> 3;                               // 16-byte chunks per row
 
   // recurrent weight slice -> LDS (once); row gc = g*8 + k is gate column g*n + u0 + k
-  for (int i = tid; i < 32 * nch; i += 256) {
+  for (int i = tid; i < 32 * nch; i += FWD_THREADS) {
     const int gc = i / nch, ch = i - gc * nch;
     const int64_t col = (int64_t)(gc >> 3) * n + u0 + (gc & 7);
     *(uint4*)(Wl + gc * ldw + ch * 8) = *(const uint4*)(p.rw4 + col * p.ld_rw + ch * 8);
   }
   // rows beyond mb stay zero for the whole kernel
-  for (int i = tid; i < (mbp - mb) * nch; i += 256) {
+  for (int i = tid; i < (mbp - mb) * nch; i += FWD_THREADS) {
     const int r = mb + i / nch, ch = i % nch;
     *(uint4*)(hl + r * ldw + ch * 8) = make_uint4(0, 0, 0, 0);
   }
@@ -127,7 +140,7 @@ __global__ void __launch_bounds__(256) lstm_persist_fwd_kernel(LstmFwdP p) {
 
   const bf16_t* hprev = p.h0;
   for (int s = 0; s < p.T; ++s) {
-    const int t = p.reverse ? p.T - 1 - s : s;
+    const int t = (p.reverse & 1) ? p.T - 1 - s : s;
     // (1) issue this lane's input-projection loads early: 4 gates x 4 units
     uint64_t xwv[4] = {0, 0, 0, 0};
     float mk = 1.f;
@@ -137,12 +150,46 @@ __global__ void __launch_bounds__(256) lstm_persist_fwd_kernel(LstmFwdP p) {
       for (int g = 0; g < 4; ++g) xwv[g] = *(const uint64_t*)(xr + (int64_t)g * n);
       if (p.maskT) mk = p.maskT[(int64_t)t * mb + row];
     }
-    // (2) h_{t-1} -> LDS
-    for (int i = tid; i < mb * nch; i += 256) {
-      const int r = i / nch, ch = i - r * nch;
-      *(uint4*)(hl + r * ldw + ch * 8) = *(const uint4*)(hprev + (int64_t)r * n + ch * 8);
+    // (2) h_{t-1} -> LDS. Step 0 reads h0 (complete before the launch); later steps poll H[t_prev], which the launch pre-filled
+    //     with the sentinel and which the owning workgroups overwrite word by word.
+    int dead = 0;
+    if (s == 0 || (p.reverse & 2)) {                      // bit 1 of `reverse`: timing experiment, no hand-off (every step reads h0)
+      if (s == 0 || !(p.reverse & 8))
+      for (int i = tid; i < mb * nch; i += FWD_THREADS) {
+        const int r = i / nch, ch = i - r * nch;
+        *(uint4*)(hl + r * ldw + ch * 8) = *(const uint4*)(hprev + (int64_t)r * n + ch * 8);
+      }
+    } else {
+      const int wpr = n >> 2;                             // 8-byte words per row
+      const int words = mb * wpr;
+      for (int base = 0; base < words; base += FWD_THREADS * LL_BATCH) {
+        uint64_t v[LL_BATCH];
+#pragma unroll
+        for (int i = 0; i < LL_BATCH; ++i) {
+          const int w = base + i * FWD_THREADS + tid;
+          v[i] = w < words ? ld_agent_u64(hprev + (int64_t)w * 4) : 0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < LL_BATCH; ++i) {
+          const int w = base + i * FWD_THREADS + tid;
+          if (w >= words) continue;
+          int spins = 0;
+          while (v[i] == LL_SENTINEL) {
+            __builtin_amdgcn_s_sleep(1);
+            v[i] = ld_agent_u64(hprev + (int64_t)w * 4);
+            if (++spins > SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(p.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+              __hip_atomic_store(p.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              v[i] = 0ull;                                 // abort: results are void, the host sees the flag
+              dead = 1;
+              break;
+            }
+          }
+          const int r = w / wpr, c4 = w - r * wpr;
+          *(uint64_t*)(hl + r * ldw + c4 * 4) = v[i];
+        }
+      }
     }
-    __syncthreads();
+    if (__syncthreads_or(dead)) return;                   // a timed-out poll ends the whole workgroup; the others follow via the flag
     // (3) gates^T tile = Wslice x h^T over K = n
     if (tile_on) {
       f32x16 acc;
@@ -150,6 +197,7 @@ __global__ void __launch_bounds__(256) lstm_persist_fwd_kernel(LstmFwdP p) {
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
       const bf16_t* ap = Wl + (lane & 31) * ldw + kq * 8;
       const bf16_t* bp = hl + (wave * 32 + (lane & 31)) * ldw + kq * 8;
+      if (!(p.reverse & 16))
 #pragma unroll 4
       for (int k = 0; k < n; k += 16) {
         const bf16x8_t a = *(const bf16x8_t*)(ap + k);
@@ -177,9 +225,9 @@ __global__ void __launch_bounds__(256) lstm_persist_fwd_kernel(LstmFwdP p) {
           c_state[j] = c * mk;
         }
         const int64_t o_idx = ((int64_t)t * mb + row) * n + uq;
-        st_agent_u64(p.H + o_idx, pack4(hn[0], hn[1], hn[2], hn[3]));
-        *(uint64_t*)(p.Cs + o_idx) = pack4(c_state[0], c_state[1], c_state[2], c_state[3]);
-        if (p.SV) {
+        st_agent_u64(p.H + o_idx, ll_clean(pack4(hn[0], hn[1], hn[2], hn[3])));
+        if (!(p.reverse & 4)) *(uint64_t*)(p.Cs + o_idx) = pack4(c_state[0], c_state[1], c_state[2], c_state[3]);
+        if (p.SV && !(p.reverse & 4)) {
           bf16_t* sv = p.SV + ((int64_t)t * mb + row) * 6 * n + uq;
           *(uint64_t*)(sv) = pack4(va[0], va[1], va[2], va[3]);
           *(uint64_t*)(sv + n) = pack4(vf[0], vf[1], vf[2], vf[3]);
@@ -190,11 +238,9 @@ __global__ void __launch_bounds__(256) lstm_persist_fwd_kernel(LstmFwdP p) {
         }
       }
     }
-    hprev = p.H + (int64_t)t * mb * n;
-    // (5) everybody's h_t slice must be in memory before anybody starts step s+1 (the last step needs no barrier)
-    if (s + 1 < p.T) {
-      if (!grid_barrier(p.bar, (unsigned)(s + 1) * gridDim.x, &s_flag)) return;
-    }
+    if (!(p.reverse & 2)) hprev = p.H + (int64_t)t * mb * n;
+    // (5) no grid barrier: the next step polls the data. Only the LDS copy of h is shared inside the workgroup.
+    __syncthreads();
   }
 }
 
@@ -222,87 +268,114 @@ struct LstmBwdP {
   float* dpeep;            // [3, n] accumulated with atomics, or null
   unsigned* bar;
   int T, mb, n, reverse;
+  const bf16_t* dG_next;   // gate gradients of the step AFTER the last one of this launch (stepwise launches), or null
+  const float* dc_in;      // [mb, n] dL/dc flowing into the last step of this launch, or null (= 0)
+  float* dc_out;           // [mb, n] dL/dc leaving the first step of this launch, or null
 };
 
 #define BWD_TILES 2         // 16-row batch tiles per wave: mb <= 4 waves * 2 * 16 = 128
 
-__global__ void __launch_bounds__(256) lstm_persist_bwd_kernel(LstmBwdP p) {
+#define BWD_THREADS 1024    // 16 waves: wave = (K quarter, batch tile). All of a step's dG loads are in flight at once.
+__global__ void __launch_bounds__(BWD_THREADS) lstm_persist_bwd_kernel(LstmBwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_flag;
   const int n = p.n, mb = p.mb, K = 4 * p.n;
   const int ldw = K + 32;                                 // row stride = 16 banks mod 64
   bf16_t* Wb = (bf16_t*)smem;                             // [8][ldw]
+  f32x4* red = (f32x4*)(Wb + 8 * ldw);                    // [BWD_TILES][3][4 tiles][64 lanes] split-K partials of K quarters 1..3
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile0 = wave & 3, kq4 = wave >> 2;            // batch tile (of 16 rows) and K quarter of this wave
   const int u0 = blockIdx.x * 8;
   const int kch = K >> 3;
-  for (int i = tid; i < 8 * kch; i += 256) {
+  for (int i = tid; i < 8 * kch; i += BWD_THREADS) {
     const int r = i / kch, ch = i - r * kch;
     *(uint4*)(Wb + r * ldw + ch * 8) = *(const uint4*)(p.rw4t + (int64_t)(u0 + r) * p.ld_rwt + ch * 8);
   }
   __syncthreads();
 
   const int bcol = lane & 15, q = lane >> 4;
-  const bool unit_lane = q < 2;                           // lanes 32..63 hold the duplicate MFMA rows
+  const bool unit_lane = q < 2 && kq4 == 0;               // lanes 32..63 hold the duplicate MFMA rows; K quarter 0 owns the cell math
   const int uq = u0 + (q & 1) * 4;
   float dc_state[BWD_TILES][4];
   float apf[4] = {0, 0, 0, 0}, apo[4] = {0, 0, 0, 0}, apg[4] = {0, 0, 0, 0};
   float wpf[4] = {0, 0, 0, 0}, wpo[4] = {0, 0, 0, 0}, wpg[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int tt = 0; tt < BWD_TILES; ++tt)
+  for (int tt = 0; tt < BWD_TILES; ++tt) {
+    const int row = (tile0 + 4 * tt) * 16 + bcol;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dc_state[tt][j] = 0.f;
+    for (int j = 0; j < 4; ++j) dc_state[tt][j] = (p.dc_in && unit_lane && row < mb) ? p.dc_in[(int64_t)row * n + uq + j] : 0.f;
+  }
   if (p.pf) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { wpf[j] = p.pf[uq + j]; wpo[j] = p.po[uq + j]; wpg[j] = p.pg[uq + j]; }
   }
-  const bf16_t* ap = Wb + (bcol & 7) * ldw + q * 8;
+  const int Kq = K >> 2;                                  // columns per K quarter (= n)
+  const bf16_t* ap = Wb + (bcol & 7) * ldw + kq4 * Kq + q * 8;
 
   for (int s = p.T - 1; s >= 0; --s) {
     const int t = p.reverse ? p.T - 1 - s : s;
     const int t_prev = p.reverse ? t + 1 : t - 1;
     const int t_next = p.reverse ? t - 1 : t + 1;         // the step handled in the previous iteration of this loop
+    const bf16_t* nextp = s < p.T - 1 ? p.dG + (int64_t)t_next * mb * K : p.dG_next;
+    f32x4 acc[BWD_TILES];
+    uint64_t ev[BWD_TILES], sva[BWD_TILES], svf[BWD_TILES], svo[BWD_TILES], svg[BWD_TILES], svc[BWD_TILES], svac[BWD_TILES], cpv[BWD_TILES];
+    float mk[BWD_TILES];
 #pragma unroll
     for (int tt = 0; tt < BWD_TILES; ++tt) {
-      const int tile = wave + 4 * tt;
+      const int tile = tile0 + 4 * tt;
+      acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mk[tt] = 1.f;
+      ev[tt] = sva[tt] = svf[tt] = svo[tt] = svg[tt] = svc[tt] = svac[tt] = cpv[tt] = 0ull;
       if (tile * 16 >= mb) continue;
       const int row = tile * 16 + bcol;
       const bool row_ok = row < mb;
-      const bool act = unit_lane && row_ok;
       // saved activations / eps / previous cell state of this lane's (row, 4 units): issued before the recurrent product
-      uint64_t ev = 0, sva = 0, svf = 0, svo = 0, svg = 0, svc = 0, svac = 0, cpv = 0;
-      float mk = 1.f;
-      if (act) {
+      if (unit_lane && row_ok) {
         const int64_t hidx = ((int64_t)t * mb + row) * n + uq;
-        ev = *(const uint64_t*)(p.E + hidx);
+        ev[tt] = *(const uint64_t*)(p.E + hidx);
         const bf16_t* sv = p.SV + ((int64_t)t * mb + row) * 6 * n + uq;
-        sva = *(const uint64_t*)(sv); svf = *(const uint64_t*)(sv + n); svo = *(const uint64_t*)(sv + 2 * (int64_t)n);
-        svg = *(const uint64_t*)(sv + 3 * (int64_t)n); svc = *(const uint64_t*)(sv + 4 * (int64_t)n);
-        svac = *(const uint64_t*)(sv + 5 * (int64_t)n);
-        cpv = s == 0 ? *(const uint64_t*)(p.c0 + (int64_t)row * n + uq) : *(const uint64_t*)(p.Cs + ((int64_t)t_prev * mb + row) * n + uq);
-        if (p.maskT) mk = p.maskT[(int64_t)t * mb + row];
+        sva[tt] = *(const uint64_t*)(sv); svf[tt] = *(const uint64_t*)(sv + n); svo[tt] = *(const uint64_t*)(sv + 2 * (int64_t)n);
+        svg[tt] = *(const uint64_t*)(sv + 3 * (int64_t)n); svc[tt] = *(const uint64_t*)(sv + 4 * (int64_t)n);
+        svac[tt] = *(const uint64_t*)(sv + 5 * (int64_t)n);
+        cpv[tt] = s == 0 ? *(const uint64_t*)(p.c0 + (int64_t)row * n + uq) : *(const uint64_t*)(p.Cs + ((int64_t)t_prev * mb + row) * n + uq);
+        if (p.maskT) mk[tt] = p.maskT[(int64_t)t * mb + row];
       }
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (s < p.T - 1) {
-        const bf16_t* bp = p.dG + ((int64_t)t_next * mb + (row_ok ? row : 0)) * K + q * 8;
+      if (nextp != nullptr) {
+        const bf16_t* bp = nextp + (int64_t)(row_ok ? row : 0) * K + kq4 * Kq + q * 8;
         // no divergent branch around MFMAs (they do not honour EXEC): rows beyond mb read row 0 and are zeroed by a select
         const bf16x8_t zero = {};
-#pragma unroll 8
-        for (int k = 0; k < K; k += 32) {
+#pragma unroll 16
+        for (int k = 0; k < Kq; k += 32) {
           const bf16x8_t a = *(const bf16x8_t*)(ap + k);
           bf16x8_t b = *(const bf16x8_t*)(bp + k);
           b = row_ok ? b : zero;
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[tt], 0, 0, 0);
         }
+        if (kq4 > 0) red[((tt * 3 + (kq4 - 1)) * 4 + tile0) * 64 + lane] = acc[tt];
       }
-      if (act) {
+    }
+    if (nextp != nullptr) __syncthreads();                // split-K partials of quarters 1..3 are in LDS
+#pragma unroll
+    for (int tt = 0; tt < BWD_TILES; ++tt) {
+      const int tile = tile0 + 4 * tt;
+      if (tile * 16 >= mb) continue;
+      const int row = tile * 16 + bcol;
+      if (unit_lane && row < mb) {
+        if (nextp != nullptr) {
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            const f32x4 part = red[((tt * 3 + kk) * 4 + tile0) * 64 + lane];
+            acc[tt] += part;
+          }
+        }
         float e4[4], a4[4], f4[4], o4[4], g4[4], c4[4], ac4[4], cp4[4];
-        unpack4(ev, e4); unpack4(sva, a4); unpack4(svf, f4); unpack4(svo, o4); unpack4(svg, g4); unpack4(svc, c4); unpack4(svac, ac4);
-        unpack4(cpv, cp4);
+        unpack4(ev[tt], e4); unpack4(sva[tt], a4); unpack4(svf[tt], f4); unpack4(svo[tt], o4); unpack4(svg[tt], g4); unpack4(svc[tt], c4);
+        unpack4(svac[tt], ac4); unpack4(cpv[tt], cp4);
         float dza[4], dzf[4], dzo[4], dzg[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float d_h = (e4[j] + acc[j]) * mk;
-          const float d_cn = dc_state[tt][j] * mk;
+          const float d_h = (e4[j] + acc[tt][j]) * mk[tt];
+          const float d_cn = dc_state[tt][j] * mk[tt];
           const float a = a4[j], f = f4[j], o = o4[j], g = g4[j], ac = ac4[j], cp = cp4[j];
           dzo[j] = d_h * ac * o * (1.f - o);
           float dc = d_cn + d_h * o * (1.f - ac * ac);
@@ -328,7 +401,237 @@ __global__ void __launch_bounds__(256) lstm_persist_bwd_kernel(LstmBwdP p) {
       if (!grid_barrier(p.bar, (unsigned)(p.T - s) * gridDim.x, &s_flag)) return;
     }
   }
+  if (p.dc_out) {
+#pragma unroll
+    for (int tt = 0; tt < BWD_TILES; ++tt) {
+      const int row = (tile0 + 4 * tt) * 16 + bcol;
+      if (unit_lane && row < mb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p.dc_out[(int64_t)row * n + uq + j] = dc_state[tt][j];
+    }
+  }
   // peephole gradients: reduce over the 16 batch columns of the lane group, then one atomic per unit and wave
+  if (p.pf && p.dpeep) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float vf = apf[j], vo = apo[j], vg = apg[j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { vf += __shfl_xor(vf, o, 64); vo += __shfl_xor(vo, o, 64); vg += __shfl_xor(vg, o, 64); }
+      if (unit_lane && bcol == 0) {
+        atomicAdd(p.dpeep + uq + j, vf);
+        atomicAdd(p.dpeep + n + uq + j, vo);
+        atomicAdd(p.dpeep + 2 * n + uq + j, vg);
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------ step kernels
+// One launch per time step, operands straight from L2 into MFMA registers (no LDS staging, so nothing waits on a fill):
+// every wave issues all of its loads at once (input projection, weights, h or dG), which leaves ONE exposed memory latency per
+// step. 16 waves = K quarter x batch tile; quarters 1..3 hand their partial accumulators to quarter 0 through LDS, which runs the
+// cell math of the persistent kernels. Ordering between steps is the kernel boundary (the cheapest all-to-all hand-off on this
+// part: MI355X_MICROARCH price list "boundary" 1.45 us vs "allgather" 3-5 us, confirmed in profiles/r2_lstm_persistent.md).
+#define STEP_THREADS 1024
+#define STEP_KSTEPS 8        // K-steps of 16 per wave held in registers at once (n <= 512 in one pass)
+
+__global__ void __launch_bounds__(STEP_THREADS) lstm_step_fwd_kernel(LstmFwdP p) {
+  __shared__ __attribute__((aligned(16))) f32x16 red[3 * 4 * 64];       // partial accumulators of K quarters 1..3 [3][4 tiles][64 lanes]
+  const int n = p.n, mb = p.mb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = wave & 3, kp = wave >> 2;
+  const int u0 = blockIdx.x * 8;
+  const int row = tile * 32 + (lane & 31);
+  const int kq = lane >> 5;
+  const int uq = u0 + kq * 4;
+  const bool tile_on = tile * 32 < mb;
+  const bool row_ok = row < mb;
+  const bool cell_lane = tile_on && row_ok && kp == 0;
+  const int Kq = n >> 2;
+  // (1) everything this wave needs, issued back to back
+  uint64_t xwv[4] = {0, 0, 0, 0}, cpv = 0;
+  float mk = 1.f;
+  if (cell_lane) {
+    const bf16_t* xr = p.xw + (int64_t)row * 4 * n + uq;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xwv[g] = *(const uint64_t*)(xr + (int64_t)g * n);
+    cpv = *(const uint64_t*)(p.c0 + (int64_t)row * n + uq);
+    if (p.maskT) mk = p.maskT[row];
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (tile_on) {
+    const int gc = lane & 31;                                            // gate column of the slice: g*8 + k
+    const bf16_t* ap = p.rw4 + ((int64_t)(gc >> 3) * n + u0 + (gc & 7)) * p.ld_rw + kp * Kq + kq * 8;
+    const bf16_t* bp = p.h0 + (int64_t)(row_ok ? row : 0) * n + kp * Kq + kq * 8;
+    const bf16x8_t zero = {};
+    for (int k0 = 0; k0 < Kq; k0 += 16 * STEP_KSTEPS) {
+      bf16x8_t a[STEP_KSTEPS], b[STEP_KSTEPS];
+#pragma unroll
+      for (int i = 0; i < STEP_KSTEPS; ++i) {
+        const int k = k0 + 16 * i;
+        a[i] = k < Kq ? *(const bf16x8_t*)(ap + k) : zero;
+        b[i] = (k < Kq && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < STEP_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+    }
+    if (kp > 0) red[((kp - 1) * 4 + tile) * 64 + lane] = acc;
+  }
+  __syncthreads();
+  if (!cell_lane) return;
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const f32x16 part = red[(kk * 4 + tile) * 64 + lane];
+    acc += part;
+  }
+  float c_state[4];
+  unpack4(cpv, c_state);
+  float wpf[4] = {0, 0, 0, 0}, wpo[4] = {0, 0, 0, 0}, wpg[4] = {0, 0, 0, 0};
+  if (p.pf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wpf[j] = p.pf[uq + j]; wpo[j] = p.po[uq + j]; wpg[j] = p.pg[uq + j]; }
+  }
+  float xa[4], xf[4], xo[4], xg[4];
+  unpack4(xwv[0], xa); unpack4(xwv[1], xf); unpack4(xwv[2], xo); unpack4(xwv[3], xg);
+  float hn[4], cn[4], va[4], vf[4], vo[4], vg[4], vac[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float cp = c_state[j];
+    const float za = acc[j] + xa[j];
+    float zf = acc[4 + j] + xf[j], zo = acc[8 + j] + xo[j], zg = acc[12 + j] + xg[j];
+    if (p.pf) { zf += cp * wpf[j]; zg += cp * wpg[j]; }
+    const float a = tanh_fast(za), f = sigm(zf), g = sigm(zg);
+    const float c = f * cp + g * a;
+    if (p.pf) zo += c * wpo[j];
+    const float o = sigm(zo), ac = tanh_fast(c);
+    va[j] = a; vf[j] = f; vo[j] = o; vg[j] = g; vac[j] = ac;
+    cn[j] = c;
+    hn[j] = o * ac * mk;
+    c_state[j] = c * mk;
+  }
+  const int64_t o_idx = (int64_t)row * n + uq;
+  *(uint64_t*)(p.H + o_idx) = pack4(hn[0], hn[1], hn[2], hn[3]);
+  *(uint64_t*)(p.Cs + o_idx) = pack4(c_state[0], c_state[1], c_state[2], c_state[3]);
+  if (p.SV) {
+    bf16_t* sv = p.SV + (int64_t)row * 6 * n + uq;
+    *(uint64_t*)(sv) = pack4(va[0], va[1], va[2], va[3]);
+    *(uint64_t*)(sv + n) = pack4(vf[0], vf[1], vf[2], vf[3]);
+    *(uint64_t*)(sv + 2 * (int64_t)n) = pack4(vo[0], vo[1], vo[2], vo[3]);
+    *(uint64_t*)(sv + 3 * (int64_t)n) = pack4(vg[0], vg[1], vg[2], vg[3]);
+    *(uint64_t*)(sv + 4 * (int64_t)n) = pack4(cn[0], cn[1], cn[2], cn[3]);
+    *(uint64_t*)(sv + 5 * (int64_t)n) = pack4(vac[0], vac[1], vac[2], vac[3]);
+  }
+}
+
+// Backward step: p.E / p.SV / p.dG / p.maskT point at THIS step; p.c0 = cell state that fed it; p.dG_next = gate gradients of the
+// following step (or null); p.dc_in / p.dc_out = dL/dc between launches (fp32).
+__global__ void __launch_bounds__(STEP_THREADS) lstm_step_bwd_kernel(LstmBwdP p) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[BWD_TILES * 3 * 4 * 64];
+  const int n = p.n, mb = p.mb, K = 4 * p.n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile0 = wave & 3, kq4 = wave >> 2;
+  const int u0 = blockIdx.x * 8;
+  const int bcol = lane & 15, q = lane >> 4;
+  const bool unit_lane = q < 2 && kq4 == 0;
+  const int uq = u0 + (q & 1) * 4;
+  const int Kq = K >> 2;
+  const bf16_t* ap = p.rw4t + (int64_t)(u0 + (bcol & 7)) * p.ld_rwt + kq4 * Kq + q * 8;
+  f32x4 acc[BWD_TILES];
+  uint64_t ev[BWD_TILES], sva[BWD_TILES], svf[BWD_TILES], svo[BWD_TILES], svg[BWD_TILES], svc[BWD_TILES], svac[BWD_TILES], cpv[BWD_TILES];
+  float mk[BWD_TILES], dcn[BWD_TILES][4];
+#pragma unroll
+  for (int tt = 0; tt < BWD_TILES; ++tt) {
+    const int tile = tile0 + 4 * tt;
+    acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mk[tt] = 1.f;
+    ev[tt] = sva[tt] = svf[tt] = svo[tt] = svg[tt] = svc[tt] = svac[tt] = cpv[tt] = 0ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dcn[tt][j] = 0.f;
+    if (tile * 16 >= mb) continue;
+    const int row = tile * 16 + bcol;
+    const bool row_ok = row < mb;
+    if (unit_lane && row_ok) {
+      const int64_t hidx = (int64_t)row * n + uq;
+      ev[tt] = *(const uint64_t*)(p.E + hidx);
+      const bf16_t* sv = p.SV + (int64_t)row * 6 * n + uq;
+      sva[tt] = *(const uint64_t*)(sv); svf[tt] = *(const uint64_t*)(sv + n); svo[tt] = *(const uint64_t*)(sv + 2 * (int64_t)n);
+      svg[tt] = *(const uint64_t*)(sv + 3 * (int64_t)n); svc[tt] = *(const uint64_t*)(sv + 4 * (int64_t)n);
+      svac[tt] = *(const uint64_t*)(sv + 5 * (int64_t)n);
+      cpv[tt] = *(const uint64_t*)(p.c0 + hidx);
+      if (p.maskT) mk[tt] = p.maskT[row];
+      if (p.dc_in) {
+        const f32x4 d = *(const f32x4*)(p.dc_in + hidx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dcn[tt][j] = d[j];
+      }
+    }
+    if (p.dG_next != nullptr) {
+      const bf16_t* bp = p.dG_next + (int64_t)(row_ok ? row : 0) * K + kq4 * Kq + q * 8;
+      const bf16x8_t zero = {};
+#pragma unroll 16
+      for (int k = 0; k < Kq; k += 32) {
+        const bf16x8_t a = *(const bf16x8_t*)(ap + k);
+        bf16x8_t b = *(const bf16x8_t*)(bp + k);
+        b = row_ok ? b : zero;
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[tt], 0, 0, 0);
+      }
+      if (kq4 > 0) red[((tt * 3 + (kq4 - 1)) * 4 + tile0) * 64 + lane] = acc[tt];
+    }
+  }
+  __syncthreads();
+  float apf[4] = {0, 0, 0, 0}, apo[4] = {0, 0, 0, 0}, apg[4] = {0, 0, 0, 0};
+  float wpf[4] = {0, 0, 0, 0}, wpo[4] = {0, 0, 0, 0}, wpg[4] = {0, 0, 0, 0};
+  if (p.pf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wpf[j] = p.pf[uq + j]; wpo[j] = p.po[uq + j]; wpg[j] = p.pg[uq + j]; }
+  }
+#pragma unroll
+  for (int tt = 0; tt < BWD_TILES; ++tt) {
+    const int tile = tile0 + 4 * tt;
+    if (tile * 16 >= mb) continue;
+    const int row = tile * 16 + bcol;
+    if (!(unit_lane && row < mb)) continue;
+    if (p.dG_next != nullptr) {
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const f32x4 part = red[((tt * 3 + kk) * 4 + tile0) * 64 + lane];
+        acc[tt] += part;
+      }
+    }
+    float e4[4], a4[4], f4[4], o4[4], g4[4], c4[4], ac4[4], cp4[4];
+    unpack4(ev[tt], e4); unpack4(sva[tt], a4); unpack4(svf[tt], f4); unpack4(svo[tt], o4); unpack4(svg[tt], g4); unpack4(svc[tt], c4);
+    unpack4(svac[tt], ac4); unpack4(cpv[tt], cp4);
+    float dza[4], dzf[4], dzo[4], dzg[4];
+    f32x4 dco;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d_h = (e4[j] + acc[tt][j]) * mk[tt];
+      const float d_cn = dcn[tt][j] * mk[tt];
+      const float a = a4[j], f = f4[j], o = o4[j], g = g4[j], ac = ac4[j], cp = cp4[j];
+      dzo[j] = d_h * ac * o * (1.f - o);
+      float dc = d_cn + d_h * o * (1.f - ac * ac);
+      if (p.pf) dc += dzo[j] * wpo[j];
+      dza[j] = dc * g * (1.f - a * a);
+      dzf[j] = dc * cp * f * (1.f - f);
+      dzg[j] = dc * a * g * (1.f - g);
+      float dcp = dc * f;
+      if (p.pf) {
+        dcp += dzf[j] * wpf[j] + dzg[j] * wpg[j];
+        apf[j] += dzf[j] * cp; apo[j] += dzo[j] * c4[j]; apg[j] += dzg[j] * cp;
+      }
+      dco[j] = dcp;
+    }
+    const int64_t hidx = (int64_t)row * n + uq;
+    if (p.dc_out) *(f32x4*)(p.dc_out + hidx) = dco;
+    bf16_t* dg = p.dG + (int64_t)row * K + uq;
+    *(uint64_t*)(dg) = pack4(dza[0], dza[1], dza[2], dza[3]);
+    *(uint64_t*)(dg + n) = pack4(dzf[0], dzf[1], dzf[2], dzf[3]);
+    *(uint64_t*)(dg + 2 * (int64_t)n) = pack4(dzo[0], dzo[1], dzo[2], dzo[3]);
+    *(uint64_t*)(dg + 3 * (int64_t)n) = pack4(dzg[0], dzg[1], dzg[2], dzg[3]);
+  }
   if (p.pf && p.dpeep) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -348,6 +651,14 @@ __global__ void __launch_bounds__(256) lstm_persist_bwd_kernel(LstmBwdP p) {
 
 extern "C" int dl4j_fill_zero_bytes(void* p, size_t bytes, hipStream_t st);
 
+__global__ void __launch_bounds__(256) fill_ones_u64_kernel(uint64_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = LL_SENTINEL;
+}
+static int dl4j_fill_ones_bytes(void* p, size_t bytes, hipStream_t st) {
+  hipLaunchKernelGGL(fill_ones_u64_kernel, dim3(grid_for((int64_t)(bytes / 8), 1024)), dim3(256), 0, st, (uint64_t*)p, bytes / 8);
+  return (int)hipGetLastError();
+}
+
 // LDS bytes of the forward kernel; 0 when the shape is not supported
 static int lstm_persist_fwd_lds(int mb, int n) {
   if (n <= 0 || mb <= 0 || n % 8 != 0 || n / 8 > 256 || mb > 128) return 0;
@@ -357,7 +668,7 @@ static int lstm_persist_fwd_lds(int mb, int n) {
 }
 
 static int lstm_persist_bwd_lds(int mb, int n);
-DL4J_API int dl4j_lstm_persist_supported(int mb, int n) { return (lstm_persist_fwd_lds(mb, n) > 0 && lstm_persist_bwd_lds(mb, n) > 0) ? 1 : 0; }
+DL4J_API int dl4j_lstm_persist_supported(int mb, int n) { return (n % 64 == 0 && lstm_persist_fwd_lds(mb, n) > 0 && lstm_persist_bwd_lds(mb, n) > 0) ? 1 : 0; }
 
 // bar: 2 x uint32 device scratch, zeroed here (stream ordered). Returns -2 for an unsupported shape.
 DL4J_API int dl4j_lstm_persist_fwd(const void* xw, const void* rw4, int64_t ld_rw, const void* h0, const void* c0, const float* pf,
@@ -374,13 +685,43 @@ DL4J_API int dl4j_lstm_persist_fwd(const void* xw, const void* rw4, int64_t ld_r
   if (zrc) return zrc;
   LstmFwdP p{(const bf16_t*)xw, (const bf16_t*)rw4, ld_rw, (const bf16_t*)h0, (const bf16_t*)c0, pf, po, pg, maskT,
              (bf16_t*)H, (bf16_t*)Cs, (bf16_t*)SV, bar, T, mb, n, reverse};
-  hipLaunchKernelGGL(lstm_persist_fwd_kernel, dim3(n / 8), dim3(256), lds, st, p);
+  // the exchange buffer is H itself: every word must read as "not written yet" before the first workgroup polls it
+  const int frc = dl4j_fill_ones_bytes(H, (size_t)T * mb * n * 2, st);
+  if (frc) return frc;
+  hipLaunchKernelGGL(lstm_persist_fwd_kernel, dim3(n / 8), dim3(FWD_THREADS), lds, st, p);
+  DL4J_RET_LAST();
+}
+
+// The same forward kernel launched once per time step (T = 1 per launch: no in-kernel hand-off, the kernel boundary orders the
+// steps). One fused launch per step instead of GEMM + cell kernel; cheaper than the in-kernel all-gather of h at these sizes
+// (measured: profiles/r2_lstm_persistent.md).
+DL4J_API int dl4j_lstm_steps_fwd(const void* xw, const void* rw4, int64_t ld_rw, const void* h0, const void* c0, const float* pf,
+                                 const float* po, const float* pg, const float* maskT, void* H, void* Cs, void* SV, unsigned* bar, int T, int mb,
+                                 int n, int reverse, hipStream_t st) {
+  if (T <= 0) return 0;
+  const int lds = lstm_persist_fwd_lds(mb, n);
+  if (lds == 0 || ld_rw % 8 != 0 || ((uintptr_t)rw4 & 15) || ((uintptr_t)h0 & 15) || ((uintptr_t)H & 15) || ((uintptr_t)xw & 7)) return -2;
+  if ((pf != nullptr) != (po != nullptr) || (pf != nullptr) != (pg != nullptr)) return -2;
+  if (n % 64 != 0) return -2;                              // whole 16-wide K-steps per K quarter
+  const size_t hn = (size_t)mb * n * 2;
+  const char* hp = (const char*)h0;
+  const char* cp = (const char*)c0;
+  (void)lds;
+  for (int s = 0; s < T; ++s) {
+    const int t = reverse ? T - 1 - s : s;
+    LstmFwdP p{(const bf16_t*)xw + (size_t)t * mb * 4 * n, (const bf16_t*)rw4, ld_rw, (const bf16_t*)hp, (const bf16_t*)cp, pf, po, pg,
+               maskT ? maskT + (size_t)t * mb : nullptr, (bf16_t*)((char*)H + t * hn), (bf16_t*)((char*)Cs + t * hn),
+               SV ? (bf16_t*)((char*)SV + (size_t)t * 6 * hn) : nullptr, bar, 1, mb, n, 0};
+    hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(n / 8), dim3(STEP_THREADS), 0, st, p);
+    hp = (const char*)H + t * hn;
+    cp = (const char*)Cs + t * hn;
+  }
   DL4J_RET_LAST();
 }
 
 static int lstm_persist_bwd_lds(int mb, int n) {
-  if (n <= 0 || mb <= 0 || n % 8 != 0 || n / 8 > 256 || mb > 64 * BWD_TILES) return 0;
-  const int64_t bytes = (int64_t)8 * (4 * n + 32) * 2;
+  if (n <= 0 || mb <= 0 || n % 32 != 0 || n / 8 > 256 || mb > 64 * BWD_TILES) return 0;     // n % 32: whole MFMA K-steps per K quarter
+  const int64_t bytes = (int64_t)8 * (4 * n + 32) * 2 + (int64_t)BWD_TILES * 3 * 4 * 64 * 16;
   return bytes <= 156 * 1024 ? (int)bytes : 0;
 }
 
@@ -400,7 +741,45 @@ DL4J_API int dl4j_lstm_persist_bwd(const void* E, const void* rw4t, int64_t ld_r
   const int zrc = dl4j_fill_zero_bytes(bar, 2 * sizeof(unsigned), st);
   if (zrc) return zrc;
   LstmBwdP p{(const bf16_t*)E, (const bf16_t*)rw4t, ld_rwt, (const bf16_t*)SV, (const bf16_t*)Cs, (const bf16_t*)c0, pf, po, pg, maskT,
-             (bf16_t*)dG, dpeep, bar, T, mb, n, reverse};
-  hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(n / 8), dim3(256), lds, st, p);
+             (bf16_t*)dG, dpeep, bar, T, mb, n, reverse, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(n / 8), dim3(BWD_THREADS), lds, st, p);
+  DL4J_RET_LAST();
+}
+
+// The backward kernel launched once per time step (see dl4j_lstm_steps_fwd). dc_ws: [2, mb, n] fp32 scratch for dL/dc between launches.
+DL4J_API int dl4j_lstm_steps_bwd(const void* E, const void* rw4t, int64_t ld_rwt, const void* SV, const void* Cs, const void* c0,
+                                 const float* pf, const float* po, const float* pg, const float* maskT, void* dG, float* dpeep, unsigned* bar,
+                                 float* dc_ws, int T, int mb, int n, int reverse, hipStream_t st) {
+  if (T <= 0) return 0;
+  const int lds = lstm_persist_bwd_lds(mb, n);
+  if (lds == 0 || ld_rwt % 8 != 0 || ((uintptr_t)rw4t & 15) || ((uintptr_t)dG & 15) || ((uintptr_t)E & 7) || ((uintptr_t)SV & 7) ||
+      ((uintptr_t)Cs & 7) || ((uintptr_t)c0 & 7))
+    return -2;
+  if ((pf != nullptr) != (po != nullptr) || (pf != nullptr) != (pg != nullptr)) return -2;
+  // measured (profiles/r2_lstm_persistent.md): with the 8 weight rows staged in LDS (the persistent kernel run for one step) a backward
+  // step takes 14.2 us, with weights read straight from L2 by every wave (lstm_step_bwd_kernel) 18.3 us -> the LDS form is used
+  static DeviceOnceLds lds_attr;
+  lds_attr.ensure((const void*)lstm_persist_bwd_kernel, lds);
+  const size_t hn = (size_t)mb * n;
+  const bf16_t* Eb = (const bf16_t*)E;
+  const bf16_t* SVb = (const bf16_t*)SV;
+  const bf16_t* Csb = (const bf16_t*)Cs;
+  bf16_t* dGb = (bf16_t*)dG;
+  float* dc_cur = nullptr;          // dL/dc into the step being launched (null for the first launch = zeros)
+  float* dc_nxt = dc_ws;
+  const bf16_t* next = nullptr;
+  for (int s = T - 1; s >= 0; --s) {
+    const int t = reverse ? T - 1 - s : s;
+    const int t_prev = reverse ? t + 1 : t - 1;
+    LstmBwdP p{Eb + t * hn, (const bf16_t*)rw4t, ld_rwt, SVb + 6 * t * hn, Csb, s == 0 ? (const bf16_t*)c0 : Csb + t_prev * hn, pf, po, pg,
+               maskT ? maskT + (size_t)t * mb : nullptr, dGb + 4 * t * hn, dpeep, bar, 1, mb, n, 0, next, dc_cur, s > 0 ? dc_nxt : nullptr};
+    if (getenv("DL4J_AMD_LSTM_STEP_BWD_NOLDS") != nullptr)
+      hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(n / 8), dim3(STEP_THREADS), 0, st, p);
+    else
+      hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(n / 8), dim3(BWD_THREADS), lds, st, p);
+    next = dGb + 4 * t * hn;
+    dc_cur = dc_nxt;
+    dc_nxt = (dc_nxt == dc_ws) ? dc_ws + hn : dc_ws;
+  }
   DL4J_RET_LAST();
 }

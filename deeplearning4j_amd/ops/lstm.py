@@ -104,6 +104,9 @@ def native_seq_ok(xw, RW4, n, act, gate_act):
 
 _PERSIST = os.environ.get("DL4J_AMD_LSTM_PERSIST", "1") == "1"
 _PERSIST_CHECK = os.environ.get("DL4J_AMD_LSTM_PERSIST_CHECK", "0") == "1"
+# "steps": the fused kernels launched once per time step (default: a kernel boundary is the cheapest all-to-all hand-off of h on
+# MI355X, profiles/r2_lstm_persistent.md); "grid": one launch per sequence with in-kernel hand-offs between the workgroups
+_PERSIST_MODE = os.environ.get("DL4J_AMD_LSTM_PERSIST_MODE", "steps")
 
 
 def persist_ok(xw, RW4, mb, n):
@@ -128,11 +131,11 @@ def seq_forward(xw, RW4, h0, c0, peep, mask, train, reverse):
     if persist_ok(xw, RW4, mb, n):
         # one launch for the whole sequence (native/csrc/lstm_persist.hip): weights resident in LDS, cell state in registers
         bar = torch.empty(2, device=dev, dtype=torch.int32)
-        L.check(L.hip().dl4j_lstm_persist_fwd(L.ptr(xw), L.ptr(RW4), L.c_int64(n), L.ptr(h0c), L.ptr(c0c), L.ptr(pf), L.ptr(po), L.ptr(pg),
-                                              L.ptr(maskT), L.ptr(H), L.ptr(Cs), L.ptr(SV), L.ptr(bar), L.c_int(T), L.c_int(mb), L.c_int(n),
-                                              L.c_int(1 if reverse else 0), L.stream()), "lstm_persist_fwd")
-        if _PERSIST_CHECK and int(bar[1]) != 0:
-            raise RuntimeError("lstm_persist_fwd: grid barrier timed out (workgroups were not co-resident)")
+        fn = L.hip().dl4j_lstm_persist_fwd if _PERSIST_MODE == "grid" else L.hip().dl4j_lstm_steps_fwd
+        L.check(fn(L.ptr(xw), L.ptr(RW4), L.c_int64(n), L.ptr(h0c), L.ptr(c0c), L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(maskT), L.ptr(H), L.ptr(Cs),
+                   L.ptr(SV), L.ptr(bar), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()), "lstm_fused_fwd")
+        if _PERSIST_MODE == "grid" and _PERSIST_CHECK and int(bar[1]) != 0:
+            raise RuntimeError("lstm_persist_fwd: inter-workgroup hand-off timed out (workgroups were not co-resident)")
         return H, {"H": H, "Cs": Cs, "SV": SV, "h0": h0c, "c0": c0c, "peep": (pf, po, pg), "maskT": maskT}
     L.check(L.hip().dl4j_lstm_seq_fwd(L.ptr(xw), L.ptr(RW4), L.c_int64(n), L.ptr(h0c), L.ptr(c0c), L.ptr(pf), L.ptr(po), L.ptr(pg),
                                       L.ptr(maskT), L.ptr(H), L.ptr(Cs), L.ptr(SV), L.ptr(ws), L.c_int(T), L.c_int(mb), L.c_int(n),
@@ -151,11 +154,18 @@ def seq_backward(E, RW4, st, reverse):
     dpeep = torch.zeros(3, n, device=dev, dtype=torch.float32) if pf is not None else None
     if persist_ok(E, rw4t, mb, n) and st["SV"] is not None:
         bar = torch.empty(2, device=dev, dtype=torch.int32)
-        L.check(L.hip().dl4j_lstm_persist_bwd(L.ptr(E), L.ptr(rw4t), L.c_int64(4 * n), L.ptr(st["SV"]), L.ptr(st["Cs"]), L.ptr(st["c0"]),
-                                              L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(bar),
-                                              L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()), "lstm_persist_bwd")
-        if _PERSIST_CHECK and int(bar[1]) != 0:
-            raise RuntimeError("lstm_persist_bwd: grid barrier timed out (workgroups were not co-resident)")
+        if _PERSIST_MODE == "grid":
+            L.check(L.hip().dl4j_lstm_persist_bwd(L.ptr(E), L.ptr(rw4t), L.c_int64(4 * n), L.ptr(st["SV"]), L.ptr(st["Cs"]), L.ptr(st["c0"]),
+                                                  L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(bar),
+                                                  L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()), "lstm_persist_bwd")
+            if _PERSIST_CHECK and int(bar[1]) != 0:
+                raise RuntimeError("lstm_persist_bwd: grid barrier timed out (workgroups were not co-resident)")
+        else:
+            dc_ws = torch.empty(2, mb, n, device=dev, dtype=torch.float32)
+            L.check(L.hip().dl4j_lstm_steps_bwd(L.ptr(E), L.ptr(rw4t), L.c_int64(4 * n), L.ptr(st["SV"]), L.ptr(st["Cs"]), L.ptr(st["c0"]),
+                                                L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(bar),
+                                                L.ptr(dc_ws), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()),
+                    "lstm_steps_bwd")
         return dG, _hprev(st, reverse), (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
     dh_ws = torch.empty(mb, n, device=dev, dtype=dt)
     dc_ws = torch.empty(2, mb, n, device=dev, dtype=dt)

@@ -106,10 +106,12 @@ def _seq_case(T, mb, n, peep, masked, seed):
 @pytest.mark.parametrize("T,mb,n,peep,masked,reverse", [(7, 64, 512, False, False, False), (5, 33, 128, True, True, False),
                                                         (6, 100, 256, True, False, True), (1, 8, 64, False, True, False),
                                                         (50, 64, 512, False, False, False)])
-def test_lstm_persistent_forward_matches_per_step_kernels(monkeypatch, T, mb, n, peep, masked, reverse):
+@pytest.mark.parametrize("mode", ["steps", "grid"])
+def test_lstm_persistent_forward_matches_per_step_kernels(monkeypatch, mode, T, mb, n, peep, masked, reverse):
     """One-launch persistent sequence kernel (lstm_persist.hip) against the per-step GEMM + cell kernels, and both against fp32 torch math."""
     from deeplearning4j_amd.ops import lstm as R
     xw, RW4, h0, c0, pp, mask = _seq_case(T, mb, n, peep, masked, 11)
+    monkeypatch.setattr(R, "_PERSIST_MODE", mode)
     monkeypatch.setattr(R, "_PERSIST", True)
     monkeypatch.setattr(R, "_PERSIST_CHECK", True)
     assert R.persist_ok(xw, RW4, mb, n)
@@ -150,7 +152,8 @@ def test_lstm_persistent_forward_matches_per_step_kernels(monkeypatch, T, mb, n,
 @pytest.mark.parametrize("T,mb,n,peep,masked,reverse", [(7, 64, 512, False, False, False), (5, 33, 128, True, True, False),
                                                         (6, 100, 256, True, False, True), (1, 8, 64, False, True, False),
                                                         (50, 64, 512, True, True, False)])
-def test_lstm_persistent_backward_matches_per_step_kernels_and_autograd(monkeypatch, T, mb, n, peep, masked, reverse):
+@pytest.mark.parametrize("mode", ["steps", "grid"])
+def test_lstm_persistent_backward_matches_per_step_kernels_and_autograd(monkeypatch, mode, T, mb, n, peep, masked, reverse):
     """Persistent backward kernel: gate gradients + peephole gradients against the per-step kernels, and against torch autograd of
     the fp32 recurrence (same saved forward in both kernel paths)."""
     from deeplearning4j_amd.ops import lstm as R
@@ -158,6 +161,7 @@ def test_lstm_persistent_backward_matches_per_step_kernels_and_autograd(monkeypa
     g = torch.Generator().manual_seed(5)
     E = (torch.randn(T, mb, n, generator=g) * 0.5).bfloat16().cuda()
     monkeypatch.setattr(R, "_PERSIST_CHECK", True)
+    monkeypatch.setattr(R, "_PERSIST_MODE", mode)
     monkeypatch.setattr(R, "_PERSIST", True)
     H, st = R.seq_forward(xw, RW4, h0, c0, pp, mask, True, reverse)
     dGp, Hprev_p, dpp = R.seq_backward(E, RW4, st, reverse)
