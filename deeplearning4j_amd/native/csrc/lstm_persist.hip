@@ -647,6 +647,222 @@ __global__ void __launch_bounds__(STEP_THREADS) lstm_step_bwd_kernel(LstmBwdP p)
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------ fp32 step kernels
+// The same one-launch-per-step decomposition for fp32 networks (the reference's default data type): v_mfma_f32_32x32x2_f32 forward,
+// v_mfma_f32_16x16x4_f32 backward. A 16-byte operand load holds 4 consecutive K values per lane and feeds 4 MFMAs; A and B use the same
+// (permuted) K order, so no shuffling is needed.
+struct LstmFwdF32 {
+  const float* xw; const float* rw4; int64_t ld_rw; const float* h0; const float* c0;
+  const float* pf; const float* po; const float* pg; const float* mask;
+  float* H; float* Cs; float* SV;
+  int mb, n;
+};
+
+__global__ void __launch_bounds__(STEP_THREADS) lstm_step_fwd_f32_kernel(LstmFwdF32 p) {
+  __shared__ __attribute__((aligned(16))) f32x16 red[3 * 4 * 64];
+  const int n = p.n, mb = p.mb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = wave & 3, kp = wave >> 2;
+  const int u0 = blockIdx.x * 8;
+  const int row = tile * 32 + (lane & 31);
+  const int kq = lane >> 5;
+  const int uq = u0 + kq * 4;
+  const bool tile_on = tile * 32 < mb;
+  const bool row_ok = row < mb;
+  const bool cell_lane = tile_on && row_ok && kp == 0;
+  const int Kq = n >> 2;
+  f32x4 xwv[4], cpv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) xwv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mk = 1.f;
+  if (cell_lane) {
+    const float* xr = p.xw + (int64_t)row * 4 * n + uq;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xwv[g] = *(const f32x4*)(xr + (int64_t)g * n);
+    cpv = *(const f32x4*)(p.c0 + (int64_t)row * n + uq);
+    if (p.mask) mk = p.mask[row];
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (tile_on) {
+    const int gc = lane & 31;
+    const float* ap = p.rw4 + ((int64_t)(gc >> 3) * n + u0 + (gc & 7)) * p.ld_rw + kp * Kq + kq * 4;
+    const float* bp = p.h0 + (int64_t)(row_ok ? row : 0) * n + kp * Kq + kq * 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Kq; k0 += 8 * STEP_KSTEPS) {
+      f32x4 a[STEP_KSTEPS], b[STEP_KSTEPS];
+#pragma unroll
+      for (int i = 0; i < STEP_KSTEPS; ++i) {
+        const int k = k0 + 8 * i;
+        a[i] = k < Kq ? *(const f32x4*)(ap + k) : zero;
+        b[i] = (k < Kq && row_ok) ? *(const f32x4*)(bp + k) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < STEP_KSTEPS; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][c], b[i][c], acc, 0, 0, 0);
+    }
+    if (kp > 0) red[((kp - 1) * 4 + tile) * 64 + lane] = acc;
+  }
+  __syncthreads();
+  if (!cell_lane) return;
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const f32x16 part = red[(kk * 4 + tile) * 64 + lane];
+    acc += part;
+  }
+  f32x4 hn, cs, va, vf, vo, vg, vc, vac;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float cp = cpv[j];
+    const float za = acc[j] + xwv[0][j];
+    float zf = acc[4 + j] + xwv[1][j], zo = acc[8 + j] + xwv[2][j], zg = acc[12 + j] + xwv[3][j];
+    if (p.pf) { zf += cp * p.pf[uq + j]; zg += cp * p.pg[uq + j]; }
+    const float a = tanhf(za), f = sigm(zf), g = sigm(zg);
+    const float c = f * cp + g * a;
+    if (p.pf) zo += c * p.po[uq + j];
+    const float o = sigm(zo), ac = tanhf(c);
+    va[j] = a; vf[j] = f; vo[j] = o; vg[j] = g; vac[j] = ac; vc[j] = c;
+    hn[j] = o * ac * mk;
+    cs[j] = c * mk;
+  }
+  const int64_t o_idx = (int64_t)row * n + uq;
+  *(f32x4*)(p.H + o_idx) = hn;
+  *(f32x4*)(p.Cs + o_idx) = cs;
+  if (p.SV) {
+    float* sv = p.SV + (int64_t)row * 6 * n + uq;
+    *(f32x4*)(sv) = va; *(f32x4*)(sv + n) = vf; *(f32x4*)(sv + 2 * (int64_t)n) = vo; *(f32x4*)(sv + 3 * (int64_t)n) = vg;
+    *(f32x4*)(sv + 4 * (int64_t)n) = vc; *(f32x4*)(sv + 5 * (int64_t)n) = vac;
+  }
+}
+
+struct LstmBwdF32 {
+  const float* E; const float* rw4t; int64_t ld_rwt; const float* SV; const float* cprev;
+  const float* pf; const float* po; const float* pg; const float* mask;
+  float* dG; float* dpeep; const float* dG_next; const float* dc_in; float* dc_out;
+  int mb, n;
+};
+
+// dynamic LDS: the workgroup's 8 rows of RW4^T [8][4n + 16] fp32
+__global__ void __launch_bounds__(STEP_THREADS) lstm_step_bwd_f32_kernel(LstmBwdF32 p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) f32x4 red[BWD_TILES * 3 * 4 * 64];
+  const int n = p.n, mb = p.mb, K = 4 * p.n;
+  const int ldw = K + 16;                                  // row stride = 16 banks mod 64
+  float* Wb = (float*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile0 = wave & 3, kq4 = wave >> 2;
+  const int u0 = blockIdx.x * 8;
+  const int bcol = lane & 15, q = lane >> 4;
+  const bool unit_lane = q < 2 && kq4 == 0;
+  const int uq = u0 + (q & 1) * 4;
+  const int Kq = K >> 2;
+  const bool has_next = p.dG_next != nullptr;
+  // this step's saved values first (independent of everything else), then the weight rows into LDS
+  f32x4 ev[BWD_TILES], sva[BWD_TILES], svf[BWD_TILES], svo[BWD_TILES], svg[BWD_TILES], svc[BWD_TILES], svac[BWD_TILES], cpv[BWD_TILES], dcn[BWD_TILES];
+  float mk[BWD_TILES];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tt = 0; tt < BWD_TILES; ++tt) {
+    const int row = (tile0 + 4 * tt) * 16 + bcol;
+    ev[tt] = sva[tt] = svf[tt] = svo[tt] = svg[tt] = svc[tt] = svac[tt] = cpv[tt] = dcn[tt] = zero;
+    mk[tt] = 1.f;
+    if (unit_lane && row < mb) {
+      const int64_t hidx = (int64_t)row * n + uq;
+      ev[tt] = *(const f32x4*)(p.E + hidx);
+      const float* sv = p.SV + (int64_t)row * 6 * n + uq;
+      sva[tt] = *(const f32x4*)(sv); svf[tt] = *(const f32x4*)(sv + n); svo[tt] = *(const f32x4*)(sv + 2 * (int64_t)n);
+      svg[tt] = *(const f32x4*)(sv + 3 * (int64_t)n); svc[tt] = *(const f32x4*)(sv + 4 * (int64_t)n); svac[tt] = *(const f32x4*)(sv + 5 * (int64_t)n);
+      cpv[tt] = *(const f32x4*)(p.cprev + hidx);
+      if (p.mask) mk[tt] = p.mask[row];
+      if (p.dc_in) dcn[tt] = *(const f32x4*)(p.dc_in + hidx);
+    }
+  }
+  f32x4 acc[BWD_TILES];
+#pragma unroll
+  for (int tt = 0; tt < BWD_TILES; ++tt) acc[tt] = zero;
+  if (has_next) {
+    const int kch = K >> 2;
+    for (int i = tid; i < 8 * kch; i += STEP_THREADS) {
+      const int r = i / kch, ch = i - r * kch;
+      *(f32x4*)(Wb + r * ldw + ch * 4) = *(const f32x4*)(p.rw4t + (int64_t)(u0 + r) * p.ld_rwt + ch * 4);
+    }
+    __syncthreads();
+    const float* ap = Wb + (bcol & 7) * ldw + kq4 * Kq + q * 4;
+#pragma unroll
+    for (int tt = 0; tt < BWD_TILES; ++tt) {
+      const int tile = tile0 + 4 * tt;
+      if (tile * 16 >= mb) continue;
+      const int row = tile * 16 + bcol;
+      const bool row_ok = row < mb;
+      const float* bp = p.dG_next + (int64_t)(row_ok ? row : 0) * K + kq4 * Kq + q * 4;
+#pragma unroll 8
+      for (int k = 0; k < Kq; k += 16) {
+        const f32x4 a = *(const f32x4*)(ap + k);
+        f32x4 b = *(const f32x4*)(bp + k);
+        b = row_ok ? b : zero;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc[tt], 0, 0, 0);
+      }
+      if (kq4 > 0) red[((tt * 3 + (kq4 - 1)) * 4 + tile0) * 64 + lane] = acc[tt];
+    }
+    __syncthreads();
+  }
+  float apf[4] = {0, 0, 0, 0}, apo[4] = {0, 0, 0, 0}, apg[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int tt = 0; tt < BWD_TILES; ++tt) {
+    const int tile = tile0 + 4 * tt;
+    if (tile * 16 >= mb) continue;
+    const int row = tile * 16 + bcol;
+    if (!(unit_lane && row < mb)) continue;
+    if (has_next) {
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const f32x4 part = red[((tt * 3 + kk) * 4 + tile0) * 64 + lane];
+        acc[tt] += part;
+      }
+    }
+    f32x4 dza, dzf, dzo, dzg, dco;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d_h = (ev[tt][j] + acc[tt][j]) * mk[tt];
+      const float d_cn = dcn[tt][j] * mk[tt];
+      const float a = sva[tt][j], f = svf[tt][j], o = svo[tt][j], g = svg[tt][j], ac = svac[tt][j], cp = cpv[tt][j];
+      dzo[j] = d_h * ac * o * (1.f - o);
+      float dc = d_cn + d_h * o * (1.f - ac * ac);
+      if (p.pf) dc += dzo[j] * p.po[uq + j];
+      dza[j] = dc * g * (1.f - a * a);
+      dzf[j] = dc * cp * f * (1.f - f);
+      dzg[j] = dc * a * g * (1.f - g);
+      float dcp = dc * f;
+      if (p.pf) {
+        dcp += dzf[j] * p.pf[uq + j] + dzg[j] * p.pg[uq + j];
+        apf[j] += dzf[j] * cp; apo[j] += dzo[j] * svc[tt][j]; apg[j] += dzg[j] * cp;
+      }
+      dco[j] = dcp;
+    }
+    const int64_t hidx = (int64_t)row * n + uq;
+    if (p.dc_out) *(f32x4*)(p.dc_out + hidx) = dco;
+    float* dg = p.dG + (int64_t)row * K + uq;
+    *(f32x4*)(dg) = dza; *(f32x4*)(dg + n) = dzf; *(f32x4*)(dg + 2 * (int64_t)n) = dzo; *(f32x4*)(dg + 3 * (int64_t)n) = dzg;
+  }
+  if (p.pf && p.dpeep) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float vf = apf[j], vo = apo[j], vg = apg[j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { vf += __shfl_xor(vf, o, 64); vo += __shfl_xor(vo, o, 64); vg += __shfl_xor(vg, o, 64); }
+      if (unit_lane && bcol == 0) {
+        atomicAdd(p.dpeep + uq + j, vf);
+        atomicAdd(p.dpeep + n + uq + j, vo);
+        atomicAdd(p.dpeep + 2 * n + uq + j, vg);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int dl4j_fill_zero_bytes(void* p, size_t bytes, hipStream_t st);
@@ -778,6 +994,65 @@ DL4J_API int dl4j_lstm_steps_bwd(const void* E, const void* rw4t, int64_t ld_rwt
     else
       hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(n / 8), dim3(BWD_THREADS), lds, st, p);
     next = dGb + 4 * t * hn;
+    dc_cur = dc_nxt;
+    dc_nxt = (dc_nxt == dc_ws) ? dc_ws + hn : dc_ws;
+  }
+  DL4J_RET_LAST();
+}
+
+// ---------------------------------------------------------------------------------------------------------------- fp32 entry points
+static int lstm_f32_bwd_lds(int mb, int n) {
+  if (n <= 0 || mb <= 0 || n % 64 != 0 || n / 8 > 256 || mb > 64 * BWD_TILES || mb > 128) return 0;
+  const int64_t bytes = (int64_t)8 * (4 * n + 16) * 4;
+  return bytes <= 128 * 1024 ? (int)bytes : 0;               // + 24 KB static split-K buffer
+}
+DL4J_API int dl4j_lstm_steps_f32_supported(int mb, int n) { return lstm_f32_bwd_lds(mb, n) > 0 ? 1 : 0; }
+
+DL4J_API int dl4j_lstm_steps_fwd_f32(const float* xw, const float* rw4, int64_t ld_rw, const float* h0, const float* c0, const float* pf,
+                                     const float* po, const float* pg, const float* maskT, float* H, float* Cs, float* SV, int T, int mb, int n,
+                                     int reverse, hipStream_t st) {
+  if (T <= 0) return 0;
+  if (lstm_f32_bwd_lds(mb, n) == 0 || ld_rw % 4 != 0 || ((uintptr_t)rw4 & 15) || ((uintptr_t)h0 & 15) || ((uintptr_t)c0 & 15) ||
+      ((uintptr_t)H & 15) || ((uintptr_t)Cs & 15) || ((uintptr_t)SV & 15) || ((uintptr_t)xw & 15))
+    return -2;
+  if ((pf != nullptr) != (po != nullptr) || (pf != nullptr) != (pg != nullptr)) return -2;
+  const size_t hn = (size_t)mb * n;
+  const float* hp = h0;
+  const float* cp = c0;
+  for (int s = 0; s < T; ++s) {
+    const int t = reverse ? T - 1 - s : s;
+    LstmFwdF32 p{xw + 4 * t * hn, rw4, ld_rw, hp, cp, pf, po, pg, maskT ? maskT + (size_t)t * mb : nullptr, H + t * hn, Cs + t * hn,
+                 SV ? SV + 6 * t * hn : nullptr, mb, n};
+    hipLaunchKernelGGL(lstm_step_fwd_f32_kernel, dim3(n / 8), dim3(STEP_THREADS), 0, st, p);
+    hp = H + t * hn;
+    cp = Cs + t * hn;
+  }
+  DL4J_RET_LAST();
+}
+
+// dc_ws: [2, mb, n] fp32 scratch; dpeep [3, n] accumulated (zeroed by the caller) or null
+DL4J_API int dl4j_lstm_steps_bwd_f32(const float* E, const float* rw4t, int64_t ld_rwt, const float* SV, const float* Cs, const float* c0,
+                                     const float* pf, const float* po, const float* pg, const float* maskT, float* dG, float* dpeep, float* dc_ws,
+                                     int T, int mb, int n, int reverse, hipStream_t st) {
+  if (T <= 0) return 0;
+  const int lds = lstm_f32_bwd_lds(mb, n);
+  if (lds == 0 || ld_rwt % 4 != 0 || ((uintptr_t)rw4t & 15) || ((uintptr_t)dG & 15) || ((uintptr_t)E & 15) || ((uintptr_t)SV & 15) ||
+      ((uintptr_t)Cs & 15) || ((uintptr_t)c0 & 15) || ((uintptr_t)dc_ws & 15))
+    return -2;
+  if ((pf != nullptr) != (po != nullptr) || (pf != nullptr) != (pg != nullptr)) return -2;
+  static DeviceOnceLds lds_attr;
+  lds_attr.ensure((const void*)lstm_step_bwd_f32_kernel, lds);
+  const size_t hn = (size_t)mb * n;
+  const float* dc_cur = nullptr;
+  float* dc_nxt = dc_ws;
+  const float* next = nullptr;
+  for (int s = T - 1; s >= 0; --s) {
+    const int t = reverse ? T - 1 - s : s;
+    const int t_prev = reverse ? t + 1 : t - 1;
+    LstmBwdF32 p{E + t * hn, rw4t, ld_rwt, SV + 6 * t * hn, s == 0 ? c0 : Cs + t_prev * hn, pf, po, pg, maskT ? maskT + (size_t)t * mb : nullptr,
+                 dG + 4 * t * hn, dpeep, next, dc_cur, s > 0 ? dc_nxt : nullptr, mb, n};
+    hipLaunchKernelGGL(lstm_step_bwd_f32_kernel, dim3(n / 8), dim3(STEP_THREADS), lds, st, p);
+    next = dG + 4 * t * hn;
     dc_cur = dc_nxt;
     dc_nxt = (dc_nxt == dc_ws) ? dc_ws + hn : dc_ws;
   }

@@ -114,6 +114,11 @@ def persist_ok(xw, RW4, mb, n):
     return _PERSIST and xw.dtype == torch.bfloat16 and RW4.dtype == torch.bfloat16 and bool(L.hip().dl4j_lstm_persist_supported(L.c_int(mb), L.c_int(n)))
 
 
+def steps_f32_ok(xw, RW4, mb, n):
+    """fp32 sequences the fused fp32 step kernels support (n % 64 == 0, n <= 2048, mb <= 128)."""
+    return _PERSIST and xw.dtype == torch.float32 and RW4.dtype == torch.float32 and bool(L.hip().dl4j_lstm_steps_f32_supported(L.c_int(mb), L.c_int(n)))
+
+
 def seq_forward(xw, RW4, h0, c0, peep, mask, train, reverse):
     """xw [T, mb, 4n]. Returns (H [T, mb, n], state dict for seq_backward)."""
     T, mb, n4 = xw.shape
@@ -136,6 +141,11 @@ def seq_forward(xw, RW4, h0, c0, peep, mask, train, reverse):
                    L.ptr(SV), L.ptr(bar), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()), "lstm_fused_fwd")
         if _PERSIST_MODE == "grid" and _PERSIST_CHECK and int(bar[1]) != 0:
             raise RuntimeError("lstm_persist_fwd: inter-workgroup hand-off timed out (workgroups were not co-resident)")
+        return H, {"H": H, "Cs": Cs, "SV": SV, "h0": h0c, "c0": c0c, "peep": (pf, po, pg), "maskT": maskT}
+    if steps_f32_ok(xw, RW4, mb, n):
+        L.check(L.hip().dl4j_lstm_steps_fwd_f32(L.ptr(xw), L.ptr(RW4), L.c_int64(n), L.ptr(h0c), L.ptr(c0c), L.ptr(pf), L.ptr(po), L.ptr(pg),
+                                                L.ptr(maskT), L.ptr(H), L.ptr(Cs), L.ptr(SV), L.c_int(T), L.c_int(mb), L.c_int(n),
+                                                L.c_int(1 if reverse else 0), L.stream()), "lstm_steps_fwd_f32")
         return H, {"H": H, "Cs": Cs, "SV": SV, "h0": h0c, "c0": c0c, "peep": (pf, po, pg), "maskT": maskT}
     L.check(L.hip().dl4j_lstm_seq_fwd(L.ptr(xw), L.ptr(RW4), L.c_int64(n), L.ptr(h0c), L.ptr(c0c), L.ptr(pf), L.ptr(po), L.ptr(pg),
                                       L.ptr(maskT), L.ptr(H), L.ptr(Cs), L.ptr(SV), L.ptr(ws), L.c_int(T), L.c_int(mb), L.c_int(n),
@@ -166,6 +176,12 @@ def seq_backward(E, RW4, st, reverse):
                                                 L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(bar),
                                                 L.ptr(dc_ws), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()),
                     "lstm_steps_bwd")
+        return dG, _hprev(st, reverse), (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
+    if steps_f32_ok(E, rw4t, mb, n) and st["SV"] is not None:
+        dc_ws = torch.empty(2, mb, n, device=dev, dtype=torch.float32)
+        L.check(L.hip().dl4j_lstm_steps_bwd_f32(L.ptr(E), L.ptr(rw4t), L.c_int64(4 * n), L.ptr(st["SV"]), L.ptr(st["Cs"]), L.ptr(st["c0"]),
+                                                L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(dc_ws),
+                                                L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()), "lstm_steps_bwd_f32")
         return dG, _hprev(st, reverse), (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
     dh_ws = torch.empty(mb, n, device=dev, dtype=dt)
     dc_ws = torch.empty(2, mb, n, device=dev, dtype=dt)

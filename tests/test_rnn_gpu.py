@@ -205,3 +205,55 @@ def test_lstm_persistent_backward_matches_per_step_kernels_and_autograd(monkeypa
             refp = ppr[q].grad
             torch.testing.assert_close(dpp[k], refp, rtol=0.08, atol=0.05 * float(refp.abs().max()) + 1e-3)
             torch.testing.assert_close(dps[k], refp, rtol=0.08, atol=0.05 * float(refp.abs().max()) + 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,mb,n,peep,masked,reverse", [(6, 64, 512, False, False, False), (5, 33, 128, True, True, False),
+                                                        (4, 100, 256, True, False, True), (1, 8, 64, False, True, False)])
+def test_lstm_fp32_step_kernels_match_autograd(monkeypatch, T, mb, n, peep, masked, reverse):
+    """fp32 fused step kernels (fp32 MFMA) against torch autograd of the same recurrence, and against the per-step GEMM + cell path."""
+    from deeplearning4j_amd.ops import lstm as R
+    g = torch.Generator().manual_seed(23)
+    xw = (torch.randn(T, mb, 4 * n, generator=g) * 0.5).cuda()
+    RW4 = (torch.randn(4 * n, n, generator=g) / n ** 0.5).cuda().t()
+    h0, c0 = (torch.randn(mb, n, generator=g) * 0.3).cuda(), (torch.randn(mb, n, generator=g) * 0.3).cuda()
+    pp = [(torch.randn(n, generator=g) * 0.2).cuda() for _ in range(3)] if peep else None
+    mask = (torch.rand(mb, T, generator=g) > 0.2).float().cuda() if masked else None
+    E = (torch.randn(T, mb, n, generator=g) * 0.5).cuda()
+    monkeypatch.setattr(R, "_PERSIST", True)
+    assert R.steps_f32_ok(xw, RW4, mb, n)
+    H, st = R.seq_forward(xw, RW4, h0, c0, pp, mask, True, reverse)
+    dG, Hprev, dp = R.seq_backward(E, RW4, st, reverse)
+    monkeypatch.setattr(R, "_PERSIST", False)
+    Hs, sts = R.seq_forward(xw, RW4, h0, c0, pp, mask, True, reverse)
+    dGs, _, dps = R.seq_backward(E, RW4, sts, reverse)
+    xr = xw.clone().requires_grad_(True)
+    ppr = [q.clone().requires_grad_(True) for q in pp] if pp else None
+    W = RW4
+    h, c = h0, c0
+    Hl = [None] * T
+    for s in range(T):
+        t = T - 1 - s if reverse else s
+        z = xr[t] + h @ W
+        za, zf, zo, zg = z[:, :n], z[:, n:2 * n], z[:, 2 * n:3 * n], z[:, 3 * n:]
+        if ppr:
+            zf, zg = zf + c * ppr[0], zg + c * ppr[2]
+        a, f, g_ = torch.tanh(za), torch.sigmoid(zf), torch.sigmoid(zg)
+        cn = f * c + g_ * a
+        if ppr:
+            zo = zo + cn * ppr[1]
+        hn = torch.sigmoid(zo) * torch.tanh(cn)
+        if mask is not None:
+            m = mask[:, t].unsqueeze(1)
+            hn, cn = hn * m, cn * m
+        h, c = hn, cn
+        Hl[t] = hn
+    Href = torch.stack(Hl)
+    (Href * E).sum().backward()
+    torch.testing.assert_close(H, Href.detach(), rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(Hs, Href.detach(), rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(dG, xr.grad, rtol=2e-3, atol=5e-4)
+    torch.testing.assert_close(dGs, xr.grad, rtol=2e-3, atol=5e-4)
+    if pp:
+        for k in range(3):
+            torch.testing.assert_close(dp[k], ppr[k].grad, rtol=2e-3, atol=2e-3)

@@ -86,6 +86,22 @@ def main():
             loss.backward()
             opt.step()
     res["pytorch_nn_lstm_fp32_eager"] = round(timed(ref_step), 2)
+
+    # the same PyTorch model under bf16 autocast (MIOpen's bf16 RNN path where it has one), for a like-for-like bf16 comparison
+    def ref_step_bf16():
+        st = None
+        for s in range(0, T, TB):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                o, st = ref(xr[:, s:s + TB], st)
+            st = tuple(v.detach() for v in st)
+            loss = torch.nn.functional.cross_entropy(o.float().reshape(-1, V), yr[:, s:s + TB].reshape(-1))
+            loss.backward()
+            opt.step()
+    try:
+        res["pytorch_nn_lstm_bf16_autocast_eager"] = round(timed(ref_step_bf16), 2)
+    except Exception as e:
+        res["pytorch_nn_lstm_bf16_autocast_eager"] = "failed: %s" % (str(e)[:120],)
     best = min(v for k, v in res.items() if isinstance(v, float) and not k.endswith("_score") and not k.startswith("pytorch"))
     res.update(batch=B, seq_len=T, tbptt=TB, hidden=Hn, layers=NL, unit="ms per minibatch fit (4 tBPTT segments)",
                chars_per_sec_best=round(B * T / best * 1e3))
