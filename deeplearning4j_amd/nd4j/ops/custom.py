@@ -340,7 +340,9 @@ class OpExecutioner:
                     if (not tracked or getattr(fn, "_differentiable", False)) and usable(ins, i, t, b, d):
                         HELPER_HIT[name] += 1
                         return fn(ins, i, t, b, d)
-                if on_gpu:
+                if not ins:
+                    _helper_fail(name, "no array inputs: the helper cannot tell the device")
+                elif on_gpu:
                     _helper_fail(name, "autograd-tracked inputs" if tracked and not any(getattr(f, "_differentiable", False) for _, f in _PLATFORM[name])
                                  else "isUsable predicate rejected the arguments")
             elif on_gpu and allow_helpers:
