@@ -974,3 +974,68 @@ def _cbow_hip(ins, i, t, b, d):
 
 
 platform("cbow_inference", _cbow_ok)(_cbow_hip)
+
+
+# ------------------------------------------------------------------ lstmLayer on the fused LSTM sequence kernels (lstm_persist.hip)
+# Reference counterpart: the cuDNN platform helper of the same op (platform/cudnn/lstmLayer.cu). Same restrictions in spirit: default
+# activations, no cell clipping, no per-example sequence lengths; anything else runs the generic implementation.
+def _lstm_layer_args(ins, i, b):
+    a = list(i) + [0] * 5
+    bb = list(b) + [False] * 8
+    has_b, has_seq, has_hi, has_ci, has_p = bb[:5]
+    k = 3
+    bias = ins[k] if has_b else None
+    k += has_b
+    seq = ins[k] if has_seq else None
+    k += has_seq
+    hI = ins[k] if has_hi else None
+    k += has_hi
+    cI = ins[k] if has_ci else None
+    k += has_ci
+    Wp = ins[k] if has_p else None
+    return dict(fmt=a[0], dir=a[1], gact=a[2] if len(i) > 2 else 2, cact=a[3] if len(i) > 3 else 0, oact=a[4] if len(i) > 4 else 0,
+                bias=bias, seq=seq, hI=hI, cI=cI, Wp=Wp, ret=bb[5:8])
+
+
+def _lstm_layer_ok(ins, i, t, b, d):
+    from ...ops import lstm as R
+    if len(ins) < 3 or ins[0].dim() != 3:
+        return False
+    a = _lstm_layer_args(ins, i, b)
+    if a["gact"] != 2 or a["cact"] != 0 or a["oact"] != 0 or (t and float(t[0]) != 0.0) or a["seq"] is not None or a["fmt"] not in (0, 1, 2, 3):
+        return False
+    x = ins[0]
+    B = x.shape[1] if a["fmt"] in (0, 3) else x.shape[0]
+    n = ins[2].shape[-2]
+    ts = [v for v in (ins[1], ins[2], a["bias"], a["hI"], a["cI"], a["Wp"]) if v is not None]
+    if not all(v.is_cuda and v.dtype == x.dtype for v in ts) or not R.lstm_layer_fused_ok(x, n, B):
+        return False
+    grad = torch.is_grad_enabled() and any(v.requires_grad for v in [x] + ts)
+    if grad and (a["ret"][2] or any(v is not None and v.requires_grad for v in (a["hI"], a["cI"]))):
+        return False                                  # gradients into / out of the cell state stay on the generic path
+    return True
+
+
+@platform("lstmLayer", _lstm_layer_ok, differentiable=True)
+def _lstm_layer_hip(ins, i, t, b, d):
+    from ...ops import lstm as R
+    a = _lstm_layer_args(ins, i, b)
+    x, Wx, Wr = ins[0], ins[1], ins[2]
+    fmt, dm = a["fmt"], a["dir"]
+    xs = {0: lambda: x, 1: lambda: x.permute(1, 0, 2), 2: lambda: x.permute(2, 0, 1), 3: lambda: x}[fmt]()
+    pick = lambda v, k: None if v is None else v[k]
+    if dm < 2:
+        hs, hl, cl = R.lstm_layer_direction(xs, Wx, Wr, a["bias"], a["hI"], a["cI"], a["Wp"], dm == 1)
+    else:
+        f = R.lstm_layer_direction(xs, Wx[0], Wr[0], pick(a["bias"], 0), pick(a["hI"], 0), pick(a["cI"], 0), pick(a["Wp"], 0), False)
+        r = R.lstm_layer_direction(xs, Wx[1], Wr[1], pick(a["bias"], 1), pick(a["hI"], 1), pick(a["cI"], 1), pick(a["Wp"], 1), True)
+        hs = f[0] + r[0] if dm == 2 else (torch.cat([f[0], r[0]], -1) if dm == 3 else torch.stack([f[0], r[0]], 1))
+        hl, cl = torch.stack([f[1], r[1]]), torch.stack([f[2], r[2]])
+    outs = []
+    if a["ret"][0]:
+        outs.append(hs if dm == 4 else {0: lambda: hs, 1: lambda: hs.permute(1, 0, 2), 2: lambda: hs.permute(1, 2, 0), 3: lambda: hs}[fmt]())
+    if a["ret"][1]:
+        outs.append(hl)
+    if a["ret"][2]:
+        outs.append(cl)
+    return tuple(outs)

@@ -273,3 +273,73 @@ def gru_sequence(x, h0, Wx, Wh, b):
     if b is not None:
         xz = xz + b
     return _GruSeq.apply(xz, h0, Wh)
+
+
+# ------------------------------------------------------------------------------------------------------ lstmLayer op on the fused kernels
+def _lib_to_kernel_perm(n, device):
+    """Column permutation from libnd4j's gate order [i | f | c' | o] (lstmLayer.cpp:200-249) to the kernels' DL4J order
+    [candidate | forget | output | input]."""
+    a = torch.arange(n, device=device)
+    return torch.cat([a + 2 * n, a + n, a + 3 * n, a])
+
+
+class _LstmLayerFn(torch.autograd.Function):
+    """One direction of the libnd4j ``lstmLayer`` op (sigmoid gates, tanh cell / output activation, no clipping, full-length
+    sequences) on the fused sequence kernels — the role cuDNN plays for the reference (platform/cudnn/lstmLayer.cu). Inputs in libnd4j
+    layout: xs [T, B, nIn], Wx [nIn, 4n], Wr [n, 4n], bias [4n] or None, h0 / c0 [B, n], Wp [3n] or None. Returns (H [T, B, n], hL, cL)."""
+
+    @staticmethod
+    def forward(ctx, xs, Wx, Wr, bias, h0, c0, Wp, reverse):
+        T, B, nIn = xs.shape
+        n = Wr.shape[0]
+        perm = _lib_to_kernel_perm(n, xs.device)
+        Wxp, Wrp = Wx.index_select(1, perm), Wr.index_select(1, perm)
+        xw = xs.reshape(T * B, nIn) @ Wxp
+        if bias is not None:
+            xw = xw + bias.index_select(0, perm)
+        xw = xw.reshape(T, B, 4 * n).contiguous()
+        RW4 = Wrp.t().contiguous().t()                   # [n, 4n] view of a [4n, n] K-contiguous image
+        peep = None if Wp is None else (Wp[n:2 * n], Wp[2 * n:], Wp[:n])          # (forget, output, input) peepholes
+        H, st = seq_forward(xw, RW4, h0, c0, peep, None, True, bool(reverse))
+        last = 0 if reverse else T - 1
+        ctx.save_for_backward(xs, Wxp, perm)
+        ctx.st, ctx.RW4, ctx.reverse, ctx.has_bias, ctx.has_peep, ctx.last = st, RW4, bool(reverse), bias is not None, Wp is not None, last
+        return H, H[last].clone(), st["Cs"][last].clone()
+
+    @staticmethod
+    def backward(ctx, gH, ghL, gcL):
+        if gcL is not None and bool((gcL != 0).any()):
+            raise NotImplementedError("lstmLayer on the fused kernels: a gradient flowing into the last cell state is not supported; "
+                                      "disable helpers (Environment.allowHelpers(False)) for this graph")
+        xs, Wxp, perm = ctx.saved_tensors
+        T, B, nIn = xs.shape
+        n = ctx.RW4.shape[0]
+        E = torch.zeros(T, B, n, device=xs.device, dtype=xs.dtype) if gH is None else gH.to(xs.dtype).contiguous().clone()
+        if ghL is not None:
+            E[ctx.last] += ghL.to(xs.dtype)
+        dG, Hprev, dpeep = seq_backward(E, ctx.RW4, ctx.st, ctx.reverse)
+        dG2 = dG.reshape(T * B, 4 * n)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(4 * n, device=perm.device)
+        dWx = (xs.reshape(T * B, nIn).t() @ dG2).index_select(1, inv)
+        dWr = (Hprev.reshape(T * B, n).t() @ dG2).index_select(1, inv)
+        db = dG2.float().sum(0).to(xs.dtype).index_select(0, inv) if ctx.has_bias else None
+        dx = (dG2 @ Wxp.t()).reshape(T, B, nIn)
+        dWp = torch.cat([dpeep[2], dpeep[0], dpeep[1]]).to(xs.dtype) if ctx.has_peep else None
+        return dx, dWx, dWr, db, None, None, dWp, None
+
+
+def lstm_layer_fused_ok(x, n, mb):
+    """Shapes / dtypes the fused lstmLayer route supports."""
+    if not (L.use_hip(x) and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    fn = L.hip().dl4j_lstm_steps_f32_supported if x.dtype == torch.float32 else L.hip().dl4j_lstm_persist_supported
+    return _PERSIST and bool(fn(L.c_int(mb), L.c_int(n)))
+
+
+def lstm_layer_direction(xs, Wx, Wr, bias, h0, c0, Wp, reverse):
+    T, B, _ = xs.shape
+    n = Wr.shape[0]
+    h0 = xs.new_zeros(B, n) if h0 is None else h0
+    c0 = xs.new_zeros(B, n) if c0 is None else c0
+    return _LstmLayerFn.apply(xs.contiguous(), Wx, Wr, bias, h0, c0, Wp, reverse)
