@@ -10,3 +10,5 @@ from .embeddings import InMemoryLookupTable, WordVectorsImpl, SequenceVectors, W
 from .fasttext import FastText  # noqa: F401
 from .serializer import WordVectorSerializer  # noqa: F401
 from .bert import BertIterator, BertMaskedLMMasker, CollectionLabeledSentenceProvider, CollectionLabeledPairSentenceProvider  # noqa: F401
+from .text import (BagOfWordsVectorizer, TfidfVectorizer, CnnSentenceDataSetIterator, UnknownWordHandling, Format, Window, Windows,  # noqa: F401,E402
+                   WindowConverter, ContextLabelRetriever, InvertedIndex, StaticWord2Vec)
