@@ -963,9 +963,11 @@ DL4J_API int dl4j_lstm_persist_bwd(const void* E, const void* rw4t, int64_t ld_r
 }
 
 // The backward kernel launched once per time step (see dl4j_lstm_steps_fwd). dc_ws: [2, mb, n] fp32 scratch for dL/dc between launches.
+// dc_last: optional [mb, n] fp32 gradient flowing into the cell state after the last step. The gradient of the initial cell state is
+// left in dc_ws[(T - 1) % 2].
 DL4J_API int dl4j_lstm_steps_bwd(const void* E, const void* rw4t, int64_t ld_rwt, const void* SV, const void* Cs, const void* c0,
                                  const float* pf, const float* po, const float* pg, const float* maskT, void* dG, float* dpeep, unsigned* bar,
-                                 float* dc_ws, int T, int mb, int n, int reverse, hipStream_t st) {
+                                 float* dc_ws, const float* dc_last, int T, int mb, int n, int reverse, hipStream_t st) {
   if (T <= 0) return 0;
   const int lds = lstm_persist_bwd_lds(mb, n);
   if (lds == 0 || ld_rwt % 8 != 0 || ((uintptr_t)rw4t & 15) || ((uintptr_t)dG & 15) || ((uintptr_t)E & 7) || ((uintptr_t)SV & 7) ||
@@ -981,14 +983,14 @@ DL4J_API int dl4j_lstm_steps_bwd(const void* E, const void* rw4t, int64_t ld_rwt
   const bf16_t* SVb = (const bf16_t*)SV;
   const bf16_t* Csb = (const bf16_t*)Cs;
   bf16_t* dGb = (bf16_t*)dG;
-  float* dc_cur = nullptr;          // dL/dc into the step being launched (null for the first launch = zeros)
+  const float* dc_cur = dc_last;    // dL/dc into the step being launched (null = zeros)
   float* dc_nxt = dc_ws;
   const bf16_t* next = nullptr;
   for (int s = T - 1; s >= 0; --s) {
     const int t = reverse ? T - 1 - s : s;
     const int t_prev = reverse ? t + 1 : t - 1;
     LstmBwdP p{Eb + t * hn, (const bf16_t*)rw4t, ld_rwt, SVb + 6 * t * hn, Csb, s == 0 ? (const bf16_t*)c0 : Csb + t_prev * hn, pf, po, pg,
-               maskT ? maskT + (size_t)t * mb : nullptr, dGb + 4 * t * hn, dpeep, bar, 1, mb, n, 0, next, dc_cur, s > 0 ? dc_nxt : nullptr};
+               maskT ? maskT + (size_t)t * mb : nullptr, dGb + 4 * t * hn, dpeep, bar, 1, mb, n, 0, next, dc_cur, dc_nxt};
     if (getenv("DL4J_AMD_LSTM_STEP_BWD_NOLDS") != nullptr)
       hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(n / 8), dim3(STEP_THREADS), 0, st, p);
     else
@@ -1033,7 +1035,7 @@ DL4J_API int dl4j_lstm_steps_fwd_f32(const float* xw, const float* rw4, int64_t 
 // dc_ws: [2, mb, n] fp32 scratch; dpeep [3, n] accumulated (zeroed by the caller) or null
 DL4J_API int dl4j_lstm_steps_bwd_f32(const float* E, const float* rw4t, int64_t ld_rwt, const float* SV, const float* Cs, const float* c0,
                                      const float* pf, const float* po, const float* pg, const float* maskT, float* dG, float* dpeep, float* dc_ws,
-                                     int T, int mb, int n, int reverse, hipStream_t st) {
+                                     const float* dc_last, int T, int mb, int n, int reverse, hipStream_t st) {
   if (T <= 0) return 0;
   const int lds = lstm_f32_bwd_lds(mb, n);
   if (lds == 0 || ld_rwt % 4 != 0 || ((uintptr_t)rw4t & 15) || ((uintptr_t)dG & 15) || ((uintptr_t)E & 15) || ((uintptr_t)SV & 15) ||
@@ -1043,14 +1045,14 @@ DL4J_API int dl4j_lstm_steps_bwd_f32(const float* E, const float* rw4t, int64_t 
   static DeviceOnceLds lds_attr;
   lds_attr.ensure((const void*)lstm_step_bwd_f32_kernel, lds);
   const size_t hn = (size_t)mb * n;
-  const float* dc_cur = nullptr;
+  const float* dc_cur = dc_last;
   float* dc_nxt = dc_ws;
   const float* next = nullptr;
   for (int s = T - 1; s >= 0; --s) {
     const int t = reverse ? T - 1 - s : s;
     const int t_prev = reverse ? t + 1 : t - 1;
     LstmBwdF32 p{E + t * hn, rw4t, ld_rwt, SV + 6 * t * hn, s == 0 ? c0 : Cs + t_prev * hn, pf, po, pg, maskT ? maskT + (size_t)t * mb : nullptr,
-                 dG + 4 * t * hn, dpeep, next, dc_cur, s > 0 ? dc_nxt : nullptr, mb, n};
+                 dG + 4 * t * hn, dpeep, next, dc_cur, dc_nxt, mb, n};
     hipLaunchKernelGGL(lstm_step_bwd_f32_kernel, dim3(n / 8), dim3(STEP_THREADS), lds, st, p);
     next = dG + 4 * t * hn;
     dc_cur = dc_nxt;

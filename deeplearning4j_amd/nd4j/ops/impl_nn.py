@@ -869,7 +869,14 @@ def _lstm_layer_bp(ins, i, t, b, d):
     fw, gs = list(ins[:len(ins) - n_out]), list(ins[len(ins) - n_out:])
     leaves = [x.detach().clone().requires_grad_(True) if x.is_floating_point() else x for x in fw]
     with torch.enable_grad():
-        ys = _lstm_layer(leaves, i, t, b, d)
+        # the fused sequence kernels where they apply (same predicate as the forward op's platform route), else the generic math
+        from .impl_platform import _lstm_layer_hip, _lstm_layer_ok
+        from .custom import HELPER_HIT
+        if _lstm_layer_ok(leaves, i, t, b, d):
+            HELPER_HIT["lstmLayer_bp"] += 1
+            ys = _lstm_layer_hip(leaves, i, t, b, d)
+        else:
+            ys = _lstm_layer(leaves, i, t, b, d)
     req = [x for x in leaves if x.requires_grad]
     return torch.autograd.grad(ys, req, gs, allow_unused=True)
 

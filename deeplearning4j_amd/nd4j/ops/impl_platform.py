@@ -1011,8 +1011,8 @@ def _lstm_layer_ok(ins, i, t, b, d):
     if not all(v.is_cuda and v.dtype == x.dtype for v in ts) or not R.lstm_layer_fused_ok(x, n, B):
         return False
     grad = torch.is_grad_enabled() and any(v.requires_grad for v in [x] + ts)
-    if grad and (a["ret"][2] or any(v is not None and v.requires_grad for v in (a["hI"], a["cI"]))):
-        return False                                  # gradients into / out of the cell state stay on the generic path
+    if grad and R._PERSIST_MODE != "steps" and (a["ret"][2] or any(v is not None and v.requires_grad for v in (a["hI"], a["cI"]))):
+        return False                                  # cell-state gradients come from the per-step launches only
     return True
 
 

@@ -153,11 +153,13 @@ def seq_forward(xw, RW4, h0, c0, peep, mask, train, reverse):
     return H, {"H": H, "Cs": Cs, "SV": SV, "h0": h0c, "c0": c0c, "peep": (pf, po, pg), "maskT": maskT}
 
 
-def seq_backward(E, RW4, st, reverse):
+def seq_backward(E, RW4, st, reverse, dc_last=None):
     """E [T, mb, n] = dL/dH. Returns (dG [T, mb, 4n], Hprev [T, mb, n], [dwFF, dwOO, dwGG] or None)."""
     T, mb, n = E.shape
     dev, dt = E.device, E.dtype
     E = E.contiguous()
+    dcl = None if dc_last is None else dc_last.float().contiguous()      # gradient into the last cell state (fused step kernels only)
+    st.pop("dc0_grad", None)
     rw4t = RW4.contiguous()                       # [n, 4n]: the NT operand of dh_prev = dgates . RW4^T
     dG = torch.empty(T, mb, 4 * n, device=dev, dtype=dt)
     pf, po, pg = st["peep"]
@@ -174,14 +176,17 @@ def seq_backward(E, RW4, st, reverse):
             dc_ws = torch.empty(2, mb, n, device=dev, dtype=torch.float32)
             L.check(L.hip().dl4j_lstm_steps_bwd(L.ptr(E), L.ptr(rw4t), L.c_int64(4 * n), L.ptr(st["SV"]), L.ptr(st["Cs"]), L.ptr(st["c0"]),
                                                 L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(bar),
-                                                L.ptr(dc_ws), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()),
-                    "lstm_steps_bwd")
+                                                L.ptr(dc_ws), L.ptr(dcl), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0),
+                                                L.stream()), "lstm_steps_bwd")
+            st["dc0_grad"] = dc_ws[(T - 1) % 2]
         return dG, _hprev(st, reverse), (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
     if steps_f32_ok(E, rw4t, mb, n) and st["SV"] is not None:
         dc_ws = torch.empty(2, mb, n, device=dev, dtype=torch.float32)
         L.check(L.hip().dl4j_lstm_steps_bwd_f32(L.ptr(E), L.ptr(rw4t), L.c_int64(4 * n), L.ptr(st["SV"]), L.ptr(st["Cs"]), L.ptr(st["c0"]),
                                                 L.ptr(pf), L.ptr(po), L.ptr(pg), L.ptr(st["maskT"]), L.ptr(dG), L.ptr(dpeep), L.ptr(dc_ws),
-                                                L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()), "lstm_steps_bwd_f32")
+                                                L.ptr(dcl), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(1 if reverse else 0), L.stream()),
+                "lstm_steps_bwd_f32")
+        st["dc0_grad"] = dc_ws[(T - 1) % 2]
         return dG, _hprev(st, reverse), (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
     dh_ws = torch.empty(mb, n, device=dev, dtype=dt)
     dc_ws = torch.empty(2, mb, n, device=dev, dtype=dt)
@@ -308,16 +313,16 @@ class _LstmLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gH, ghL, gcL):
-        if gcL is not None and bool((gcL != 0).any()):
-            raise NotImplementedError("lstmLayer on the fused kernels: a gradient flowing into the last cell state is not supported; "
-                                      "disable helpers (Environment.allowHelpers(False)) for this graph")
         xs, Wxp, perm = ctx.saved_tensors
         T, B, nIn = xs.shape
         n = ctx.RW4.shape[0]
         E = torch.zeros(T, B, n, device=xs.device, dtype=xs.dtype) if gH is None else gH.to(xs.dtype).contiguous().clone()
         if ghL is not None:
             E[ctx.last] += ghL.to(xs.dtype)
-        dG, Hprev, dpeep = seq_backward(E, ctx.RW4, ctx.st, ctx.reverse)
+        dG, Hprev, dpeep = seq_backward(E, ctx.RW4, ctx.st, ctx.reverse, dc_last=gcL)
+        dc0 = ctx.st.get("dc0_grad")
+        if dc0 is None and (gcL is not None or ctx.needs_input_grad[5]):
+            raise NotImplementedError("lstmLayer: cell-state gradients need the fused step kernels (DL4J_AMD_LSTM_PERSIST_MODE=steps)")
         dG2 = dG.reshape(T * B, 4 * n)
         inv = torch.empty_like(perm)
         inv[perm] = torch.arange(4 * n, device=perm.device)
@@ -326,7 +331,10 @@ class _LstmLayerFn(torch.autograd.Function):
         db = dG2.float().sum(0).to(xs.dtype).index_select(0, inv) if ctx.has_bias else None
         dx = (dG2 @ Wxp.t()).reshape(T, B, nIn)
         dWp = torch.cat([dpeep[2], dpeep[0], dpeep[1]]).to(xs.dtype) if ctx.has_peep else None
-        return dx, dWx, dWr, db, None, None, dWp, None
+        first = T - 1 if ctx.reverse else 0                       # the step that consumed h0 / c0
+        dh0 = (dG[first] @ ctx.RW4.t()) if ctx.needs_input_grad[4] else None      # RW4 [n, 4n] in kernel gate order, like dG
+        dc0g = dc0.to(xs.dtype) if (ctx.needs_input_grad[5] and dc0 is not None) else None
+        return dx, dWx, dWr, db, dh0, dc0g, dWp, None
 
 
 def lstm_layer_fused_ok(x, n, mb):

@@ -275,11 +275,11 @@ def test_lstm_layer_op_fused_route_matches_generic(dtype, fmt, dir_mode, peep):
     Wx, Wr, bias = mk(*((2,) if bid else ()), nIn, 4 * n), mk(*((2,) if bid else ()), n, 4 * n), mk(*((2,) if bid else ()), 4 * n)
     hI, cI = mk(*((2,) if bid else ()), B, n), mk(*((2,) if bid else ()), B, n)
     Wp = mk(*((2,) if bid else ()), 3 * n) if peep else None
-    bargs = [True, False, True, True, peep, True, True, False]
+    bargs = [True, False, True, True, peep, True, True, True]          # full sequence, last h and last c returned; all of them get gradients
     iargs = [fmt, dir_mode, 2, 0, 0]
 
     def run(helpers):
-        leaves = [v.to(dtype).cuda().requires_grad_(k < 4 or k == 6) for k, v in enumerate([x, Wx, Wr, bias, hI, cI] + ([Wp] if peep else []))]
+        leaves = [v.to(dtype).cuda().requires_grad_(True) for v in [x, Wx, Wr, bias, hI, cI] + ([Wp] if peep else [])]
         Environment.getInstance().allowHelpers(helpers)
         try:
             OpExecutioner.resetHelperStatistics()
