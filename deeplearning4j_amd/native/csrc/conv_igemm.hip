@@ -47,7 +47,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool FIN>
 __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA blocks per wave in M / N
   constexpr int AI = BM / 32, BI = BN / 32;   // 16-byte loads per thread per tile for A / B
@@ -189,13 +189,14 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
     const int qs = tid / BN, col = tid - qs * BN;
     const float v = sS[(0 * 2 + qs) * BN + col] + sS[(1 * 2 + qs) * BN + col];
     float* dst = p.stats + ((int64_t)mt * 2 + qs) * p.K + n0 + col;
-    if (p.fin.cnt != nullptr) ticket::st_agent(dst, v); else *dst = v;      // write-through only when another block reads it
+    if (FIN && p.fin.cnt != nullptr) ticket::st_agent(dst, v); else *dst = v;      // write-through only when another block reads it
   }
   // in-kernel BatchNorm finalize (ticket.h): the ticket is taken BEFORE the output tile is stored, so only the 2*BN statistic
   // stores are waited for and the atomic's round trip overlaps the tile stores
+  // FIN is a template parameter: the default instantiation carries none of the hand-off code (it cost the plain kernel ~5 %)
   __shared__ int s_last;
   const ticket::BnFin& f = p.fin;
-  const bool fin = f.cnt != nullptr;
+  const bool fin = FIN && f.cnt != nullptr;
   const int G = fin ? f.G : 1, ngroups = (p.mtiles + G - 1) / G;
   const int g = mt / G, gbeg = g * G, gend = (gbeg + G < p.mtiles) ? gbeg + G : p.mtiles;
   unsigned tk = 0;
@@ -247,8 +248,15 @@ static int launch_fwd(IGemmP& p, hipStream_t st) {
   int smem = p.nbuf * (BM + BN) * 128;
   if (smem < epi) smem = epi;
   static DeviceOnceLds lds_attr;
-  lds_attr.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN>), 2 * (BM + BN) * 128 > epi ? 2 * (BM + BN) * 128 : epi);
-  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+  const int want = 2 * (BM + BN) * 128 > epi ? 2 * (BM + BN) * 128 : epi;
+  if (p.fin.cnt != nullptr) {
+    static DeviceOnceLds lds_attr_fin;
+    lds_attr_fin.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, true>), want);
+    hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, true>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+    DL4J_RET_LAST();
+  }
+  lds_attr.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, false>), want);
+  hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, false>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
   DL4J_RET_LAST();
 }
 
