@@ -101,7 +101,7 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, f
 //           is recomputed as [x*mscale + mshift > 0] so that the activation tensor is not re-read.
 // block = 256 threads: cpb channel-vectors x rpi rows per iteration.
 // ---------------------------------------------------------------------------------------
-template <typename T, int V, int MODE>
+template <typename T, int V, int MODE, bool FUSED>
 __global__ void __launch_bounds__(256) bn_colreduce_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ out,
     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -162,10 +162,10 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
       for (int r = 0; r < rpi; ++r) { s0 += red[j * 256 + r * cpb + c_in]; s1 += red[(V + j) * 256 + r * cpb + c_in]; }
       float* d0 = partial + ((int64_t)blockIdx.y * 2) * C + cvec * V + j;
       float* d1 = partial + ((int64_t)blockIdx.y * 2 + 1) * C + cvec * V + j;
-      if (cnt != nullptr) { ticket::st_agent(d0, s0); ticket::st_agent(d1, s1); } else { *d0 = s0; *d1 = s1; }
+      if (FUSED && cnt != nullptr) { ticket::st_agent(d0, s0); ticket::st_agent(d1, s1); } else { *d0 = s0; *d1 = s1; }
     }
   }
-  if (cnt == nullptr) return;
+  if (!FUSED || cnt == nullptr) return;
   // ---------------- second stage inside this launch (ticket.h): the last block of each group of G row-blocks sums the group's
   // partial rows, the last group sums the group results into sums[2C] (+ the dbeta / dgamma gradient views)
   __shared__ int s_last;
@@ -258,12 +258,13 @@ static int launch_colreduce(const void* x, const void* dy, const void* out, cons
   // fused second stage: counters laid out as [gx] level-2 + [gx][ngroups] level-1 (BN_TICKET_COUNTERS entries available)
   const bool fused = cnt != nullptr && gpart != nullptr && (int64_t)gx * (1 + (gy + G - 1) / G) <= BN_TICKET_COUNTERS;
   unsigned* c = fused ? cnt : nullptr;
-  if (vec_ok)
-    hipLaunchKernelGGL((bn_colreduce_kernel<T, VFULL, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
-                       (const T*)out, mean, invstd, mscale, mshift, partial, M, C, cpb, rpi, sums, out0, out1, gpart, c, G);
-  else
-    hipLaunchKernelGGL((bn_colreduce_kernel<T, 1, MODE>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy,
-                       (const T*)out, mean, invstd, mscale, mshift, partial, M, C, cpb, rpi, sums, out0, out1, gpart, c, G);
+#define COLREDUCE_LAUNCH(VV, FF)                                                                                             \
+  hipLaunchKernelGGL((bn_colreduce_kernel<T, VV, MODE, FF>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)out, mean, \
+                     invstd, mscale, mshift, partial, M, C, cpb, rpi, sums, out0, out1, gpart, c, G)
+  // the hand-off code is a template parameter: carried in the plain kernel it costs registers the bandwidth-bound loop wants
+  if (vec_ok) { if (fused) COLREDUCE_LAUNCH(VFULL, true); else COLREDUCE_LAUNCH(VFULL, false); }
+  else { if (fused) COLREDUCE_LAUNCH(1, true); else COLREDUCE_LAUNCH(1, false); }
+#undef COLREDUCE_LAUNCH
   if (!fused)
     hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, st, partial, (int)gy, C, sums, out0,
                        out1);
