@@ -14,6 +14,8 @@ Parameter layout is DL4J's (LSTMParamInitializer.java:122-145): W [nIn,4n], RW [
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from ...nd4j.activations import ActivationSigmoid, ActivationTanH
@@ -50,8 +52,9 @@ class LSTMImpl(LayerImpl):
     def rnnSetPreviousState(self, s):
         self.stateMap = dict(s)
 
-    def forward(self, x, train=False, initial_state=None, store_state=False):
-        """x: [mb, nIn, T] -> [mb, n, T]."""
+    def forward(self, x, train=False, initial_state=None, store_state=False, fork=None):
+        """x: [mb, nIn, T] -> [mb, n, T]. ``fork`` (a _side_stream): the native recurrence is issued on the side stream, the input
+        projection (a library GEMM) stays on the current one."""
         x = self._dropout_in(x, train)
         if x.dtype != self.ctx.cdtype:
             x = x.to(self.ctx.cdtype)
@@ -73,7 +76,8 @@ class LSTMImpl(LayerImpl):
         mask = self.maskArray
         if LSTMOP.native_seq_ok(xw, RW4, n, c.activationFn, c.gateActivationFn):
             # whole sequence issued from C++ (native/csrc/rnn_seq.hip): recurrent GEMM on the in-tree MFMA kernel + fused cell
-            H, st = LSTMOP.seq_forward(xw, RW4, h, cs, peep, mask, train, self.reverse)
+            with (fork.fork(x, xw, h, cs) if fork is not None else contextlib.nullcontext()):
+                H, st = LSTMOP.seq_forward(xw, RW4, h, cs, peep, mask, train, self.reverse)
             if train:
                 self._saved, self._xt, self._dims, self._peep = ("native", st), xt, (mb, nIn, T, n), peep
             t_last = 0 if self.reverse else T - 1
@@ -102,14 +106,19 @@ class LSTMImpl(LayerImpl):
 
     def backward(self, eps):
         """eps: [mb, n, T] -> dx [mb, nIn, T]; writes dW, dRW, db."""
+        return self.backward_finish(self.backward_recur(eps))
+
+    def backward_recur(self, eps, fork=None):
+        """The time recursion of the backward pass: (dG [T, mb, 4n], Hprev [T, mb, n], dpeep). With ``fork`` the native loop is issued on the
+        side stream."""
         c = self.conf
         mb, nIn, T, n = self._dims
-        k = self.prefix
         W, RW = self._p("W"), self._p("RW")
         RW4 = RW[:, :4 * n]
         E = eps.permute(2, 0, 1).to(W.dtype)                           # [T, mb, n]
         if isinstance(self._saved, tuple) and self._saved[0] == "native":
-            dG, Hprev, dpeep = LSTMOP.seq_backward(E, RW4, self._saved[1], self.reverse)
+            with (fork.fork(eps, E, self._saved) if fork is not None else contextlib.nullcontext()):
+                dG, Hprev, dpeep = LSTMOP.seq_backward(E, RW4, self._saved[1], self.reverse)
             self._saved = []
         else:
             dG = torch.empty(T, mb, 4 * n, dtype=W.dtype, device=W.device)
@@ -128,6 +137,14 @@ class LSTMImpl(LayerImpl):
             if dp is not None:
                 for i in range(3):
                     dpeep[i] += dp[i]
+        return dG, Hprev, dpeep
+
+    def backward_finish(self, rec):
+        """Weight / bias / input gradients from the recursion's outputs (library GEMMs, current stream)."""
+        dG, Hprev, dpeep = rec
+        mb, nIn, T, n = self._dims
+        k = self.prefix
+        W = self._p("W")
         dG2 = dG.view(T * mb, 4 * n)
         gW, gRW, gb = self.grads["W" + k], self.grads["RW" + k], self.grads["b" + k]
         gW.copy_(torch.matmul(self._xt.t(), dG2))
@@ -145,6 +162,79 @@ class LSTMImpl(LayerImpl):
         super().clear()
         self._saved = None
         self._xt = None
+
+
+_SIDE_STREAMS = {}
+
+
+class _side_stream:
+    """Fork / join of a second HIP stream so that the two directions of a bidirectional layer overlap on the chip (each per-step launch
+    of the recurrence fills 64 of 256 CUs at the char-RNN shape). ``fork()`` makes the side stream wait for everything queued on the
+    current one and returns the context that issues on it; ``join()`` makes the current stream wait for the side stream. The pattern is
+    legal inside a hipGraph capture (the side stream joins the capture through the first wait and is merged back before the capture
+    ends). Tensors allocated on the side stream are released only after the join and every later use of the side stream starts with a
+    wait on the current one, so the caching allocator's per-stream reuse stays ordered.
+
+    Only this framework's own recurrence kernels are issued on the side stream. Library GEMMs stay on the current stream: the fp32
+    input-projection GEMM of the vendor library is a persistent stream-K style kernel whose workgroups wait for each other, and two of
+    them launched from two streams at the same time were measured to dead-lock the device (each holds CUs the other needs;
+    profiles/r2_lstm_persistent.md). The kernels of native/csrc never wait on another workgroup in their per-step form, so they can share
+    the chip with anything. On the CPU, or with ``DL4J_AMD_BIDIR_STREAMS=0``, ``active`` is False and callers run in line."""
+
+    def __init__(self, x):
+        import os
+        self.cur = self.side = None
+        if x.is_cuda and os.environ.get("DL4J_AMD_BIDIR_STREAMS", "1") != "0":
+            dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+            if dev not in _SIDE_STREAMS:
+                _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            self.side = _SIDE_STREAMS[dev]
+            self.cur = torch.cuda.current_stream(dev)
+        self.forked = False
+
+    @property
+    def active(self):
+        return self.side is not None
+
+    def fork(self, *inputs):
+        """``inputs``: tensors (or containers of them, e.g. the forward state with its current-stream h0 / c0) allocated on the current
+        stream that the side stream reads. They are held until the join, so that the caching
+        allocator cannot hand their blocks to later current-stream work while the side stream still reads them."""
+        self.side.wait_stream(self.cur)
+        self.forked = True
+        self.held = inputs
+        return torch.cuda.stream(self.side)
+
+    def join(self):
+        if self.forked:
+            self.cur.wait_stream(self.side)
+            self.forked = False
+        self.held = ()
+
+
+def _overlap_forward(f, b, xf, xb, train):
+    """(yf, yb) of two independent LSTMImpl directions; b's recurrence on the side stream when both run the native loop."""
+    ss = _side_stream(xf)
+    if not ss.active or not (isinstance(f, LSTMImpl) and isinstance(b, LSTMImpl)):
+        return f.forward(xf, train), b.forward(xb, train)
+    try:
+        yb = b.forward(xb, train, fork=ss)
+        yf = f.forward(xf, train)
+    finally:
+        ss.join()
+    return yf, yb
+
+
+def _overlap_backward(f, b, ef, eb):
+    ss = _side_stream(ef)
+    if not ss.active or not (isinstance(f, LSTMImpl) and isinstance(b, LSTMImpl)):
+        return f.backward(ef), b.backward(eb)
+    try:
+        rec = b.backward_recur(eb, fork=ss)
+        dxf = f.backward(ef)
+    finally:
+        ss.join()
+    return dxf, b.backward_finish(rec)
 
 
 class GravesBidirectionalLSTMImpl(LayerImpl):
@@ -170,11 +260,11 @@ class GravesBidirectionalLSTMImpl(LayerImpl):
         self.f.cparams = self.b.cparams = self.cparams
         self.f.maskArray = self.b.maskArray = self.maskArray
         x = self._dropout_in(x, train)
-        return self.f.forward(x, train) + self.b.forward(x, train)
+        yf, yb = _overlap_forward(self.f, self.b, x, x, train)   # the two recurrences overlap on two HIP streams
+        return yf + yb
 
     def backward(self, eps):
-        dx = self.f.backward(eps)
-        dxb = self.b.backward(eps)
+        dx, dxb = _overlap_backward(self.f, self.b, eps, eps)
         return self._dropout_back(dx + dxb) if dx is not None else None
 
     def rnnClearPreviousState(self):
@@ -262,8 +352,9 @@ class BidirectionalImpl(LayerImpl):
         self._sync_replicas()
         self.fwd.maskArray = self.maskArray
         self.bwd.maskArray = None if self.maskArray is None else torch.flip(self.maskArray, dims=[1])
-        yf = self.fwd.forward(x, train)
-        yb = torch.flip(self.bwd.forward(torch.flip(x, dims=[2]), train), dims=[2])
+        # the two directions do not depend on each other until the merge: their recurrences overlap on two HIP streams
+        yf, yb = _overlap_forward(self.fwd, self.bwd, x, torch.flip(x, dims=[2]), train)
+        yb = torch.flip(yb, dims=[2])
         m = self.conf.mode
         self._yf, self._yb = (yf, yb) if m == "MUL" else (None, None)
         if m == "CONCAT":
@@ -285,8 +376,7 @@ class BidirectionalImpl(LayerImpl):
             ef, eb = eps * self._yb, eps * self._yf
         else:
             ef = eb = 0.5 * eps
-        dxf = self.fwd.backward(ef.contiguous())
-        dxb = self.bwd.backward(torch.flip(eb, dims=[2]).contiguous())
+        dxf, dxb = _overlap_backward(self.fwd, self.bwd, ef.contiguous(), torch.flip(eb, dims=[2]).contiguous())
         if dxf is None:
             return None
         return dxf + torch.flip(dxb, dims=[2])
