@@ -911,10 +911,13 @@ DL4J_API int dl4j_lstm_persist_fwd(const void* xw, const void* rw4, int64_t ld_r
 // The same forward kernel launched once per time step (T = 1 per launch: no in-kernel hand-off, the kernel boundary orders the
 // steps). One fused launch per step instead of GEMM + cell kernel; cheaper than the in-kernel all-gather of h at these sizes
 // (measured: profiles/r2_lstm_persistent.md).
-DL4J_API int dl4j_lstm_steps_fwd(const void* xw, const void* rw4, int64_t ld_rw, const void* h0, const void* c0, const float* pf,
-                                 const float* po, const float* pg, const float* maskT, void* H, void* Cs, void* SV, unsigned* bar, int T, int mb,
-                                 int n, int reverse, hipStream_t st) {
-  if (T <= 0) return 0;
+// [s_begin, s_end): the steps (in processing order) this call launches; the state of step s_begin - 1 is read from H / Cs, so a sequence
+// can be issued in chunks (the multi-layer pipeline of nn/layers/lstm_stack.py interleaves chunks of several layers on several streams).
+DL4J_API int dl4j_lstm_steps_fwd_range(const void* xw, const void* rw4, int64_t ld_rw, const void* h0, const void* c0, const float* pf,
+                                       const float* po, const float* pg, const float* maskT, void* H, void* Cs, void* SV, unsigned* bar, int T,
+                                       int mb, int n, int reverse, int s_begin, int s_end, hipStream_t st) {
+  if (T <= 0 || s_begin >= s_end) return 0;
+  if (s_begin < 0 || s_end > T) return -2;
   const int lds = lstm_persist_fwd_lds(mb, n);
   if (lds == 0 || ld_rw % 8 != 0 || ((uintptr_t)rw4 & 15) || ((uintptr_t)h0 & 15) || ((uintptr_t)H & 15) || ((uintptr_t)xw & 7)) return -2;
   if ((pf != nullptr) != (po != nullptr) || (pf != nullptr) != (pg != nullptr)) return -2;
@@ -922,8 +925,13 @@ DL4J_API int dl4j_lstm_steps_fwd(const void* xw, const void* rw4, int64_t ld_rw,
   const size_t hn = (size_t)mb * n * 2;
   const char* hp = (const char*)h0;
   const char* cp = (const char*)c0;
+  if (s_begin > 0) {
+    const int tp = reverse ? T - s_begin : s_begin - 1;
+    hp = (const char*)H + tp * hn;
+    cp = (const char*)Cs + tp * hn;
+  }
   (void)lds;
-  for (int s = 0; s < T; ++s) {
+  for (int s = s_begin; s < s_end; ++s) {
     const int t = reverse ? T - 1 - s : s;
     LstmFwdP p{(const bf16_t*)xw + (size_t)t * mb * 4 * n, (const bf16_t*)rw4, ld_rw, (const bf16_t*)hp, (const bf16_t*)cp, pf, po, pg,
                maskT ? maskT + (size_t)t * mb : nullptr, (bf16_t*)((char*)H + t * hn), (bf16_t*)((char*)Cs + t * hn),
@@ -933,6 +941,12 @@ DL4J_API int dl4j_lstm_steps_fwd(const void* xw, const void* rw4, int64_t ld_rw,
     cp = (const char*)Cs + t * hn;
   }
   DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_lstm_steps_fwd(const void* xw, const void* rw4, int64_t ld_rw, const void* h0, const void* c0, const float* pf,
+                                 const float* po, const float* pg, const float* maskT, void* H, void* Cs, void* SV, unsigned* bar, int T, int mb,
+                                 int n, int reverse, hipStream_t st) {
+  return dl4j_lstm_steps_fwd_range(xw, rw4, ld_rw, h0, c0, pf, po, pg, maskT, H, Cs, SV, bar, T, mb, n, reverse, 0, T, st);
 }
 
 static int lstm_persist_bwd_lds(int mb, int n) {
@@ -965,10 +979,14 @@ DL4J_API int dl4j_lstm_persist_bwd(const void* E, const void* rw4t, int64_t ld_r
 // The backward kernel launched once per time step (see dl4j_lstm_steps_fwd). dc_ws: [2, mb, n] fp32 scratch for dL/dc between launches.
 // dc_last: optional [mb, n] fp32 gradient flowing into the cell state after the last step. The gradient of the initial cell state is
 // left in dc_ws[(T - 1) % 2].
-DL4J_API int dl4j_lstm_steps_bwd(const void* E, const void* rw4t, int64_t ld_rwt, const void* SV, const void* Cs, const void* c0,
-                                 const float* pf, const float* po, const float* pg, const float* maskT, void* dG, float* dpeep, unsigned* bar,
-                                 float* dc_ws, const float* dc_last, int T, int mb, int n, int reverse, hipStream_t st) {
-  if (T <= 0) return 0;
+// Steps are processed from s = T - 1 down to 0; a call launches s in [s_begin, s_end), highest first. The carry between calls lives in the
+// arrays: dL/dh comes from the dG of the step processed before (read from dG), dL/dc from dc_ws[parity of the step].
+DL4J_API int dl4j_lstm_steps_bwd_range(const void* E, const void* rw4t, int64_t ld_rwt, const void* SV, const void* Cs, const void* c0,
+                                       const float* pf, const float* po, const float* pg, const float* maskT, void* dG, float* dpeep,
+                                       unsigned* bar, float* dc_ws, const float* dc_last, int T, int mb, int n, int reverse, int s_begin,
+                                       int s_end, hipStream_t st) {
+  if (T <= 0 || s_begin >= s_end) return 0;
+  if (s_begin < 0 || s_end > T) return -2;
   const int lds = lstm_persist_bwd_lds(mb, n);
   if (lds == 0 || ld_rwt % 8 != 0 || ((uintptr_t)rw4t & 15) || ((uintptr_t)dG & 15) || ((uintptr_t)E & 7) || ((uintptr_t)SV & 7) ||
       ((uintptr_t)Cs & 7) || ((uintptr_t)c0 & 7))
@@ -983,23 +1001,27 @@ DL4J_API int dl4j_lstm_steps_bwd(const void* E, const void* rw4t, int64_t ld_rwt
   const bf16_t* SVb = (const bf16_t*)SV;
   const bf16_t* Csb = (const bf16_t*)Cs;
   bf16_t* dGb = (bf16_t*)dG;
-  const float* dc_cur = dc_last;    // dL/dc into the step being launched (null = zeros)
-  float* dc_nxt = dc_ws;
-  const bf16_t* next = nullptr;
-  for (int s = T - 1; s >= 0; --s) {
+  for (int s = s_end - 1; s >= s_begin; --s) {
     const int t = reverse ? T - 1 - s : s;
     const int t_prev = reverse ? t + 1 : t - 1;
+    const int t_next = reverse ? t - 1 : t + 1;       // the step processed before this one
+    const float* dc_cur = s == T - 1 ? dc_last : dc_ws + (size_t)((T - 2 - s) & 1) * hn;   // dL/dc into this step (null = zeros)
+    float* dc_nxt = dc_ws + (size_t)((T - 1 - s) & 1) * hn;
+    const bf16_t* next = s == T - 1 ? nullptr : dGb + 4 * t_next * hn;
     LstmBwdP p{Eb + t * hn, (const bf16_t*)rw4t, ld_rwt, SVb + 6 * t * hn, Csb, s == 0 ? (const bf16_t*)c0 : Csb + t_prev * hn, pf, po, pg,
                maskT ? maskT + (size_t)t * mb : nullptr, dGb + 4 * t * hn, dpeep, bar, 1, mb, n, 0, next, dc_cur, dc_nxt};
     if (getenv("DL4J_AMD_LSTM_STEP_BWD_NOLDS") != nullptr)
       hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(n / 8), dim3(STEP_THREADS), 0, st, p);
     else
       hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(n / 8), dim3(BWD_THREADS), lds, st, p);
-    next = dGb + 4 * t * hn;
-    dc_cur = dc_nxt;
-    dc_nxt = (dc_nxt == dc_ws) ? dc_ws + hn : dc_ws;
   }
   DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_lstm_steps_bwd(const void* E, const void* rw4t, int64_t ld_rwt, const void* SV, const void* Cs, const void* c0,
+                                 const float* pf, const float* po, const float* pg, const float* maskT, void* dG, float* dpeep, unsigned* bar,
+                                 float* dc_ws, const float* dc_last, int T, int mb, int n, int reverse, hipStream_t st) {
+  return dl4j_lstm_steps_bwd_range(E, rw4t, ld_rwt, SV, Cs, c0, pf, po, pg, maskT, dG, dpeep, bar, dc_ws, dc_last, T, mb, n, reverse, 0, T, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- fp32 entry points
@@ -1010,10 +1032,11 @@ static int lstm_f32_bwd_lds(int mb, int n) {
 }
 DL4J_API int dl4j_lstm_steps_f32_supported(int mb, int n) { return lstm_f32_bwd_lds(mb, n) > 0 ? 1 : 0; }
 
-DL4J_API int dl4j_lstm_steps_fwd_f32(const float* xw, const float* rw4, int64_t ld_rw, const float* h0, const float* c0, const float* pf,
-                                     const float* po, const float* pg, const float* maskT, float* H, float* Cs, float* SV, int T, int mb, int n,
-                                     int reverse, hipStream_t st) {
-  if (T <= 0) return 0;
+DL4J_API int dl4j_lstm_steps_fwd_f32_range(const float* xw, const float* rw4, int64_t ld_rw, const float* h0, const float* c0, const float* pf,
+                                           const float* po, const float* pg, const float* maskT, float* H, float* Cs, float* SV, int T, int mb,
+                                           int n, int reverse, int s_begin, int s_end, hipStream_t st) {
+  if (T <= 0 || s_begin >= s_end) return 0;
+  if (s_begin < 0 || s_end > T) return -2;
   if (lstm_f32_bwd_lds(mb, n) == 0 || ld_rw % 4 != 0 || ((uintptr_t)rw4 & 15) || ((uintptr_t)h0 & 15) || ((uintptr_t)c0 & 15) ||
       ((uintptr_t)H & 15) || ((uintptr_t)Cs & 15) || ((uintptr_t)SV & 15) || ((uintptr_t)xw & 15))
     return -2;
@@ -1021,7 +1044,12 @@ DL4J_API int dl4j_lstm_steps_fwd_f32(const float* xw, const float* rw4, int64_t 
   const size_t hn = (size_t)mb * n;
   const float* hp = h0;
   const float* cp = c0;
-  for (int s = 0; s < T; ++s) {
+  if (s_begin > 0) {
+    const int tp = reverse ? T - s_begin : s_begin - 1;
+    hp = H + tp * hn;
+    cp = Cs + tp * hn;
+  }
+  for (int s = s_begin; s < s_end; ++s) {
     const int t = reverse ? T - 1 - s : s;
     LstmFwdF32 p{xw + 4 * t * hn, rw4, ld_rw, hp, cp, pf, po, pg, maskT ? maskT + (size_t)t * mb : nullptr, H + t * hn, Cs + t * hn,
                  SV ? SV + 6 * t * hn : nullptr, mb, n};
@@ -1032,11 +1060,19 @@ DL4J_API int dl4j_lstm_steps_fwd_f32(const float* xw, const float* rw4, int64_t 
   DL4J_RET_LAST();
 }
 
+DL4J_API int dl4j_lstm_steps_fwd_f32(const float* xw, const float* rw4, int64_t ld_rw, const float* h0, const float* c0, const float* pf,
+                                     const float* po, const float* pg, const float* maskT, float* H, float* Cs, float* SV, int T, int mb, int n,
+                                     int reverse, hipStream_t st) {
+  return dl4j_lstm_steps_fwd_f32_range(xw, rw4, ld_rw, h0, c0, pf, po, pg, maskT, H, Cs, SV, T, mb, n, reverse, 0, T, st);
+}
+
 // dc_ws: [2, mb, n] fp32 scratch; dpeep [3, n] accumulated (zeroed by the caller) or null
-DL4J_API int dl4j_lstm_steps_bwd_f32(const float* E, const float* rw4t, int64_t ld_rwt, const float* SV, const float* Cs, const float* c0,
-                                     const float* pf, const float* po, const float* pg, const float* maskT, float* dG, float* dpeep, float* dc_ws,
-                                     const float* dc_last, int T, int mb, int n, int reverse, hipStream_t st) {
-  if (T <= 0) return 0;
+DL4J_API int dl4j_lstm_steps_bwd_f32_range(const float* E, const float* rw4t, int64_t ld_rwt, const float* SV, const float* Cs, const float* c0,
+                                           const float* pf, const float* po, const float* pg, const float* maskT, float* dG, float* dpeep,
+                                           float* dc_ws, const float* dc_last, int T, int mb, int n, int reverse, int s_begin, int s_end,
+                                           hipStream_t st) {
+  if (T <= 0 || s_begin >= s_end) return 0;
+  if (s_begin < 0 || s_end > T) return -2;
   const int lds = lstm_f32_bwd_lds(mb, n);
   if (lds == 0 || ld_rwt % 4 != 0 || ((uintptr_t)rw4t & 15) || ((uintptr_t)dG & 15) || ((uintptr_t)E & 15) || ((uintptr_t)SV & 15) ||
       ((uintptr_t)Cs & 15) || ((uintptr_t)c0 & 15) || ((uintptr_t)dc_ws & 15))
@@ -1045,18 +1081,22 @@ DL4J_API int dl4j_lstm_steps_bwd_f32(const float* E, const float* rw4t, int64_t 
   static DeviceOnceLds lds_attr;
   lds_attr.ensure((const void*)lstm_step_bwd_f32_kernel, lds);
   const size_t hn = (size_t)mb * n;
-  const float* dc_cur = dc_last;
-  float* dc_nxt = dc_ws;
-  const float* next = nullptr;
-  for (int s = T - 1; s >= 0; --s) {
+  for (int s = s_end - 1; s >= s_begin; --s) {
     const int t = reverse ? T - 1 - s : s;
     const int t_prev = reverse ? t + 1 : t - 1;
+    const int t_next = reverse ? t - 1 : t + 1;
+    const float* dc_cur = s == T - 1 ? dc_last : dc_ws + (size_t)((T - 2 - s) & 1) * hn;
+    float* dc_nxt = dc_ws + (size_t)((T - 1 - s) & 1) * hn;
+    const float* next = s == T - 1 ? nullptr : dG + 4 * t_next * hn;
     LstmBwdF32 p{E + t * hn, rw4t, ld_rwt, SV + 6 * t * hn, s == 0 ? c0 : Cs + t_prev * hn, pf, po, pg, maskT ? maskT + (size_t)t * mb : nullptr,
                  dG + 4 * t * hn, dpeep, next, dc_cur, dc_nxt, mb, n};
     hipLaunchKernelGGL(lstm_step_bwd_f32_kernel, dim3(n / 8), dim3(STEP_THREADS), lds, st, p);
-    next = dG + 4 * t * hn;
-    dc_cur = dc_nxt;
-    dc_nxt = (dc_nxt == dc_ws) ? dc_ws + hn : dc_ws;
   }
   DL4J_RET_LAST();
+}
+
+DL4J_API int dl4j_lstm_steps_bwd_f32(const float* E, const float* rw4t, int64_t ld_rwt, const float* SV, const float* Cs, const float* c0,
+                                     const float* pf, const float* po, const float* pg, const float* maskT, float* dG, float* dpeep, float* dc_ws,
+                                     const float* dc_last, int T, int mb, int n, int reverse, hipStream_t st) {
+  return dl4j_lstm_steps_bwd_f32_range(E, rw4t, ld_rwt, SV, Cs, c0, pf, po, pg, maskT, dG, dpeep, dc_ws, dc_last, T, mb, n, reverse, 0, T, st);
 }

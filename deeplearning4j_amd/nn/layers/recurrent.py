@@ -139,7 +139,7 @@ class LSTMImpl(LayerImpl):
                     dpeep[i] += dp[i]
         return dG, Hprev, dpeep
 
-    def backward_finish(self, rec):
+    def backward_finish(self, rec, want_dx=True):
         """Weight / bias / input gradients from the recursion's outputs (library GEMMs, current stream)."""
         dG, Hprev, dpeep = rec
         mb, nIn, T, n = self._dims
@@ -153,7 +153,7 @@ class LSTMImpl(LayerImpl):
             gRW[:, 4 * n].copy_(dpeep[0]); gRW[:, 4 * n + 1].copy_(dpeep[1]); gRW[:, 4 * n + 2].copy_(dpeep[2])
         gb.copy_(dG2.sum(0, dtype=torch.float32).reshape(1, -1))
         self._saved = None
-        if not getattr(self, "needs_input_grad", True):
+        if not want_dx or not getattr(self, "needs_input_grad", True):
             return None
         dx = torch.matmul(dG2, W.t()).view(T, mb, nIn).permute(1, 2, 0)
         return self._dropout_back(dx)

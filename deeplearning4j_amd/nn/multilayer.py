@@ -165,9 +165,13 @@ class MultiLayerNetwork(BaseNetwork):
         mb = x.shape[0]
         mask = fmask
         plan = self._plan if collect is None else [("layer", i) for i in range(len(self.layers))]
+        runs = self._lstm_runs() if (collect is None and mode != "timestep" and x.is_cuda) else {}
+        skip = -1
         for kind, i in plan:
             if i >= n:
                 break
+            if i <= skip:
+                continue
             if i in pre:
                 x = pre[i].preProcess(x, mb, train)
                 mask = pre[i].feedForwardMaskArray(mask, mb) if mask is not None else None
@@ -176,6 +180,15 @@ class MultiLayerNetwork(BaseNetwork):
                 mask = l.feedForwardMaskArray(mask, mb)
             else:
                 l.maskArray = None
+            run = runs.get(i)
+            if run is not None and mask is None and run[-1] < n:
+                from .layers import lstm_stack
+                ls = [self.layers[j] for j in run]
+                if lstm_stack.ok(ls, x, train):
+                    # consecutive LSTM layers: one layer x chunk wavefront over several HIP streams (nn/layers/lstm_stack.py)
+                    x = lstm_stack.forward(ls, x, train, mode)
+                    skip = run[-1]
+                    continue
             if kind == "bn_relu" and i + 1 < n:
                 x = l.forward(x, train, relu=True)
             else:
@@ -183,6 +196,12 @@ class MultiLayerNetwork(BaseNetwork):
             if collect is not None:
                 collect.append(x)
         return x
+
+    def _lstm_runs(self):
+        if getattr(self, "_lstm_runs_cache", None) is None:
+            from .layers import lstm_stack
+            self._lstm_runs_cache = lstm_stack.find_runs(self.layers, self._plan, self.conf.inputPreProcessors)
+        return self._lstm_runs_cache
 
     def output(self, x, train=False, featuresMask=None, labelsMask=None):
         if hasattr(x, "getFeatures") and not isinstance(x, torch.Tensor):
@@ -265,11 +284,27 @@ class MultiLayerNetwork(BaseNetwork):
                 self._on_backward_begin()
             offs = self._layer_min_offsets()
         first = True
+        ends = {r[-1]: r for r in self._lstm_runs().values()}
+        skip_lo = len(self.layers)
         for kind, i in reversed(steps):
+            if i >= skip_lo:
+                continue                # part of an LSTM stack that has been back-propagated as a whole
             l = self.layers[i]
             if prog is not None and not first:
                 prog(offs[i + 1])       # layers i+1.. have finished writing their gradients
             first = False
+            run = ends.get(i)
+            if run is not None and eps is not None and eps.is_cuda:
+                from .layers import lstm_stack
+                ls = [self.layers[j] for j in run]
+                if lstm_stack.can_backward(ls):
+                    eps = lstm_stack.backward(ls, eps)
+                    skip_lo = i = run[0]
+                    if eps is not None and i in pre:
+                        eps = pre[i].backprop(eps, mb)
+                    if eps is None:
+                        break
+                    continue
             if getattr(l, "is_output", False) and i == len(self.layers) - 1:
                 eps = l.backward(None)
             else:

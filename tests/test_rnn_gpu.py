@@ -327,3 +327,73 @@ def test_bidirectional_two_stream_overlap_matches_single_stream(monkeypatch, cap
     assert torch.isfinite(out["1"][0]).all()
     assert torch.equal(out["0"][0], out["1"][0]), (out["0"][0] - out["1"][0]).abs().max().item()
     assert abs(out["0"][1] - out["1"][1]) < 1e-5 * abs(out["0"][1])   # the score reduction is not bit-reproducible
+
+
+def _stack_net(kind, dtype, n=64, nIn=12, T=24, tbptt=None, seed=5):
+    from deeplearning4j_amd.nd4j.learning import Sgd
+    from deeplearning4j_amd.nn.conf.base import InputType, BackpropType
+    from deeplearning4j_amd.nn.conf.configuration import NeuralNetConfiguration
+    from deeplearning4j_amd.nn.conf.layers import LSTM, GravesLSTM, RnnOutputLayer
+    from deeplearning4j_amd.nn.multilayer import MultiLayerNetwork
+    b = NeuralNetConfiguration.Builder().seed(seed).updater(Sgd(0.05)).weightInit("XAVIER")
+    if dtype:
+        b = b.computeDataType(dtype)
+    Lc = {"lstm": LSTM, "graves": GravesLSTM}[kind]
+    lb = b.list().layer(Lc(nIn=nIn, nOut=n, activation="TANH")).layer(Lc(nIn=n, nOut=2 * n, activation="TANH")).layer(Lc(nIn=2 * n, nOut=n, activation="TANH"))
+    lb = lb.layer(RnnOutputLayer(nIn=n, nOut=5, activation="SOFTMAX", lossFunction="MCXENT"))
+    if tbptt:
+        lb = lb.backpropType(BackpropType.TruncatedBPTT).tBPTTForwardLength(tbptt).tBPTTBackwardLength(tbptt)
+    return MultiLayerNetwork(lb.setInputType(InputType.recurrent(nIn, T)).build(), device="cuda").init()
+
+
+@pytest.mark.parametrize("kind", ["lstm", "graves"])
+@pytest.mark.parametrize("dtype", [None, "BFLOAT16"])
+def test_lstm_stack_pipeline_matches_layer_by_layer(monkeypatch, kind, dtype):
+    """Three stacked LSTM layers run as a layer x chunk wavefront over several HIP streams (nn/layers/lstm_stack.py): score, activations and
+    every gradient equal the layer-by-layer schedule (the chunked projection GEMMs may round differently from the one big GEMM)."""
+    from deeplearning4j_amd.nn.layers import lstm_stack
+    calls = {"f": 0, "b": 0}
+    rf, rb = lstm_stack.forward, lstm_stack.backward
+    monkeypatch.setattr(lstm_stack, "forward", lambda *a, **k: (calls.__setitem__("f", calls["f"] + 1), rf(*a, **k))[1])
+    monkeypatch.setattr(lstm_stack, "backward", lambda *a, **k: (calls.__setitem__("b", calls["b"] + 1), rb(*a, **k))[1])
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 12, 24, generator=g).cuda()
+    y = torch.nn.functional.one_hot(torch.randint(0, 5, (8, 24), generator=g), 5).permute(0, 2, 1).float().cuda()
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(lstm_stack, "ENABLED", on)
+        net = _stack_net(kind, dtype)
+        out = net.output(x).float()
+        net.computeGradientAndScore(x, y)
+        torch.cuda.synchronize()
+        res[on] = (out, float(net._score), net._grads.float().clone())
+    assert calls["f"] == 2 and calls["b"] == 1, calls
+    tol = 2e-2 if dtype else 1e-4
+    assert (res[True][0] - res[False][0]).abs().max().item() < tol
+    assert abs(res[True][1] - res[False][1]) < tol * max(1.0, abs(res[False][1]))
+    ga, gb = res[False][2].double(), res[True][2].double()
+    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > (0.9995 if dtype else 0.999999)
+    assert (ga - gb).abs().max().item() < tol * max(1.0, ga.abs().max().item())
+
+
+@pytest.mark.parametrize("capture", [False, True])
+def test_lstm_stack_pipeline_tbptt_fit(monkeypatch, capture):
+    """Truncated BPTT over the pipelined stack: the state carried between segments and the parameters after two fits match the
+    layer-by-layer schedule, eager and with the training step captured in a hipGraph."""
+    from deeplearning4j_amd.nn.layers import lstm_stack
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(8, 12, 48, generator=g).cuda()
+    y = torch.nn.functional.one_hot(torch.randint(0, 5, (8, 48), generator=g), 5).permute(0, 2, 1).float().cuda()
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(lstm_stack, "ENABLED", on)
+        net = _stack_net("graves", None, T=48, tbptt=16)
+        if capture:
+            net.enableGraphCapture(True)
+        for _ in range(3):
+            net.fit(x, y)
+        torch.cuda.synchronize()
+        res[on] = (net.params().clone(), float(net.score()))
+    assert torch.isfinite(res[True][0]).all()
+    assert (res[True][0] - res[False][0]).abs().max().item() < 1e-4
+    assert abs(res[True][1] - res[False][1]) < 1e-4 * max(1.0, abs(res[False][1]))

@@ -37,7 +37,7 @@ def build(dtype, graph, graves=False):
     return net
 
 
-def timed(fn, steps=8, warm=4):
+def timed(fn, steps=20, warm=5):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -53,15 +53,23 @@ def main():
     idx = torch.randint(0, V, (B, T), generator=g)
     x = torch.nn.functional.one_hot(idx, V).permute(0, 2, 1).float().cuda()
     y = torch.nn.functional.one_hot(torch.roll(idx, -1, 1), V).permute(0, 2, 1).float().cuda()
+    import os
+    only = [v for v in os.environ.get("BENCH_LSTM_ONLY", "").split(",") if v]      # e.g. bf16_eager,fp32_eager: skip the rest
     res = {}
     for name, dtype, graph, graves in (("fp32_eager", None, False, False), ("bf16_eager", "BFLOAT16", False, False),
                                        ("bf16_graves_eager", "BFLOAT16", False, True), ("bf16_hip_graph", "BFLOAT16", True, False)):
+        if only and name not in only:
+            continue
         try:
             net = build(dtype, graph, graves)
             res[name] = round(timed(lambda: net.fit(x, y)), 2)
             res[name + "_score"] = round(float(net.score()), 4)
         except Exception as e:                      # keep the other variants
             res[name] = "failed: %s" % (str(e)[:160],)
+
+    if only:
+        print(json.dumps(res))
+        return
 
     class Ref(torch.nn.Module):
         def __init__(self):
