@@ -97,6 +97,41 @@ class _FusedBNNode(_Node):
         return [dxa, self.bn2.backward(dz)]
 
 
+class _LstmStackNode(_Node):
+    """A chain of LSTM / GravesLSTM layer vertices, each feeding only the next one: run as one layer x chunk wavefront over several HIP
+    streams (nn/layers/lstm_stack.py) when the shapes allow it, vertex by vertex otherwise."""
+    __slots__ = ("chain", "impls")
+
+    def __init__(self, chain):
+        last = chain[-1]
+        super().__init__(last.out, chain[0].inputs, last.impl, chain[0].pre, True, False, [c.out for c in chain])
+        self.chain, self.impls = chain, [c.impl for c in chain]
+
+    def forward(self, xs, train, mode=None):
+        from ..layers import lstm_stack
+        x = xs[0]
+        if mode != "timestep" and x.is_cuda and all(l.maskArray is None for l in self.impls):
+            xp = x if self.pre is None else self.pre.preProcess(x, x.shape[0], train)
+            if lstm_stack.ok(self.impls, xp, train):
+                return lstm_stack.forward(self.impls, xp, train, mode)
+        for c in self.chain:
+            x = c.forward([x], train, mode)
+        return x
+
+    def backward(self, eps, mb):
+        from ..layers import lstm_stack
+        if eps.is_cuda and lstm_stack.can_backward(self.impls):
+            dx = lstm_stack.backward(self.impls, eps)
+        else:
+            dx = eps
+            for c in reversed(self.chain[1:]):
+                dx = c.impl.backward(dx)
+            dx = self.chain[0].impl.backward(dx)
+        if dx is not None and self.pre is not None:
+            dx = self.pre.backprop(dx, mb)
+        return [dx]
+
+
 def _stats_only(self, x, train):
     """Batch statistics / coefficients for a BN whose normalisation is applied inside another fused node."""
     x2, shp = self._to2d(x)
@@ -262,6 +297,8 @@ class ComputationGraph(BaseNetwork):
                 plan.append(_Node(n, conf.vertexInputs[n], impl, v.preProcessor, True, getattr(impl, "is_output", False) and n in outs))
             else:
                 plan.append(_Node(n, conf.vertexInputs[n], impl, None, False, False))
+        if self.fusion_enabled:
+            plan = self._merge_lstm_chains(plan, cons, outs, fused_away)
         self._fused_alias = fused_away
         # last-use table for freeing activations in inference
         last = {}
@@ -375,6 +412,48 @@ class ComputationGraph(BaseNetwork):
                     if last.get(i) == k and i not in outs:
                         acts.pop(i, None)
         return acts
+
+    @staticmethod
+    def _merge_lstm_chains(plan, cons, outs, fused_away):
+        """Chains of plain LSTM layer vertices (each output used by the next vertex only, no preprocessor inside the chain) become one
+        _LstmStackNode at the position of the chain's last vertex."""
+        by_out = {nd.out: nd for nd in plan}
+
+        def plain(nd):
+            return (type(nd) is _Node and nd.is_layer and not nd.is_output and type(nd.impl) is LSTMImpl and not nd.impl.reverse
+                    and len(nd.inputs) == 1)
+        chains, used = [], set()
+        for nd in plan:
+            if nd.out in used or not plain(nd):
+                continue
+            prev = by_out.get(nd.inputs[0])
+            if prev is not None and plain(prev) and len(cons.get(prev.out, [])) == 1 and prev.out not in outs and nd.pre is None:
+                continue                      # not the head of its chain
+            chain = [nd]
+            while True:
+                c = cons.get(chain[-1].out, [])
+                if len(c) != 1 or chain[-1].out in outs:
+                    break
+                nx = by_out.get(c[0])
+                if nx is None or not plain(nx) or nx.pre is not None:
+                    break
+                chain.append(nx)
+            if len(chain) >= 2:
+                chains.append(chain)
+                used.update(c.out for c in chain)
+        if not chains:
+            return plan
+        last_of = {ch[-1].out: ch for ch in chains}
+        out = []
+        for nd in plan:
+            if nd.out in last_of:
+                ch = last_of[nd.out]
+                for c in ch:
+                    fused_away[c.out] = nd.out
+                out.append(_LstmStackNode(ch))
+            elif nd.out not in used:
+                out.append(nd)
+        return out
 
     def _prep_inputs(self, xs):
         if isinstance(xs, torch.Tensor) or not isinstance(xs, (list, tuple)):

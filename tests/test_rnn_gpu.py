@@ -397,3 +397,29 @@ def test_lstm_stack_pipeline_tbptt_fit(monkeypatch, capture):
     assert torch.isfinite(res[True][0]).all()
     assert (res[True][0] - res[False][0]).abs().max().item() < 1e-4
     assert abs(res[True][1] - res[False][1]) < 1e-4 * max(1.0, abs(res[False][1]))
+
+
+@pytest.mark.parametrize("dtype", [None, "BFLOAT16"])
+def test_graph_lstm_chain_pipeline_matches_vertex_by_vertex(monkeypatch, dtype):
+    """ComputationGraph: a chain of LSTM vertices runs through the same multi-stream pipeline (_LstmStackNode)."""
+    from deeplearning4j_amd.nn.layers import lstm_stack
+    from tests.test_networks_cpu import _lstm_chain_graph
+    calls = {"f": 0, "b": 0}
+    rf, rb = lstm_stack.forward, lstm_stack.backward
+    monkeypatch.setattr(lstm_stack, "forward", lambda *a, **k: (calls.__setitem__("f", calls["f"] + 1), rf(*a, **k))[1])
+    monkeypatch.setattr(lstm_stack, "backward", lambda *a, **k: (calls.__setitem__("b", calls["b"] + 1), rb(*a, **k))[1])
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(8, 6, 12, generator=g).cuda()
+    y = torch.nn.functional.one_hot(torch.randint(0, 3, (8, 12), generator=g), 3).permute(0, 2, 1).float().cuda()
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(lstm_stack, "ENABLED", on)
+        cg = _lstm_chain_graph("cuda", dtype, n=64)
+        cg.computeGradientAndScore([x], [y])
+        torch.cuda.synchronize()
+        res[on] = (float(cg._score), cg._grads.float().clone())
+    assert calls == {"f": 1, "b": 1}, calls
+    tol = 2e-2 if dtype else 1e-4
+    assert abs(res[True][0] - res[False][0]) < tol * max(1.0, abs(res[False][0]))
+    ga, gb = res[False][1].double(), res[True][1].double()
+    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > (0.9995 if dtype else 0.999999)
