@@ -982,7 +982,9 @@ class SameDiff:
                 res = self._run_graph(ph, list(self.lossVariables) + list(extra_outputs), True, listeners, at)
                 losses = [res[n] for n in self.lossVariables]
                 total = sum(l.sum() for l in losses)
-                grads = torch.autograd.grad(total, leaves, allow_unused=True)
+                from ..ops import streams as _streams
+                with _streams.dense_scope():      # dense weight gradients overlap the dx chain on a side stream; joined here
+                    grads = torch.autograd.grad(total, leaves, allow_unused=True)
         finally:
             for n, a in saved.items():
                 self._arrays[n] = a

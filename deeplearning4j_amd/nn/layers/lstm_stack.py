@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -37,12 +38,19 @@ from ...ops import lstm as LSTMOP
 
 ENABLED = os.environ.get("DL4J_AMD_LSTM_STACK", "1") != "0"
 CHUNK = int(os.environ.get("DL4J_AMD_LSTM_STACK_CHUNK", "0"))     # 0: about a sixth of the sequence, at least 4 steps
-_STREAMS = {}
-_EVENTS = {}
+_TLS = threading.local()      # side streams and the event pool are per host thread (ParallelWrapper / ParallelInference workers share a device)
+
+
+def _tls(name):
+    d = getattr(_TLS, name, None)
+    if d is None:
+        d = {}
+        setattr(_TLS, name, d)
+    return d
 
 
 def _streams(dev, k):
-    s = _STREAMS.setdefault(dev, [])
+    s = _tls("streams").setdefault(dev, [])
     while len(s) < k:
         s.append(torch.cuda.Stream(device=dev))
     return s[:k]
@@ -52,7 +60,7 @@ class _Events:
     """A per-device pool of events, handed out in order and reused from the start by the next pass."""
 
     def __init__(self, dev):
-        self.pool = _EVENTS.setdefault(dev, [])
+        self.pool = _tls("events").setdefault(dev, [])
         self.i = 0
 
     def record(self, stream):

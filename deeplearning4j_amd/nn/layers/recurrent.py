@@ -15,6 +15,7 @@ Parameter layout is DL4J's (LSTMParamInitializer.java:122-145): W [nIn,4n], RW [
 from __future__ import annotations
 
 import contextlib
+import threading
 
 import torch
 
@@ -164,7 +165,7 @@ class LSTMImpl(LayerImpl):
         self._xt = None
 
 
-_SIDE_STREAMS = {}
+_SIDE_TLS = threading.local()     # one side stream per (host thread, device)
 
 
 class _side_stream:
@@ -186,9 +187,12 @@ class _side_stream:
         self.cur = self.side = None
         if x.is_cuda and os.environ.get("DL4J_AMD_BIDIR_STREAMS", "1") != "0":
             dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-            if dev not in _SIDE_STREAMS:
-                _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
-            self.side = _SIDE_STREAMS[dev]
+            pool = getattr(_SIDE_TLS, "streams", None)
+            if pool is None:
+                pool = _SIDE_TLS.streams = {}
+            if dev not in pool:
+                pool[dev] = torch.cuda.Stream(device=dev)
+            self.side = pool[dev]
             self.cur = torch.cuda.current_stream(dev)
         self.forked = False
 

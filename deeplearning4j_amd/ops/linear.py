@@ -15,6 +15,7 @@ import torch
 
 from . import gemm as G
 from . import dense as DENSE
+from . import streams as STREAMS
 
 
 def usable(x, w):
@@ -190,16 +191,24 @@ class FusedDenseFn(torch.autograd.Function):
             d2 = act_bwd_colsum(z, d2, ctx.act_id, tgt)
             if db is not None:
                 db = db.to(ctx.bias_meta[0]).reshape(ctx.bias_meta[1])
+        lw = ctx.wlink
+        direct = ctx.needs_input_grad[1] and lw is not None and lw.hits == 0 and DENSE.dw_ok(x2, d2, lw.grad.view(K, N))
+        side = direct and STREAMS.dense_active()
+        if side:
+            # dW is off the critical path: issued first, on the side stream, so that it overlaps dx and what follows (ops/streams.py)
+            lw.hits += 1
+            with torch.cuda.stream(STREAMS.fork(x2, d2)):
+                DENSE.dw(x2, d2, lw.grad.view(K, N), True)
         if ctx.needs_input_grad[0]:
             wc = w if w.is_contiguous() else w.contiguous()
             dx = G.gemm_nt(d2, wc).view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            lw = ctx.wlink
-            direct = lw is not None and lw.hits == 0 and DENSE.dw_ok(x2, d2, lw.grad.view(K, N))
+        if ctx.needs_input_grad[1] and not side:
             if direct:
                 lw.hits += 1
                 DENSE.dw(x2, d2, lw.grad.view(K, N), True)         # x^T . dy -> [K, N] fp32, straight into the flat gradient vector
             else:
+                if lw is not None:
+                    STREAMS.join()                                 # an earlier use of this weight may still be accumulating on the side stream
                 t = torch.zeros(K, N, device=w.device, dtype=torch.float32)
                 if DENSE.dw_ok(x2, d2, t):
                     DENSE.dw(x2, d2, t, True)

@@ -58,6 +58,36 @@ def join():
         _pending = False
 
 
+# Dense layers (ops/linear.py FusedDenseFn.backward): dW = x^T . dy goes straight into the flat gradient vector and nothing reads it before
+# the updater, while dx = dy . W^T is on the critical path. At transformer sizes neither GEMM fills the chip (BERT-base, 4096 tokens:
+# 192 tiles of 128 x 128 for dx, 36 output tiles x split-K for dW), so the two run side by side. Both are in-tree kernels that never wait
+# on another workgroup (see nn/layers/lstm_stack.py for why library GEMMs are kept off side streams).
+# Measured on the BERT-base step (tools/bench_bert.py, batch 32 x 128, captured step): 11.19 ms with the side stream, 11.08 ms without:
+# the split-K dW grid already covers the chip, so like the convolution case this stays OFF by default (DL4J_AMD_DENSE_WGRAD_STREAM=1).
+_DENSE_ENABLED = os.environ.get("DL4J_AMD_DENSE_WGRAD_STREAM", "0") == "1"
+_dense_depth = 0
+
+
+def dense_active() -> bool:
+    return _DENSE_ENABLED and _dense_depth > 0
+
+
+class dense_scope:
+    """Backward region in which dense weight gradients may run on the side stream; joins on exit."""
+
+    def __enter__(self):
+        global _dense_depth
+        _dense_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _dense_depth
+        _dense_depth -= 1
+        if _dense_depth == 0:
+            join()
+        return False
+
+
 class backward_scope:
     def __enter__(self):
         global _depth
