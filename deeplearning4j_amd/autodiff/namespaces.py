@@ -14,6 +14,7 @@ from ..nd4j.ops.custom import describe
 from .generated.sd_bitwise import GenSDBitwise
 from .generated.sd_image import GenSDImage
 from .generated.sd_linalg import GenSDLinalg
+from .generated.sd_loss import GenSDLoss
 from .generated.sd_random import GenSDRandom
 
 
@@ -271,26 +272,8 @@ class SDRNN(_NS):
     def sruCell(self, x, c0, w, b, name=None): return self._o("sruCell", [x, c0, w, b], name, 2)
 
 
-class SDLoss(_NS):
-    def _l(self, opn, label, pred, weights, reduce, name, tArgs=None, extraI=None):
-        w = weights if weights is not None else self.sd.constant(None, 1.0)
-        return self._o(opn, [pred, w, label], name, iArgs=[reduce] + list(extraI or []), tArgs=tArgs)
-
-    def meanSquaredError(self, label, pred, weights=None, lossReduce=3, name=None): return self._l("mean_sqerr_loss", label, pred, weights, lossReduce, name)
-    def absoluteDifference(self, label, pred, weights=None, lossReduce=3, name=None): return self._l("absolute_difference_loss", label, pred, weights, lossReduce, name)
-    def huberLoss(self, label, pred, weights=None, lossReduce=3, delta=1.0, name=None): return self._l("huber_loss", label, pred, weights, lossReduce, name, [delta])
-    def hingeLoss(self, label, pred, weights=None, lossReduce=3, name=None): return self._l("hinge_loss", label, pred, weights, lossReduce, name)
-    def logLoss(self, label, pred, weights=None, lossReduce=3, epsilon=1e-7, name=None): return self._l("log_loss", label, pred, weights, lossReduce, name, [epsilon])
-    def logPoisson(self, label, pred, weights=None, lossReduce=3, full=False, name=None): return self._l("log_poisson_loss", label, pred, weights, lossReduce, name, None, [int(full)])
-    def cosineDistance(self, label, pred, weights=None, lossReduce=3, dimension=-1, name=None): return self._l("cosine_distance_loss", label, pred, weights, lossReduce, name, None, [dimension])
-    def sigmoidCrossEntropy(self, label, logits, weights=None, lossReduce=3, labelSmoothing=0.0, name=None): return self._l("sigm_cross_entropy_loss", label, logits, weights, lossReduce, name, [labelSmoothing])
-    def softmaxCrossEntropy(self, label, logits, weights=None, lossReduce=3, labelSmoothing=0.0, name=None): return self._l("softmax_cross_entropy_loss", label, logits, weights, lossReduce, name, [labelSmoothing])
-    def sparseSoftmaxCrossEntropy(self, logits, labels, name=None): return self._o("sparse_softmax_cross_entropy_loss_with_logits", [labels, logits], name)
-    def meanPairwiseSquaredError(self, label, pred, weights=None, lossReduce=3, name=None): return self._l("mean_pairwssqerr_loss", label, pred, weights, lossReduce, name)
-    def l2Loss(self, x, name=None): return self._o("l2_loss", [x], name)
-    def ctcLoss(self, targetLabels, logits, targetLengths, logitLengths, blankIndex=0, name=None):
-        return self._o("ctc_loss", [targetLabels, logits, targetLengths, logitLengths], name, iArgs=[blankIndex])
-    def weightedCrossEntropyWithLogits(self, targets, logits, weights, name=None): return self._o("weighted_cross_entropy_with_logits", [targets, logits, weights], name)
+class SDLoss(GenSDLoss, _NS):       # the whole surface is generated (codegen/ops/loss.py)
+    pass
 
 
 class SDLinalg(GenSDLinalg, _NS):       # generated surface (codegen/ops/linalg.py) + the overrides below

@@ -61,9 +61,13 @@ class _Param:
 
 
 class Input(_Param):
-    def __init__(self, name, type_, doc, count: Optional[Count] = None, optional=False):
+    def __init__(self, name, type_, doc, count: Optional[Count] = None, optional=False, default=None):
+        """``default``: scalar constant passed to the native op when an optional input is not given (the loss ops' weights = 1.0); without it
+        an absent optional input is simply left out of the op's input list."""
         super().__init__(name, type_, doc)
-        self.count, self.optional = count or Count.Exactly(1), optional
+        self.count, self.optional, self.default = count or Count.Exactly(1), optional, default
+        if default is not None and not optional:
+            raise ValueError("input %s: only an optional input can have a default" % name)
 
 
 class Output(_Param):
@@ -99,11 +103,17 @@ class Op:
         self.outputs: List[Output] = []
         self.aliases: List[str] = []
         self.nOutExpr: Optional[str] = None
+        self.order: Optional[List[str]] = None
         self.legacy = False
 
     # -- fluent definition
-    def input(self, name, type_, doc, count=None, optional=False):
-        self.inputs.append(Input(name, type_, doc, count, optional))
+    def input(self, name, type_, doc, count=None, optional=False, default=None):
+        self.inputs.append(Input(name, type_, doc, count, optional, default))
+        return self
+
+    def nativeOrder(self, *names):
+        """Order in which the native op takes the inputs when it differs from the signature's (losses: predictions, weights, labels)."""
+        self.order = list(names)
         return self
 
     def arg(self, name, type_, doc, default=_NO_DEFAULT, count=None, slot=None, convert=None, possibleValues=None):
@@ -143,6 +153,11 @@ class Op:
         varargs = [a for a in self.args if not a.count.isScalar()]
         if len(varargs) > 1:
             raise ValueError("%s: at most one variable-length argument is supported" % where)
+        if self.order is not None:
+            if sorted(self.order) != sorted(i.name for i in self.inputs):
+                raise ValueError("%s: nativeOrder must name every input exactly once" % where)
+            if any(not i.count.isScalar() or (i.optional and i.default is None) for i in self.inputs):
+                raise ValueError("%s: nativeOrder needs single inputs, optional ones with a default" % where)
         opt = [i for i in self.inputs if i.optional]
         if opt and self.inputs.index(opt[0]) < len(self.inputs) - len(opt):
             raise ValueError("%s: optional inputs must come last" % where)

@@ -586,7 +586,7 @@ class _EagerNamespace:
     """Nd4j.math() / nn() / cnn() / rnn() / loss() / linalg() / bitwise() / random() / image() / base(): eager op namespaces
     (reference: org.nd4j.linalg.factory.ops.ND*). Any registered custom-op name is callable: arrays in, INDArray(s) out."""
 
-    _GENERATED = {"bitwise": "NDBitwise", "linalg": "NDLinalg", "random": "NDRandom", "image": "NDImage"}
+    _GENERATED = {"bitwise": "NDBitwise", "linalg": "NDLinalg", "random": "NDRandom", "image": "NDImage", "loss": "NDLoss"}
 
     def __init__(self, kind):
         self.kind = kind

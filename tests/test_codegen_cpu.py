@@ -111,3 +111,30 @@ def test_generated_eager_namespaces():
     assert _tensor(crop).shape == (1, 4, 4, 1)
     # ops outside the generated surface are still reachable by registry name
     assert _tensor(Nd4j.math().reduce_sum(torch.tensor([1.0, 2.0]))).tolist() == 3.0
+
+
+def test_generated_loss_namespace_matches_reference_math():
+    """codegen/ops/loss.py: inputs reach the native op as (predictions, weights, labels), an absent weights input becomes the constant 1.0,
+    the reduction enum maps to libnd4j's mode number; SameDiff and eager surfaces agree with plain torch."""
+    from deeplearning4j_amd.autodiff.samediff import SameDiff
+    from deeplearning4j_amd.nd4j.factory import Nd4j
+    g = torch.Generator().manual_seed(0)
+    lab, pred = torch.rand(6, 5, generator=g), torch.rand(6, 5, generator=g)
+    w = torch.rand(6, 1, generator=g)
+    sd = SameDiff.create("cpu")
+    L, P, W = sd.constant("l", lab), sd.constant("p", pred), sd.constant("w", w)
+    mse = sd.loss.meanSquaredError(L, P)
+    mse_w = sd.loss.meanSquaredError(L, P, W, "SUM")
+    hub = sd.loss.huberLoss(L, P, None, 3, 0.3)
+    out = sd.output({}, [mse.name, mse_w.name, hub.name])
+    t = lambda n: _tensor(out[n])
+    assert abs(float(t(mse.name)) - float(((lab - pred) ** 2).mean())) < 1e-6
+    assert abs(float(t(mse_w.name)) - float((((lab - pred) ** 2) * w).sum())) < 1e-5
+    d = (lab - pred).abs()
+    ref_h = torch.where(d <= 0.3, 0.5 * d * d, 0.3 * d - 0.5 * 0.09).mean()
+    assert abs(float(t(hub.name)) - float(ref_h)) < 1e-6
+    e = Nd4j.loss().absoluteDifference(lab, pred, None, "NONE")
+    assert torch.allclose(_tensor(e), (lab - pred).abs(), atol=1e-6)
+    logits, cls = torch.randn(4, 7, generator=g), torch.tensor([1, 0, 6, 3])
+    sp = Nd4j.loss().sparseSoftmaxCrossEntropy(logits, cls)
+    assert torch.allclose(_tensor(sp), torch.nn.functional.cross_entropy(logits, cls, reduction="none"), atol=1e-5)
