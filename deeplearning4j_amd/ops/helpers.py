@@ -320,6 +320,7 @@ def index_map(x, out, maps, out_base=0, pad_value=0.0):
     xs, os2 = x.untyped_storage().nbytes() // x.element_size(), out.untyped_storage().nbytes() // out.element_size()
     assert x.storage_offset() + lo >= 0 and x.storage_offset() + hi < xs, "index_map: input range outside the tensor's storage"
     assert out.storage_offset() + olo >= 0 and out.storage_offset() + ohi < os2, "index_map: output range outside the tensor's storage"
+    maps = _collapse_maps(maps)
     flat = []
     for m in maps:
         flat += [int(v) for v in m]
@@ -328,6 +329,25 @@ def index_map(x, out, maps, out_base=0, pad_value=0.0):
                                 ctypes.c_uint64(_pad_bits(pad_value, x.dtype)), L.c_int(x.element_size()), L.stream())
     L.check(rc, "index_map")
     return out
+
+
+def _collapse_maps(maps):
+    """Merge neighbouring dimensions that are copied unchanged (shift by 0 over the whole extent) and are laid out as one dimension on both
+    sides: fewer coordinates to decompose per row and longer innermost rows for the kernel (TensorIterator-style coalescing)."""
+    out = []
+    for m in maps:
+        os_, is_, region, in_dim, a, b, mode = [int(v) for v in m]
+        if region == 1 and in_dim == 1 and mode in (SHIFT, REVERSE, WRAP) and len(maps) > 1 and (mode != SHIFT or a == 0):
+            continue                                     # size-1 dimension: contributes nothing
+        if out:
+            po, pi, pr, pd, pa, pb, pm = out[-1]
+            ident = mode == SHIFT and a == 0 and region == in_dim
+            pident = pm == SHIFT and pa == 0 and pr == pd
+            if ident and pident and po == os_ * region and pi == is_ * in_dim and pr * region < 2 ** 31:
+                out[-1] = (os_, is_, pr * region, pd * in_dim, 0, 0, SHIFT)
+                continue
+        out.append((os_, is_, region, in_dim, a, b, mode))
+    return out or [tuple(int(v) for v in maps[-1])]
 
 
 def _cstrides(shape):

@@ -219,3 +219,44 @@ def test_index_map_family():
     # indices that leave the input extent are never dereferenced: the kernel writes the pad value instead
     oob = H.strided_slice_nd(xc, [0, 0, 0], [1, 1, 3], [3, 5, 7]).cpu()
     assert torch.equal(oob[:, :, :3], x[:, :, 0:7:3]) and float(oob[:, :, 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.bfloat16, torch.float32, torch.int64])
+def test_index_map_vector_paths(dtype):
+    """The 16-bytes-per-thread form of index_map.hip: aligned runs (vector load + store), runs at odd element offsets (dword-aligned or
+    not), rows shorter than / not a multiple of a vector, reversed and wrapped innermost dimensions, strided inputs; bit-exact vs torch."""
+    from deeplearning4j_amd.ops import helpers as H
+    g = torch.Generator().manual_seed(11)
+
+    def mk(*shape):
+        if dtype.is_floating_point:
+            return torch.randn(*shape, generator=g).to(dtype)
+        return torch.randint(0, 120, shape, generator=g).to(dtype)
+    for shape in ((5, 64), (3, 7, 33), (4, 3, 130), (2, 3, 5, 48), (9,), (6, 1), (2, 5000), (70001,)):
+        x = mk(*shape)
+        xc = x.to(dev())
+        last = len(shape) - 1
+        assert torch.equal(H.reverse_dims(xc, [last]).cpu(), torch.flip(x, [last]))
+        assert torch.equal(H.reverse_dims(xc, [0]).cpu(), torch.flip(x, [0]))
+        for sh in (1, 3, 8, 17):
+            assert torch.equal(H.roll_nd(xc, [sh], [last]).cpu(), torch.roll(x, sh, last)), (shape, sh)
+        assert torch.equal(H.roll_nd(xc, [2], [0]).cpu(), torch.roll(x, 2, 0))
+        reps = [2] * len(shape)
+        assert torch.equal(H.tile_nd(xc, reps).cpu(), x.repeat(*reps))
+        pads = [(1, 2)] * len(shape)
+        ref = torch.nn.functional.pad(x.float() if dtype == torch.bfloat16 else x, [v for p in reversed(pads) for v in p], value=3).to(dtype)
+        assert torch.equal(H.pad_nd(xc, pads, "constant", 3).cpu(), ref), shape
+        assert torch.equal(H.pad_nd(xc, [(0, 0)] * last + [(-1, 0)], "constant", 0).cpu(), x[..., 1:]) if shape[last] > 1 else True
+        y = mk(*shape)
+        for ax in range(len(shape)):
+            assert torch.equal(H.concat_nd([xc, y.to(dev()), xc], ax).cpu(), torch.cat([x, y, x], ax)), (shape, ax)
+        if len(shape) >= 2:
+            perm = list(range(len(shape)))[::-1]
+            assert torch.equal(H.permute_copy(xc, perm).cpu(), x.permute(*perm).contiguous())
+            xt = xc.transpose(0, last)
+            assert torch.equal(H.tile_nd(xt, [1] * len(shape)).cpu(), x.transpose(0, last).contiguous())
+        n = shape[last]
+        if n >= 9:
+            cnt = (n - 1) // 2
+            assert torch.equal(H.strided_slice_nd(xc, [0] * last + [1], [1] * last + [2], list(shape[:last]) + [cnt]).cpu(), x[..., 1:1 + 2 * cnt:2])
+            assert torch.equal(H.strided_slice_nd(xc, [0] * last + [3], [1] * len(shape), list(shape[:last]) + [n - 3]).cpu(), x[..., 3:])
