@@ -457,3 +457,25 @@ def test_batchnorm_running_statistics_follow_cpu_training(capture):
             moved += float((pa[sl] - p0[sl]).norm())
             assert float((pa[sl] - pb[sl]).norm()) < 2e-3 * max(1e-3, float((pa[sl] - p0[sl]).norm())) + 1e-6, (e.spec.key, e.layer_idx)
     assert moved > 1.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N", [8, 1000, 1024, 2056, 4096, 8192, 16384, 20000, 1001])
+def test_softmax_rows_register_resident_forms(dtype, N):
+    """softmax / log-softmax / softmax backward with the row held in registers (softmax_xent.hip *_vec_kernel, 1-8 16-byte pieces per
+    thread) and the three-pass fallback for rows that do not fit or are not a multiple of the vector width; vs fp32 torch."""
+    from deeplearning4j_amd.ops import softmax as S
+    g = torch.Generator(device="cuda").manual_seed(N)
+    z = (torch.randn(37, N, device="cuda", generator=g) * 3).to(dtype)
+    dy = torch.randn(37, N, device="cuda", generator=g).to(dtype)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    p = S.softmax(z)
+    ref = torch.softmax(z.float(), -1)
+    assert (p.float() - ref).abs().max().item() < tol * ref.max().item() + 1e-7
+    lp = S.softmax(z, log=True)
+    refl = torch.log_softmax(z.float(), -1)
+    assert (lp.float() - refl).abs().max().item() < (0.1 if dtype == torch.bfloat16 else 1e-4)
+    dz = S.softmax_bp(p, dy)
+    pf = p.float()
+    refd = pf * (dy.float() - (dy.float() * pf).sum(-1, keepdim=True))
+    assert (dz.float() - refd).abs().max().item() < tol * max(refd.abs().max().item(), 1e-3) + 1e-6
