@@ -297,3 +297,17 @@ def test_sru_bi_and_barnes_edge_forces():
     y = torch.randn(N, D)
     _platform_vs_generic("barnes_edge_forces", [rowP, colP, val, y], [N], atol=1e-5)
     _platform_vs_generic("barnes_edge_forces", [rowP.int(), colP.int(), val, torch.randn(N, 3)], [N], atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.uint8, torch.int64])
+@pytest.mark.parametrize("W,fH", [(8, 2), (56, 2), (16, 3), (6, 2), (32, 1)])
+def test_upsampling2d_factor2_vector_path(dtype, W, fH):
+    """helpers_data.hip upsample2d_fwd_w2_kernel (rows that are whole 16-byte pieces, width factor 2) and the element-wise fallback."""
+    from deeplearning4j_amd.ops import helpers as H
+    x = (torch.randn(3, 5, 7, W) * 50).to(dtype).cuda()
+    y = H.upsample2d_fwd(x, fH, 2) if hasattr(H, "upsample2d_fwd") else None
+    if y is None:
+        from deeplearning4j_amd.nd4j.ops.custom import exec_op
+        y = exec_op("upsampling2d", [x], iArgs=[fH, 2, 1])[0]
+        y = y.tensor() if hasattr(y, "tensor") and callable(y.tensor) else y
+    assert torch.equal(y, x.repeat_interleave(fH, 2).repeat_interleave(2, 3))
