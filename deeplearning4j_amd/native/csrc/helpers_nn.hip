@@ -118,6 +118,50 @@ __global__ void bias_add_kernel(const T* __restrict__ x, const float* __restrict
   }
 }
 
+// 16-byte pieces: V elements per thread and one 32-bit channel computation per piece. inner % V == 0 (NCHW: a piece lies inside one
+// channel) or inner == 1 with C % V == 0 (channels-last: a piece covers V consecutive channels).
+template <typename T> struct BPack;
+template <> struct BPack<float> {
+  static constexpr int V = 4;
+  static __device__ __forceinline__ void ld(const float* p, float* x) { const float4 v = *(const float4*)p; x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+  static __device__ __forceinline__ void st(float* p, const float* x) { *(float4*)p = make_float4(x[0], x[1], x[2], x[3]); }
+};
+template <> struct BPack<bf16_t> {
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float* x) {
+    const uint4 v = *(const uint4*)p;
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[2 * j] = __uint_as_float(w[j] << 16); x[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float* x) {
+    alignas(16) bf16_t h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = f2bf(x[j]);
+    *(uint4*)p = *(const uint4*)h;
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) bias_add_vec_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y,
+                                                           uint32_t nvec, uint32_t C, uint32_t inner_vec) {
+  constexpr int V = BPack<T>::V;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nvec; i += gridDim.x * 256u) {
+    float v[V];
+    BPack<T>::ld(x + (int64_t)i * V, v);
+    if (inner_vec) {                                   // channels-first: one channel per piece
+      const float b = bias[(i / inner_vec) % C];
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] += b;
+    } else {                                           // channels-last: V consecutive channels
+      const float* bp = bias + ((uint64_t)i * V) % C;
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] += bp[j];
+    }
+    BPack<T>::st(y + (int64_t)i * V, v);
+  }
+}
+
 // ------------------------------------------------------------------ dropout (inverted): keep with prob p, scale 1/p
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ mask, int64_t n, float p,
@@ -245,6 +289,14 @@ DL4J_API int dl4j_layer_norm_bwd(const void* x, const void* g, const float* gamm
 
 DL4J_API int dl4j_bias_add(const void* x, const float* bias, void* y, int64_t n, int C, int64_t inner, int dtype, hipStream_t st) {
   if (n <= 0) return 0;
+  const int V = dtype == 1 ? 8 : 4;
+  const bool cf = inner > 1 && inner % V == 0, cl = inner == 1 && C % V == 0;
+  if ((cf || cl) && n % V == 0 && n / V < 4294967295LL && inner / V < 4294967295LL && !((uintptr_t)x & 15) && !((uintptr_t)y & 15)) {
+    const uint32_t nvec = (uint32_t)(n / V);
+    DISPATCH_T(hipLaunchKernelGGL(bias_add_vec_kernel<T>, dim3(grid_for(nvec, 512)), dim3(256), 0, st, (const T*)x, bias, (T*)y, nvec, (uint32_t)C,
+                                  cf ? (uint32_t)(inner / V) : 0u);)
+    DL4J_RET_LAST();
+  }
   DISPATCH_T(hipLaunchKernelGGL(bias_add_kernel<T>, dim3(grid_for(n, 1024)), dim3(256), 0, st, (const T*)x, bias, (T*)y, n, C, inner);)
   DL4J_RET_LAST();
 }

@@ -260,3 +260,16 @@ def test_index_map_vector_paths(dtype):
             cnt = (n - 1) // 2
             assert torch.equal(H.strided_slice_nd(xc, [0] * last + [1], [1] * last + [2], list(shape[:last]) + [cnt]).cpu(), x[..., 1:1 + 2 * cnt:2])
             assert torch.equal(H.strided_slice_nd(xc, [0] * last + [3], [1] * len(shape), list(shape[:last]) + [n - 3]).cpu(), x[..., 3:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_biasadd_vector_paths(dtype):
+    """helpers_nn.hip bias_add_vec_kernel: channels-first pieces inside one channel, channels-last pieces over 8 / 4 channels, and the
+    element-wise fallback for shapes that are neither."""
+    tol = dict(atol=3e-2, rtol=2e-2) if dtype == torch.bfloat16 else {}
+    g = torch.Generator().manual_seed(3)
+    for shape, nchw in (((2, 6, 4, 8), True), ((3, 5, 8, 16), True), ((4, 7, 3, 5), True), ((5, 16), False), ((9, 64), False), ((2, 3, 4, 24), False),
+                        ((7, 12), False)):
+        C = shape[1] if nchw else shape[-1]
+        x = torch.randn(*shape, generator=g).to(dtype)
+        _platform_vs_generic("biasadd", [x, torch.randn(C, generator=g).to(dtype)], [], [], [True] if nchw else [], **tol)
