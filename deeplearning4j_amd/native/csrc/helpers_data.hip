@@ -29,6 +29,19 @@ __global__ void gather_rows_kernel(const T* __restrict__ table, const I* __restr
   }
 }
 
+// rows that are whole 16-byte pieces: one thread moves one piece (one 32-bit division per 16 bytes; the index is read once per piece and
+// hits the cache for the other pieces of the row)
+template <typename I>
+__global__ void __launch_bounds__(256) gather_rows_vec_kernel(const uint4* __restrict__ table, const I* __restrict__ idx, uint4* __restrict__ out,
+                                                              uint32_t total_pieces, uint32_t ppr, int64_t V) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total_pieces; i += gridDim.x * 256u) {
+    const uint32_t r = i / ppr, c = i - r * ppr;
+    int64_t v = (int64_t)idx[r];
+    if (v < 0) v += V;
+    out[i] = (v >= 0 && v < V) ? table[v * ppr + c] : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 // table[idx[r], :] += alpha * src[r, :]   (fp32 accumulate; duplicates are summed)
 template <typename T, typename I>
 __global__ void scatter_add_rows_kernel(const T* __restrict__ src, const I* __restrict__ idx, float* __restrict__ table, int64_t n_idx,
@@ -313,6 +326,13 @@ __global__ __launch_bounds__(256) void sg_pairs_kernel(const float* __restrict__
 DL4J_API int dl4j_gather_rows(const void* table, const void* idx, void* out, int64_t n_idx, int D, int64_t V, int esize, int idx64,
                               hipStream_t st) {
   if (n_idx <= 0 || D <= 0) return 0;
+  const int64_t row_bytes = (int64_t)D * esize;
+  if (row_bytes % 16 == 0 && n_idx * (row_bytes / 16) < 4294967295LL && !((uintptr_t)table & 15) && !((uintptr_t)out & 15)) {
+    const uint32_t ppr = (uint32_t)(row_bytes / 16), total = (uint32_t)(n_idx * ppr);
+    DISPATCH_I(hipLaunchKernelGGL((gather_rows_vec_kernel<I>), dim3(grid_for(total, 512)), dim3(256), 0, st, (const uint4*)table, (const I*)idx,
+                                  (uint4*)out, total, ppr, V);)
+    DL4J_RET_LAST();
+  }
   const int g = grid_for(n_idx * D, 1024);
   DISPATCH_BYTES(esize, DISPATCH_I(hipLaunchKernelGGL((gather_rows_kernel<T, I>), dim3(g), dim3(256), 0, st, (const T*)table,
                                                       (const I*)idx, (T*)out, n_idx, D, V);))

@@ -273,3 +273,19 @@ def test_biasadd_vector_paths(dtype):
         C = shape[1] if nchw else shape[-1]
         x = torch.randn(*shape, generator=g).to(dtype)
         _platform_vs_generic("biasadd", [x, torch.randn(C, generator=g).to(dtype)], [], [], [True] if nchw else [], **tol)
+
+
+def test_gather_rows_vector_path():
+    """helpers_data.hip gather_rows_vec_kernel (rows that are whole 16-byte pieces) and the element-wise fallback; negative indices wrap."""
+    g = torch.Generator().manual_seed(5)
+    for shape, dt in (((50, 64), torch.float32), ((50, 24), torch.bfloat16), ((33, 7), torch.float32), ((40, 16), torch.int64), ((9, 48), torch.uint8)):
+        table = (torch.randn(*shape, generator=g) * 40).to(dt)
+        for idt in (torch.int64, torch.int32):
+            idx = torch.randint(-shape[0], shape[0], (3, 29), generator=g).to(idt)
+            ref = table[idx.long() % shape[0]]
+            if dt.is_floating_point:
+                _platform_vs_generic("embedding_lookup", [table, idx.clamp(min=0)])
+            from deeplearning4j_amd.ops import helpers as H
+            got = H.gather_rows(table.to(dev()), idx.to(dev()).reshape(-1)) if hasattr(H, "gather_rows") else None
+            if got is not None:
+                assert torch.equal(got.cpu().reshape(ref.shape), ref), (shape, dt, idt)
