@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void sg_pairs_kernel(const float* __restrict__
                                                        const float* __restrict__ hidden, const int64_t* __restrict__ in_idx,
                                                        const int64_t* __restrict__ tgt_idx, const float* __restrict__ label,
                                                        float* __restrict__ dh, int64_t n_pairs, int D, float lr, float scale,
-                                                       int64_t V0, int64_t V1) {
+                                                       int64_t V0, int64_t V1, int sat_mode) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -294,7 +294,14 @@ __global__ __launch_bounds__(256) void sg_pairs_kernel(const float* __restrict__
     float dot = 0.f;
     for (int c = lane; c < D; c += 64) dot += h[c] * w[c];
     dot = wave_sum(dot);
-    const float f = 1.f / (1.f + __expf(-dot));
+    // the reference's exp-table bounds (MAX_EXP = 6, sg_cb.cu): a saturated hierarchic-softmax node is skipped, a saturated negative
+    // sample is treated as exactly 0 / 1. Without the skip the batched hogwild update can run away (NaN after ~40 epochs on a toy corpus)
+    float f = 1.f / (1.f + __expf(-dot));
+    if (sat_mode == 1 && !(dot > -6.f && dot < 6.f)) {
+      for (int c = lane; c < D; c += 64) dh[p * D + c] = 0.f;
+      continue;
+    }
+    if (sat_mode == 2) f = dot > 6.f ? 1.f : (dot < -6.f ? 0.f : f);
     const float g = (label[p] - f) * lr * scale;
     for (int c = lane; c < D; c += 64) {
       const float wv = w[c], hv = h[c];
@@ -431,10 +438,10 @@ DL4J_API int dl4j_resize_nhwc(const void* x, void* y, int N, int H, int W, int C
 // dh: [n_pairs, D] fp32, fully written here
 DL4J_API int dl4j_sg_pairs(const float* syn0, float* syn1, const float* hidden, const int64_t* in_idx, const int64_t* tgt_idx,
                            const float* label, float* dh, int64_t n_pairs, int D, float lr, float scale, int64_t V0, int64_t V1,
-                           hipStream_t st) {
+                           int sat_mode, hipStream_t st) {
   if (n_pairs <= 0 || D <= 0) return 0;
   const int g = grid_for(n_pairs, 4);      // 4 waves per block, one pair per wave
   hipLaunchKernelGGL(sg_pairs_kernel, dim3(g), dim3(256), 0, st, syn0, syn1, hidden, in_idx, tgt_idx, label, dh, n_pairs, D, lr, scale,
-                     V0, V1);
+                     V0, V1, sat_mode);
   DL4J_RET_LAST();
 }

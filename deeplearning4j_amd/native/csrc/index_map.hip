@@ -42,6 +42,9 @@ struct MapP {
   uint32_t seg_m;       // fast divisor: segments per innermost row (long rows are cut into segments of seg_vecs pieces)
   int32_t seg_s;
   int32_t segs_per_row, seg_vecs;
+  uint32_t slab_m;      // fast divisor: slabs of the second-innermost dimension (short rows: one visit covers `slab` of its coordinates)
+  int32_t slab_s;
+  int32_t slab, slabs;
 };
 
 __device__ __forceinline__ int map_dim(const DimMap& m, int c) {
@@ -91,48 +94,65 @@ __global__ void __launch_bounds__(256) index_map_kernel(const T* __restrict__ in
   const DimMap m0 = p.d[p.rank - 1];
   const bool unit = m0.mode == M_SHIFT || m0.mode == M_WRAP || (m0.mode == M_STRIDE && m0.b == 1);
   const bool in_unit = m0.in_stride == 1, out_unit = m0.out_stride == 1;
-  const int64_t vrows = rows * p.segs_per_row;
+  // visits: (outer coordinates) x (slabs of the second-innermost dimension) x (segments of the innermost row)
+  const DimMap m1 = p.d[p.rank >= 2 ? p.rank - 2 : 0];
+  const int region1 = p.rank >= 2 ? m1.region : 1;
+  const int64_t vrows = (rows / region1) * p.slabs * p.segs_per_row;
+  const bool small = vrows < 2147483647LL;
   for (int64_t vrow = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> lg2_L); vrow < vrows; vrow += (int64_t)gridDim.x * rows_per_block) {
-    int64_t io = 0, oo = p.out_base;
-    bool row_valid = true;
-    int64_t row = vrow;
-    int seg = 0;
-    if (p.segs_per_row > 1) {
-      if (vrows < 2147483647LL) {
-        const uint32_t q = fastdiv((uint32_t)vrow, p.seg_m, p.seg_s);
-        seg = (int)((uint32_t)vrow - q * (uint32_t)p.segs_per_row);
-        row = q;
-      } else {
-        seg = (int)(vrow % p.segs_per_row);
-        row = vrow / p.segs_per_row;
+    int64_t io0 = 0, oo0 = p.out_base;
+    bool outer_valid = true;
+    int seg = 0, slab = 0;
+    if (small) {
+      uint32_t rem = (uint32_t)vrow;
+      if (p.segs_per_row > 1) {
+        const uint32_t q = fastdiv(rem, p.seg_m, p.seg_s);
+        seg = (int)(rem - q * (uint32_t)p.segs_per_row);
+        rem = q;
       }
-    }
-    const int v_begin = seg * p.seg_vecs, v_end = min(vec_per_row, v_begin + p.seg_vecs);
-    if (rows < 2147483647LL) {
-      uint32_t rem = (uint32_t)row;
+      if (p.slabs > 1) {
+        const uint32_t q = fastdiv(rem, p.slab_m, p.slab_s);
+        slab = (int)(rem - q * (uint32_t)p.slabs);
+        rem = q;
+      }
 #pragma unroll 1
-      for (int k = p.rank - 2; k >= 0; --k) {
+      for (int k = p.rank - 3; k >= 0; --k) {
         const DimMap& m = p.d[k];
         const uint32_t q = fastdiv(rem, m.div_m, m.div_s);
         const int c = (int)(rem - q * (uint32_t)m.region);
         rem = q;
         const int s = m.mode == M_SHIFT ? c + m.a : map_dim(m, c);
-        if ((unsigned)s >= (unsigned)m.in_dim) row_valid = false;
-        io += (int64_t)s * m.in_stride;
-        oo += (int64_t)c * m.out_stride;
+        if ((unsigned)s >= (unsigned)m.in_dim) outer_valid = false;
+        io0 += (int64_t)s * m.in_stride;
+        oo0 += (int64_t)c * m.out_stride;
       }
     } else {
-      int64_t rem = row;
+      int64_t rem = vrow;
+      seg = (int)(rem % p.segs_per_row);
+      rem /= p.segs_per_row;
+      slab = (int)(rem % p.slabs);
+      rem /= p.slabs;
 #pragma unroll 1
-      for (int k = p.rank - 2; k >= 0; --k) {
+      for (int k = p.rank - 3; k >= 0; --k) {
         const DimMap& m = p.d[k];
         const int c = (int)(rem % m.region);
         rem /= m.region;
         const int s = map_dim(m, c);
-        if ((unsigned)s >= (unsigned)m.in_dim) row_valid = false;
-        io += (int64_t)s * m.in_stride;
-        oo += (int64_t)c * m.out_stride;
+        if ((unsigned)s >= (unsigned)m.in_dim) outer_valid = false;
+        io0 += (int64_t)s * m.in_stride;
+        oo0 += (int64_t)c * m.out_stride;
       }
+    }
+    const int v_begin = seg * p.seg_vecs, v_end = min(vec_per_row, v_begin + p.seg_vecs);
+    const int c1_begin = slab * p.slab, c1_end = min(region1, c1_begin + p.slab);
+    for (int c1 = c1_begin; c1 < c1_end; ++c1) {
+    int64_t io = io0, oo = oo0;
+    bool row_valid = outer_valid;
+    if (p.rank >= 2) {
+      const int s1 = m1.mode == M_SHIFT ? c1 + m1.a : map_dim(m1, c1);
+      if ((unsigned)s1 >= (unsigned)m1.in_dim) row_valid = false;
+      io += (int64_t)s1 * m1.in_stride;
+      oo += (int64_t)c1 * m1.out_stride;
     }
     const T* irow = in + io;
     T* orow = out + oo;
@@ -182,6 +202,7 @@ __global__ void __launch_bounds__(256) index_map_kernel(const T* __restrict__ in
           if (j < nv) dst[(int64_t)j * m0.out_stride] = val.v[j];
       }
     }
+    }   // c1
   }
 }
 
@@ -198,9 +219,14 @@ static void launch_index_map(const void* in, void* out, MapP& p, uint64_t pad_bi
   int lg = 0;
   while ((1 << lg) < p.seg_vecs && lg < 6) ++lg;              // lanes per row segment: 1 .. 64
   const int rows_per_block = 256 >> lg;
+  // short rows: one visit walks up to 8 coordinates of the second-innermost dimension, so the outer decomposition is paid once per slab
+  const int region1 = p.rank >= 2 ? p.d[p.rank - 2].region : 1;
+  p.slab = (p.rank >= 2 && p.segs_per_row == 1 && vec_per_row <= 64) ? (region1 < 8 ? region1 : 8) : 1;
+  p.slabs = (region1 + p.slab - 1) / p.slab;
+  fastdiv_init((uint32_t)p.slabs, &p.slab_m, &p.slab_s);
+  const int64_t vrows = (rows / region1) * p.slabs * p.segs_per_row;
   // about 8 pieces per thread before the grid-stride loop repeats
-  const int64_t pieces_per_block = (int64_t)rows_per_block * p.seg_vecs;
-  const int64_t vrows = rows * p.segs_per_row;
+  const int64_t pieces_per_block = (int64_t)rows_per_block * p.seg_vecs * p.slab;
   int64_t blocks = (vrows + rows_per_block - 1) / rows_per_block;
   if (pieces_per_block < 2048) {
     const int64_t fold = 2048 / (pieces_per_block > 0 ? pieces_per_block : 1);

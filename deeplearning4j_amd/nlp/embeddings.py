@@ -143,17 +143,17 @@ def _train_batch_hip(table, l1, targets, alpha, hs, n_neg, gen):
     B, D = l1.shape
     neu1e = torch.zeros_like(l1)
 
-    def run(syn, tg, lab):
+    def run(syn, tg, lab, saturation):
         K = tg.shape[1]
         hidden = l1.unsqueeze(1).expand(B, K, D).reshape(B * K, D).contiguous()
         dh = H.sg_pairs_(table.syn0, syn, tg.reshape(-1), tg.reshape(-1).contiguous(), lab.reshape(-1).contiguous(), float(alpha),
-                         hidden=hidden)
+                         hidden=hidden, saturation=saturation)
         return dh.view(B, K, D).sum(1)
 
     if hs is not None:
         codes, points, mask = hs
         pts = torch.where(mask[targets] > 0, points[targets], torch.full_like(points[targets], -1))
-        neu1e += run(table.syn1, pts.long(), (1.0 - codes[targets]).float())
+        neu1e += run(table.syn1, pts.long(), (1.0 - codes[targets]).float(), 1)
     if n_neg > 0:
         r = torch.rand(B, n_neg, device=l1.device, generator=gen)
         negs = torch.searchsorted(table.neg_cdf(), r).clamp_(max=table.syn1neg.shape[0] - 1)
@@ -161,7 +161,7 @@ def _train_batch_hip(table, l1, targets, alpha, hs, n_neg, gen):
         tg = torch.cat([targets.unsqueeze(1), negs], 1)
         lab = torch.zeros(tg.shape, dtype=torch.float32, device=l1.device)
         lab[:, 0] = 1
-        neu1e += run(table.syn1neg, tg.long(), lab)
+        neu1e += run(table.syn1neg, tg.long(), lab, 2)
     return neu1e
 
 

@@ -268,9 +268,10 @@ def resize_nhwc(x, oH, oW, mode="bilinear", align_corners=False, half_pixel=Fals
 
 
 # ----------------------------------------------------------------------------- word2vec batched step
-def sg_pairs_(syn0, syn1, in_idx, tgt_idx, label, lr, hidden=None, scale=1.0):
+def sg_pairs_(syn0, syn1, in_idx, tgt_idx, label, lr, hidden=None, scale=1.0, saturation=0):
     """One batched skip-gram / CBOW update: syn1 rows are updated in place, returns dh [n_pairs, D] (the input-side
-    gradient of each pair, to be scatter-added into syn0 — or distributed over the context for CBOW)."""
+    gradient of each pair, to be scatter-added into syn0 — or distributed over the context for CBOW). ``saturation``: the reference's
+    MAX_EXP = 6 rule, 1 = hierarchic softmax (a saturated node is skipped), 2 = negative sampling (sigmoid clamped to 0 / 1), 0 = none."""
     n = tgt_idx.numel()
     D = syn0.shape[1]
     for t in (syn0, syn1):
@@ -282,7 +283,7 @@ def sg_pairs_(syn0, syn1, in_idx, tgt_idx, label, lr, hidden=None, scale=1.0):
     dh = torch.empty(n, D, device=syn0.device, dtype=torch.float32)
     L.check(L.hip().dl4j_sg_pairs(L.ptr(syn0), L.ptr(syn1), L.ptr(hidden), L.ptr(in_idx), L.ptr(tgt_idx), L.ptr(label), L.ptr(dh),
                                   L.c_int64(n), L.c_int(D), L.c_float(lr), L.c_float(scale), L.c_int64(syn0.shape[0]),
-                                  L.c_int64(syn1.shape[0]), L.stream()), "sg_pairs")
+                                  L.c_int64(syn1.shape[0]), L.c_int(int(saturation)), L.stream()), "sg_pairs")
     return dh
 
 
