@@ -15,6 +15,7 @@
 //    a second merge kernel. Short TADs get one wave64 each, long ones a 256-thread block.
 //  * 64-bit indexing throughout (288 GB HBM makes > 2^31 elements reachable).
 #include "common.h"
+#include <type_traits>
 
 #define MAXR 8
 
@@ -710,7 +711,16 @@ __global__ void __launch_bounds__(256) reduce_finish_kernel(const double* __rest
   const int lane = threadIdx.x & 63;
   for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < num_tads; t += (int64_t)gridDim.x * 4) {
     double acc = red_init(kind);
-    for (int s = lane; s < segs; s += 64) acc = red_merge(kind, acc, partial[t * segs + s]);
+    int s = lane;
+    // 8 loads in flight per lane: with 8k segments of one TAD a lane walks 128 partials, and one dependent load per step cost ~35 us
+    for (; s + 7 * 64 < segs; s += 8 * 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[t * segs + s + u * 64];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = red_merge(kind, acc, v[u]);
+    }
+    for (; s < segs; s += 64) acc = red_merge(kind, acc, partial[t * segs + s]);
     acc = wave_merge(kind, acc);
     if (lane == 0) stv<Z, double>(z, t, red_post(f, acc, (double)tad_len, ex.e));
   }
@@ -736,12 +746,34 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(const T* __restrict__ x
     const int64_t seg_len = (nvec + segs - 1) / segs;
     const int64_t j0 = sidx * seg_len, j1 = (j0 + seg_len < nvec) ? j0 + seg_len : nvec;
     const T* base = x + tad_base(d.oshape, d.ostride, d.orank, t);
-    for (int64_t j = j0 + lane; j < j1; j += group) {
+    int64_t j = j0 + lane;
+    // four 16-byte loads in flight per lane and two accumulator chains: with one load per iteration the loop is bound by HBM latency
+    // (8 dependent round trips per thread at 64M elements), not bandwidth
+    double acc2 = red_init(kind);
+    for (; j + 3 * (int64_t)group < j1; j += 4 * (int64_t)group) {
+      float v0[N], v1[N], v2[N], v3[N];
+      VecIO<T>::ld(base + j * N, v0);
+      VecIO<T>::ld(base + (j + group) * N, v1);
+      VecIO<T>::ld(base + (j + 2 * (int64_t)group) * N, v2);
+      VecIO<T>::ld(base + (j + 3 * (int64_t)group) * N, v3);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        acc = red_merge(kind, acc, red_pre(f, (double)v0[k], ex.e));
+        acc2 = red_merge(kind, acc2, red_pre(f, (double)v1[k], ex.e));
+      }
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        acc = red_merge(kind, acc, red_pre(f, (double)v2[k], ex.e));
+        acc2 = red_merge(kind, acc2, red_pre(f, (double)v3[k], ex.e));
+      }
+    }
+    for (; j < j1; j += group) {
       float v[N];
       VecIO<T>::ld(base + j * N, v);
 #pragma unroll
       for (int k = 0; k < N; ++k) acc = red_merge(kind, acc, red_pre(f, (double)v[k], ex.e));
     }
+    acc = red_merge(kind, acc, acc2);
     acc = wave_merge(kind, acc);
     if (group == 256) {
       __syncthreads();
@@ -773,7 +805,29 @@ __global__ __launch_bounds__(256) void reduce_col_kernel(const T* __restrict__ x
 #pragma unroll
   for (int k = 0; k < CPT; ++k) acc[k] = red_init(kind);
   if (c0 < cols) {
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
+    int64_t r = r0 + rl;
+    // four rows in flight per lane (loads first, then the accumulate chain): one row per iteration left the loop latency-bound
+    for (; r + 12 < r1; r += 16) {
+      double v[4][CPT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const T* p = x + (r + 4 * u) * pitch + c0;
+        if (std::is_same<T, bf16_t>::value && CPT == 2 && c0 + 1 < cols && (reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(p);        // both bf16 columns of the lane in one dword load
+          v[u][0] = (double)__uint_as_float(w << 16);
+          v[u][CPT - 1] = (double)__uint_as_float(w & 0xffff0000u);
+        } else {
+#pragma unroll
+          for (int k = 0; k < CPT; ++k) v[u][k] = (c0 + k < cols) ? (double)ldv<T>(p, k) : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+          if (c0 + k < cols) acc[k] = red_merge(kind, acc[k], red_pre(f, v[u][k], ex.e));
+    }
+    for (; r < r1; r += 4) {
       const T* p = x + r * pitch + c0;
 #pragma unroll
       for (int k = 0; k < CPT; ++k)
