@@ -111,7 +111,7 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
             else:
                 dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
         if need_dx:
-            if w_dgrad is not None and IG.dgrad_supported(w, stride, padding):
+            if w_dgrad is not None and IG.dgrad_supported(w, stride, padding, dz):
                 acc = dx_accum if IG.accum_ok(dx_accum, x.shape) else None
                 dx = IG.dgrad(dz, x.shape, w_dgrad, stride, padding, dilation, accum_into=acc)
                 if dx_accum is not None and acc is None:

@@ -147,7 +147,10 @@ def wgrad_supported(x, w):
             and x.numel() <= _MAX_ELEMS and x.data_ptr() % 16 == 0)
 
 
-def dgrad_supported(w, stride, padding):
+def dgrad_supported(w, stride, padding, dz=None):
+    """``dz``: the incoming gradient; dgrad reuses the forward kernel with dz as the gathered operand, whose offsets are 32-bit."""
+    if dz is not None and dz.numel() > _MAX_ELEMS:
+        return False
     R, S = w.shape[2], w.shape[3]
     if tuple(stride) == (1, 1):
         return True
