@@ -66,6 +66,25 @@ __global__ void one_hot_kernel(const I* __restrict__ idx, T* __restrict__ out, i
   }
 }
 
+// rows that are whole 16-byte pieces: one thread writes one piece (V = 4 fp32 / 8 bf16 elements), one 32-bit division per piece
+template <typename T, typename I>
+__global__ void __launch_bounds__(256) one_hot_vec_kernel(const I* __restrict__ idx, T* __restrict__ out, uint32_t total_pieces, uint32_t ppr,
+                                                          float on, float off) {
+  constexpr int V = 16 / (int)sizeof(T);
+  struct alignas(16) Vec { T v[V]; };
+  T t_on, t_off;
+  Cvt<T>::st(&t_on, 0, on);
+  Cvt<T>::st(&t_off, 0, off);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total_pieces; i += gridDim.x * 256u) {
+    const uint32_t r = i / ppr, c0 = (i - r * ppr) * V;
+    const int64_t hot = (int64_t)idx[r] - (int64_t)c0;          // position of the hot element inside this piece, if any
+    Vec o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o.v[j] = hot == j ? t_on : t_off;
+    *reinterpret_cast<Vec*>(out + (int64_t)i * V) = o;
+  }
+}
+
 // ------------------------------------------------------------------ cumsum along the innermost dim, one block (4 waves) per row
 __device__ __forceinline__ float wave_incl_scan(float v) {
   const int lane = threadIdx.x & 63;
@@ -357,6 +376,13 @@ DL4J_API int dl4j_scatter_add_rows(const void* src, const void* idx, float* tabl
 
 DL4J_API int dl4j_one_hot(const void* idx, void* out, int64_t n, int depth, float on, float off, int dtype, int idx64, hipStream_t st) {
   if (n <= 0 || depth <= 0) return 0;
+  const int V = dtype == 1 ? 8 : 4;
+  if (depth % V == 0 && n * (depth / V) < 4294967295LL && !((uintptr_t)out & 15)) {
+    const uint32_t ppr = (uint32_t)(depth / V), total = (uint32_t)(n * ppr);
+    DISPATCH_T(DISPATCH_I(hipLaunchKernelGGL((one_hot_vec_kernel<T, I>), dim3(grid_for(total, 512)), dim3(256), 0, st, (const I*)idx, (T*)out, total,
+                                             ppr, on, off);))
+    DL4J_RET_LAST();
+  }
   const int g = grid_for(n * depth, 1024);
   DISPATCH_T(DISPATCH_I(hipLaunchKernelGGL((one_hot_kernel<T, I>), dim3(g), dim3(256), 0, st, (const I*)idx, (T*)out, n, depth, on, off);))
   DL4J_RET_LAST();

@@ -290,3 +290,15 @@ def test_gather_rows_vector_path():
             got = H.gather_rows(table.to(dev()), idx.to(dev()).reshape(-1)) if hasattr(H, "gather_rows") else None
             if got is not None:
                 assert torch.equal(got.cpu().reshape(ref.shape), ref), (shape, dt, idt)
+
+
+def test_onehot_vector_path():
+    """helpers_data.hip one_hot_vec_kernel (depth a multiple of the 16-byte vector) next to the element-wise form; out-of-range and negative
+    indices give an all-off row."""
+    g = torch.Generator().manual_seed(2)
+    for depth in (16, 1024, 10):
+        for idt in (torch.int64, torch.int32):
+            idx = torch.randint(-2, depth + 2, (7, 33), generator=g).to(idt)
+            got = _platform_vs_generic("onehot", [idx], [-1, depth], [2.0, -1.0])[0]
+            ref = torch.where(torch.arange(depth).view(1, 1, -1) == idx.long().unsqueeze(-1), 2.0, -1.0)
+            assert torch.equal(got.float().cpu(), ref)
