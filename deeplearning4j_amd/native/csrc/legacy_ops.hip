@@ -1042,7 +1042,8 @@ template <> struct HasVec<bf16_t> { static constexpr bool value = true; };
 
 // rows-per-slab choice of the column reduction: enough (column block, slab) pairs to fill the chip, slabs of at least 64 rows
 static int col_segs(int64_t rows, int64_t col_blocks) {
-  int64_t want = (4 * DL4J_NUM_CU + col_blocks - 1) / col_blocks;
+  // 8 blocks per CU (a full complement of 2048 threads): the kernel is bound by the loads in flight, 4 per CU left bf16 at 2.6 TB/s
+  int64_t want = (8 * DL4J_NUM_CU + col_blocks - 1) / col_blocks;
   const int64_t maxs = (rows + 63) / 64;
   if (want > maxs) want = maxs;
   if (want > 256) want = 256;
