@@ -726,6 +726,31 @@ __global__ void __launch_bounds__(256) reduce_finish_kernel(const double* __rest
   }
 }
 
+// few TADs with many segments (a full reduction: 1 TAD x 8k partials): one 256-thread block per TAD instead of one wave
+template <typename Z>
+__global__ void __launch_bounds__(256) reduce_finish_block_kernel(const double* __restrict__ partial, Z* __restrict__ z, int64_t num_tads,
+                                                                  int segs, int64_t tad_len, int f, Extra ex) {
+  __shared__ double red[4];
+  const int kind = red_kind(f);
+  const int64_t t = blockIdx.x;
+  if (t >= num_tads) return;
+  double acc = red_init(kind);
+  int s = threadIdx.x;
+  for (; s + 7 * 256 < segs; s += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[t * segs + s + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = red_merge(kind, acc, v[u]);
+  }
+  for (; s < segs; s += 256) acc = red_merge(kind, acc, partial[t * segs + s]);
+  acc = wave_merge(kind, acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    stv<Z, double>(z, t, red_post(f, red_merge(kind, red_merge(kind, red[0], red[1]), red_merge(kind, red[2], red[3])), (double)tad_len, ex.e));
+}
+
 // Dense-TAD variant of reduce_kernel for fp32 / bf16: the reduced elements of a TAD are contiguous and every TAD starts on a 16-byte
 // boundary, so a lane moves 16-byte vectors (same grouping / segment scheme, same double accumulators).
 template <typename T, typename Z, int F>
@@ -1110,7 +1135,10 @@ static int run_reduce(const void* x, void* z, double* partial, const TadDesc& d,
   }
   if (!vec) reduce_kernel<T, Z><<<g, 256, 0, st>>>((const T*)x, (Z*)z, partial, d, f, ex, group, (int)segs);
   if (segs > 1)
-    reduce_finish_kernel<Z><<<grid_for((d.num_tads + 3) / 4, 1), 256, 0, st>>>(partial, (Z*)z, d.num_tads, (int)segs, d.tad_len, f, ex);
+    if (d.num_tads <= 64 && segs >= 1024)
+      reduce_finish_block_kernel<Z><<<(unsigned)d.num_tads, 256, 0, st>>>(partial, (Z*)z, d.num_tads, (int)segs, d.tad_len, f, ex);
+    else
+      reduce_finish_kernel<Z><<<grid_for((d.num_tads + 3) / 4, 1), 256, 0, st>>>(partial, (Z*)z, d.num_tads, (int)segs, d.tad_len, f, ex);
   return (int)hipGetLastError();
 }
 
