@@ -65,6 +65,8 @@ def main():
 
     for _ in range(args.warmup):
         net.fit(x, y)
+    if pw is not None:
+        pw.buckets.bytes_launched = pw.buckets.collectives = 0
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -78,6 +80,12 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     score = net.score()
+    # verification block (outside the timed region): what the collectives saw and whether the replicas still agree bit for bit
+    if pw is not None:
+        comm_rep = pw.comm_report(steps=args.steps)
+    else:
+        comm_rep = {"backend": "none", "world_size_seen": 1, "buckets": 0, "bytes_per_step": 0, "collectives_per_step": 0,
+                    "params_in_sync": True}
     if rank == 0:
         gb = args.batch * world
         ips = gb * args.steps / dt
@@ -89,7 +97,8 @@ def main():
             "config": {"model": "ResNet-50 zoo ComputationGraph (DL4J ResNet50.java definition)", "global_batch": gb,
                        "per_gpu_batch": args.batch, "image": "3x%dx%d" % (args.image, args.image), "classes": args.classes,
                        "updater": "RmsProp(0.1,0.96,0.001)+l1 1e-7+l2 5e-5", "parallelism": "dp%d" % world,
-                       "hip_graph": not args.no_graph, "final_score": round(float(score), 4)}})
+                       "hip_graph": not args.no_graph, "final_score": round(float(score), 4)},
+            "comm": comm_rep})
         sys.stdout.flush()
         os.write(result_fd, (line + "\n").encode())
     if torch.distributed.is_initialized():

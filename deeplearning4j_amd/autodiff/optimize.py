@@ -337,7 +337,7 @@ class Fusion(Optimization):
             for a_, m_ in (cur.inputs, cur.inputs[::-1]):
                 src = self._additive_key_mask(sd, m_)
                 if src is not None:
-                    key_mask, cur = src, _producer(sd, a_)
+                    key_mask, mask_at_add, cur = src, m_, _producer(sd, a_)
                     break
             else:
                 return False
@@ -354,6 +354,16 @@ class Fusion(Optimization):
         if ia[0] or not ia[1] or ia[2]:
             return False                          # need q · kᵀ
         q, k, v = cur.inputs[0], cur.inputs[1], mm2.inputs[1]
+        if key_mask is not None:
+            # only a PADDING mask qualifies: [B, 1, .., 1, Tk] at the add, from a [B, Tk] array. A [Tq, Tk] additive mask
+            # broadcast over batch and heads (causal (1 - tril) * -1e9) must stay unfused: the fused op would read it as a
+            # per-batch key mask.
+            qs, ks, ms, ss = sd.inferShape(q), sd.inferShape(k), sd.inferShape(mask_at_add), sd.inferShape(key_mask)
+            if qs is None or ks is None or ms is None or ss is None or len(qs) != len(ks) or len(qs) < 3 or len(ms) != len(qs):
+                return False
+            B, Tk = qs[0], ks[-2]            # a dynamic batch (-1) must be dynamic on both sides
+            if list(ms) != [B] + [1] * (len(qs) - 2) + [Tk] or list(ss) != [B, Tk]:
+                return False
         ins = [q, v, k] + ([key_mask] if key_mask is not None else [])
         new = SameDiffOp(mm2.name, "dot_product_attention_v2", ins, mm2.outputs, iArgs=[0, 1 if key_mask is not None else 0],
                          tArgs=[scale, 0.0], bArgs=[False, False])
@@ -374,6 +384,8 @@ class Fusion(Optimization):
             one = _const_val(sd, sub.inputs[0])
             if one is None or one.numel() != 1 or abs(float(one) - 1.0) > 1e-6:
                 continue
+            # walk up through pure shape / type changes only; the rank-2 array must be REACHED through at least one of them
+            # or be the operand itself with the broadcast done by the subtract (checked against q / k by the caller)
             m = sub.inputs[1]
             for _ in range(6):
                 shp = sd.inferShape(m)

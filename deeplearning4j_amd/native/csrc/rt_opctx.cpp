@@ -155,6 +155,7 @@ struct Bcast {
 };
 bool make_bcast(const Arr& a, const Arr& b, const Arr& o, Bcast& bc) {
   bc.rank = o.rank();
+  if (bc.rank > rt::MAX_RANK || a.rank() > bc.rank || b.rank() > bc.rank || bc.rank < 0) return false;
   LongType sa = 1, sb = 1;
   for (int k = bc.rank - 1, ka = a.rank() - 1, kb = b.rank() - 1; k >= 0; --k, --ka, --kb) {
     const LongType od = o.dim(k), ad = ka >= 0 ? a.dim(ka) : 1, bd = kb >= 0 ? b.dim(kb) : 1;
@@ -201,6 +202,7 @@ void fill_strides3(const Arr& x, const Arr* y, const Arr& z, Strides3& s) {
   if (same) return;
   s.contiguous = 0;
   s.rank = z.rank();
+  if (s.rank > 8) { s.rank = 0; s.contiguous = 1; return; }     // callers reject rank > 8 before launching; never write past [8]
   LongType sx = 1, sy = 1, sz = 1;
   for (int k = z.rank() - 1, kx = x.rank() - 1, ky = y ? y->rank() - 1 : -1; k >= 0; --k, --kx, --ky) {
     const LongType od = z.dim(k), xd = kx >= 0 ? x.dim(kx) : 1, yd = (y && ky >= 0) ? y->dim(ky) : 1;
@@ -226,8 +228,8 @@ int exec_binary(OpaqueContext& c) {
   if (all_device(c)) {
     Hip* h = hip();
     if (!h || !h->pairwise || legacy_code(dt) < 0) return fail(24, "device execution unavailable for this op / data type");
+    if (o.rank() > 8 || a.rank() > 8 || b.rank() > 8) return fail(24, "device broadcast: rank above 8 is not handled natively");
     Strides3 s; fill_strides3(a, &b, o, s);
-    Arr da = a, db = b, dz = o;
     return h->pairwise(FUNCTOR, a.dev, b.dev, o.dev, o.length(), &s, nullptr, 0, 0.0, legacy_code(dt), 0, c.stream) == 0 ? 0
            : fail(25, "dl4j_legacy_pairwise failed");
   }
@@ -262,6 +264,7 @@ int exec_unary(OpaqueContext& c) {
   if (all_device(c)) {
     Hip* h = hip();
     if (!h || legacy_code(dt) < 0) return fail(24, "device execution unavailable for this op / data type");
+    if (o.rank() > 8 || a.rank() > 8) return fail(24, "device transform: rank above 8 is not handled natively");
     Strides3 s; fill_strides3(a, nullptr, o, s);
     if (KIND == 0) return h->pairwise(B_RELU, a.dev, nullptr, o.dev, o.length(), &s, nullptr, 1, c.t.empty() ? 0.0 : c.t[0], legacy_code(dt), 0, c.stream) == 0 ? 0 : fail(25, "dl4j_legacy_pairwise failed");
     const int f = KIND == 1 ? U_SIGMOID : KIND == 2 ? U_TANH : U_IDENTITY;
@@ -393,7 +396,10 @@ int exec_reduce(OpaqueContext& c) {
   if (!contiguous_all(c)) return fail(23, "native executors take c-contiguous arrays");
   const int rank = x.rank();
   std::vector<char> red((size_t)rank, c.i.empty() ? 1 : 0);
-  for (LongType dmn : c.i) red[(size_t)(dmn < 0 ? dmn + rank : dmn)] = 1;
+  for (LongType dmn : c.i) {
+    if (dmn < -rank || dmn >= rank) return fail(22, "reduce: dimension out of range for the input rank");
+    red[(size_t)(dmn < 0 ? dmn + rank : dmn)] = 1;
+  }
   std::vector<LongType> ostride((size_t)rank, 0);
   LongType s = 1, cnt = 1;
   for (int k = rank - 1; k >= 0; --k) { if (!red[(size_t)k]) { ostride[(size_t)k] = s; s *= x.dim(k); } else cnt *= x.dim(k); }
@@ -454,7 +460,10 @@ int shape_reduce(const std::vector<const LongType*>& in, const OpaqueContext& a,
   const int rank = rt::si_rank(in[0]);
   const bool keep = !a.b.empty() && a.b[0];
   std::vector<char> red((size_t)rank, a.i.empty() ? 1 : 0);
-  for (LongType d : a.i) red[(size_t)(d < 0 ? d + rank : d)] = 1;
+  for (LongType d : a.i) {
+    if (d < -rank || d >= rank) return fail(31, "reduce shape function: dimension out of range for the input rank");
+    red[(size_t)(d < 0 ? d + rank : d)] = 1;
+  }
   std::vector<LongType> s;
   for (int k = 0; k < rank; ++k) { if (!red[(size_t)k]) s.push_back(rt::si_shape(in[0])[k]); else if (keep) s.push_back(1); }
   push_shape(out, s, dtype_of(in[0]));
@@ -520,16 +529,40 @@ RT_API void setGraphContextDArguments(OpaqueContext* ctx, int* arguments, int nu
 RT_API int ctxNumInputs(OpaqueContext* ctx) { return (int)ctx->in.size(); }
 RT_API int ctxNumOutputs(OpaqueContext* ctx) { return (int)ctx->out.size(); }
 // accessors the fallback needs to read a context from the other side of the ABI
-RT_API void* ctxInputBuffer(OpaqueContext* ctx, int k, int special) { return special ? ctx->in[(size_t)k].dev : ctx->in[(size_t)k].host; }
-RT_API const LongType* ctxInputShapeInfo(OpaqueContext* ctx, int k) { return ctx->in[(size_t)k].si; }
-RT_API void* ctxOutputBuffer(OpaqueContext* ctx, int k, int special) { return special ? ctx->out[(size_t)k].dev : ctx->out[(size_t)k].host; }
-RT_API const LongType* ctxOutputShapeInfo(OpaqueContext* ctx, int k) { return ctx->out[(size_t)k].si; }
+namespace {
+template <typename V> inline bool in_range(const V& v, int k) { return k >= 0 && (size_t)k < v.size(); }
+}
+RT_API void* ctxInputBuffer(OpaqueContext* ctx, int k, int special) {
+  if (!ctx || !in_range(ctx->in, k)) { fail(14, "ctxInputBuffer: index out of range"); return nullptr; }
+  return special ? ctx->in[(size_t)k].dev : ctx->in[(size_t)k].host;
+}
+RT_API const LongType* ctxInputShapeInfo(OpaqueContext* ctx, int k) {
+  if (!ctx || !in_range(ctx->in, k)) { fail(14, "ctxInputShapeInfo: index out of range"); return nullptr; }
+  return ctx->in[(size_t)k].si;
+}
+RT_API void* ctxOutputBuffer(OpaqueContext* ctx, int k, int special) {
+  if (!ctx || !in_range(ctx->out, k)) { fail(14, "ctxOutputBuffer: index out of range"); return nullptr; }
+  return special ? ctx->out[(size_t)k].dev : ctx->out[(size_t)k].host;
+}
+RT_API const LongType* ctxOutputShapeInfo(OpaqueContext* ctx, int k) {
+  if (!ctx || !in_range(ctx->out, k)) { fail(14, "ctxOutputShapeInfo: index out of range"); return nullptr; }
+  return ctx->out[(size_t)k].si;
+}
 RT_API int ctxNumTArgs(OpaqueContext* ctx) { return (int)ctx->t.size(); }
 RT_API int ctxNumIArgs(OpaqueContext* ctx) { return (int)ctx->i.size(); }
 RT_API int ctxNumBArgs(OpaqueContext* ctx) { return (int)ctx->b.size(); }
-RT_API double ctxTArg(OpaqueContext* ctx, int k) { return ctx->t[(size_t)k]; }
-RT_API LongType ctxIArg(OpaqueContext* ctx, int k) { return ctx->i[(size_t)k]; }
-RT_API int ctxBArg(OpaqueContext* ctx, int k) { return ctx->b[(size_t)k]; }
+RT_API double ctxTArg(OpaqueContext* ctx, int k) {
+  if (!ctx || !in_range(ctx->t, k)) { fail(14, "ctxTArg: index out of range"); return 0.0; }
+  return ctx->t[(size_t)k];
+}
+RT_API LongType ctxIArg(OpaqueContext* ctx, int k) {
+  if (!ctx || !in_range(ctx->i, k)) { fail(14, "ctxIArg: index out of range"); return 0; }
+  return ctx->i[(size_t)k];
+}
+RT_API int ctxBArg(OpaqueContext* ctx, int k) {
+  if (!ctx || !in_range(ctx->b, k)) { fail(14, "ctxBArg: index out of range"); return 0; }
+  return ctx->b[(size_t)k];
+}
 
 RT_API void registerCustomOpFallback(void* fn, void* user) { g_fallback = (FallbackFn)fn; g_fallback_user = user; }
 RT_API int nativeOpImplemented(LongType hash) { return table().count(hash) ? 1 : 0; }

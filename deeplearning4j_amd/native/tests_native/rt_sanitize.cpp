@@ -61,6 +61,25 @@ const char* graph_var_name(LongType id, int v);
 int graph_var_shape(LongType id, int v, LongType* out, int cap);
 const void* graph_var_data(LongType id, int v, LongType* len);
 void nd4j_clear_error();
+LongType ops_hash(const char* name);
+struct OpaqueContext;
+struct OpaqueShapeList;
+OpaqueContext* createGraphContext(int nodeId);
+void deleteGraphContext(OpaqueContext* ctx);
+void setGraphContextInputArrays(OpaqueContext* ctx, int n, void** buffer, void** shapeInfo, void** specialBuffer, void** specialShapeInfo);
+void setGraphContextOutputArrays(OpaqueContext* ctx, int n, void** buffer, void** shapeInfo, void** specialBuffer, void** specialShapeInfo);
+void setGraphContextIArguments(OpaqueContext* ctx, LongType* arguments, int n);
+void setGraphContextTArguments(OpaqueContext* ctx, double* arguments, int n);
+int execCustomOp2(void** extra, LongType hash, OpaqueContext* ctx);
+OpaqueShapeList* calculateOutputShapes2(void** extra, LongType hash, void** inputBuffers, void** inputShapes, int numInputShapes, double* tArgs,
+                                        int numTArgs, LongType* iArgs, int numIArgs, bool* bArgs, int numBArgs, int* dArgs, int numDArgs);
+void deleteShapeList(OpaqueShapeList* list);
+void* ctxInputBuffer(OpaqueContext* ctx, int k, int special);
+const LongType* ctxInputShapeInfo(OpaqueContext* ctx, int k);
+void* ctxOutputBuffer(OpaqueContext* ctx, int k, int special);
+double ctxTArg(OpaqueContext* ctx, int k);
+LongType ctxIArg(OpaqueContext* ctx, int k);
+int ctxBArg(OpaqueContext* ctx, int k);
 }
 
 #define CHECK(c)                                          \
@@ -157,6 +176,48 @@ int main(int argc, char** argv) {
     dv_free(pc);
   }
   nd4j_clear_error();
+
+  // ---- op-execution ABI with hostile arguments: out-of-range reduce dimensions, rank > 8 "device" broadcast, bad accessor indices
+  {
+    const LongType F_FLOAT = 8192;
+    LongType xs[2] = {3, 4}, xsi[16], osi[16], o1[1] = {3};
+    CHECK(nd4j_shape_buffer(2, xs, 'c', F_FLOAT, xsi) == 0 && nd4j_shape_buffer(1, o1, 'c', F_FLOAT, osi) == 0);
+    std::vector<float> xv(12, 1.f), ov(3, 0.f);
+    void* ib[1] = {xv.data()}; void* isi[1] = {xsi}; void* ob[1] = {ov.data()}; void* oshp[1] = {osi};
+    OpaqueContext* c = createGraphContext(1);
+    setGraphContextInputArrays(c, 1, ib, isi, nullptr, nullptr);
+    setGraphContextOutputArrays(c, 1, ob, oshp, nullptr, nullptr);
+    LongType good[1] = {1}, bad_hi[1] = {2}, bad_lo[1] = {-3}, bad_far[1] = {1000000};
+    setGraphContextIArguments(c, good, 1);
+    CHECK(execCustomOp2(nullptr, ops_hash("reduce_sum"), c) == 0 && ov[0] == 4.f);
+    for (LongType* bad : {bad_hi, bad_lo, bad_far}) {
+      setGraphContextIArguments(c, bad, 1);
+      CHECK(execCustomOp2(nullptr, ops_hash("reduce_sum"), c) != 0);
+      OpaqueShapeList* sl = calculateOutputShapes2(nullptr, ops_hash("reduce_sum"), nullptr, isi, 1, nullptr, 0, bad, 1, nullptr, 0, nullptr, 0);
+      CHECK(sl == nullptr);
+    }
+    // accessor indices outside the context
+    CHECK(ctxInputBuffer(c, 5, 0) == nullptr && ctxInputBuffer(c, -1, 1) == nullptr && ctxInputShapeInfo(c, 9) == nullptr);
+    CHECK(ctxOutputBuffer(c, 3, 0) == nullptr && ctxTArg(c, 0) == 0.0 && ctxIArg(c, 7) == 0 && ctxBArg(c, 0) == 0);
+    deleteGraphContext(c);
+    // rank-9 broadcast add with "device" pointers: must be declined before any stride table is written (no device is touched)
+    LongType s9[9] = {2, 1, 2, 1, 2, 1, 2, 1, 2}, t9[9] = {1, 2, 1, 2, 1, 2, 1, 2, 1}, o9[9] = {2, 2, 2, 2, 2, 2, 2, 2, 2};
+    LongType a9[64], b9[64], z9[64];
+    CHECK(nd4j_shape_buffer(9, s9, 'c', F_FLOAT, a9) == 0 && nd4j_shape_buffer(9, t9, 'c', F_FLOAT, b9) == 0 && nd4j_shape_buffer(9, o9, 'c', F_FLOAT, z9) == 0);
+    std::vector<float> av(32, 1.f), bv(16, 2.f), zv(512, 0.f);
+    void* fake_dev_in[2] = {(void*)0x1000, (void*)0x2000}; void* fake_dev_out[1] = {(void*)0x3000};
+    void* hin[2] = {av.data(), bv.data()}; void* sin_[2] = {a9, b9}; void* hout[1] = {zv.data()}; void* sout[1] = {z9};
+    OpaqueContext* d = createGraphContext(2);
+    setGraphContextInputArrays(d, 2, nullptr, sin_, fake_dev_in, nullptr);
+    setGraphContextOutputArrays(d, 1, nullptr, sout, fake_dev_out, nullptr);
+    CHECK(execCustomOp2(nullptr, ops_hash("add"), d) != 0);
+    // the same shapes on the host are computed (rank 9 < MAX_RANK)
+    setGraphContextInputArrays(d, 2, hin, sin_, nullptr, nullptr);
+    setGraphContextOutputArrays(d, 1, hout, sout, nullptr, nullptr);
+    CHECK(execCustomOp2(nullptr, ops_hash("add"), d) == 0 && zv[0] == 3.f && zv[511] == 3.f);
+    deleteGraphContext(d);
+    nd4j_clear_error();
+  }
 
   // ---- op registry
   const int nops = ops_count();

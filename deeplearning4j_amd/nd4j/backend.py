@@ -128,7 +128,7 @@ class DL4JSystemProperties:
     CRASH_DUMP_OUTPUT_DIRECTORY_PROPERTY = "org.deeplearning4j.crash.reporting.directory"  # (DL4J_CRASH_REPORTING_DIR)
     UI_SERVER_PORT_PROPERTY = "org.deeplearning4j.ui.port"                      # (DL4J_UI_PORT)
     DISABLE_HELPER_PROPERTY = "org.eclipse.deeplearning4j.helpers.disable"      # (SD_FORBID_HELPERS)
-    HELPER_DISABLE_DEFAULT_VALUE = "false"          # the HIP helpers ARE the default path here (reference default: "true")
+    HELPER_DISABLE_DEFAULT_VALUE = "true"           # as the reference (DL4JSystemProperties.java:115): HelperUtils objects are opt-in
     NLP_UIMA_TOKENIZER_CACHE = "org.deeplearning4j.nlp.uima.tokenizer.cache"
     _ENV = {DL4J_TEMP_DIR_PROPERTY: "DL4J_TEMP_DIR", DL4J_RESOURCES_DIR_PROPERTY: "DL4J_RESOURCES_DIR",
             CRASH_DUMP_ENABLED_PROPERTY: "DL4J_CRASH_REPORTING_ENABLED", CRASH_DUMP_OUTPUT_DIRECTORY_PROPERTY: "DL4J_CRASH_REPORTING_DIR",

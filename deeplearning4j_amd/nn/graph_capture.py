@@ -18,6 +18,41 @@ from __future__ import annotations
 import torch
 
 
+class CutPlanner:
+    """Where the captured backward is cut so gradient buckets can be handed to RCCL while the rest of backward replays.
+
+    Every cut costs a graph-launch boundary (the 1-rank RCCL rehearsal measured +5 % with one cut per bucket), so at most
+    ``DL4J_AMD_DP_MAX_CUTS`` cuts are made (default 2), each releasing a GROUP of finished buckets; the head bucket (offset 0) is
+    never worth a cut — nothing is left to overlap it with, ``finish()`` launches it. One rank has nobody to overlap with: no
+    cuts at all unless ``DL4J_AMD_DP_CUTS_AT_ONE_RANK=1`` (rehearsal of the cut path itself).
+
+    ``buckets`` needs ``ranges`` and ``count_ready(min_done_offset)`` only (unit-tested on CPU with a stand-in)."""
+
+    def __init__(self, buckets, max_cuts=None, world=None):
+        import os
+        if world is None:
+            from ..parallel import comm
+            world = comm.world_size()
+        if max_cuts is None:
+            max_cuts = int(os.environ.get("DL4J_AMD_DP_MAX_CUTS", "2"))
+        if world == 1 and os.environ.get("DL4J_AMD_DP_CUTS_AT_ONE_RANK") != "1":
+            max_cuts = 0
+        self.buckets = buckets
+        self.cuttable = max(0, len(buckets.ranges) - 1)
+        self.group = max(1, -(-self.cuttable // max_cuts)) if max_cuts > 0 else self.cuttable + 1
+        self.launched = 0
+        self.cuts = 0
+
+    def release(self, min_done_offset) -> int:
+        """Number of buckets to release with a cut NOW (0: keep capturing)."""
+        nb = min(self.buckets.count_ready(min_done_offset), self.cuttable) - self.launched
+        if nb >= self.group or (nb > 0 and self.launched + nb == self.cuttable and self.group <= self.cuttable):
+            self.launched += nb
+            self.cuts += 1
+            return nb
+        return 0
+
+
 class CapturedTrainStep:
     def __init__(self, net, warmup=3):
         self.net = net
@@ -106,22 +141,22 @@ class CapturedTrainStep:
         Returns [(graph, n_buckets_ready_after_it), ...]; all graphs share one memory pool and are replayed in capture order."""
         net = self.net
         segs = []
-        state = {"g": None, "pool": torch.cuda.graph_pool_handle(), "launched": 0}
+        state = {"g": None, "pool": torch.cuda.graph_pool_handle()}
 
         def begin():
             g = torch.cuda.CUDAGraph()
             g.capture_begin(pool=state["pool"], capture_error_mode="thread_local")
             state["g"] = g
 
+        planner = CutPlanner(buckets)
+
         def progress(min_done_offset):
-            # the head bucket is never worth a cut: nothing is left to overlap it with (finish() launches it)
-            nb = min(buckets.count_ready(min_done_offset), len(buckets.ranges) - 1) - state["launched"]
+            nb = planner.release(min_done_offset)
             if nb > 0:
                 from ..ops import streams
                 streams.join()                  # side-stream wgrads belong to this segment: join before the cut
                 state["g"].capture_end()
                 segs.append((state["g"], nb))
-                state["launched"] += nb
                 begin()
 
         hook, begin_hook = net._on_backward_progress, net._on_backward_begin

@@ -82,7 +82,11 @@ class HelperUtils:
                     cls = v
         if cls is None or cls is LayerHelper:
             return None
-        if str(DL4JSystemProperties.get("org.eclipse.deeplearning4j.helpers.disable", "false")).lower() == "true":
+        # reference default is "true" (DL4JSystemProperties.java:114-115 HELPER_DISABLE_DEFAULT_VALUE, HelperUtils.java:57):
+        # the DL4J-level helper objects are opt-in there, the libnd4j platform helpers carry the acceleration. Same here:
+        # the layer implementations call the HIP kernels directly; this object API only answers when explicitly enabled.
+        if str(DL4JSystemProperties.get(DL4JSystemProperties.DISABLE_HELPER_PROPERTY,
+                                        DL4JSystemProperties.HELPER_DISABLE_DEFAULT_VALUE)).lower() == "true":
             return None
         h = cls(device, dtype)
         return h if h.checkSupported() else None

@@ -76,8 +76,6 @@ class BaseNetwork:
         dt = DataType.to_torch(conf.dataType)
         cdt = DataType.to_torch(conf.computeDataType) if getattr(conf, "computeDataType", None) else None
         dev = torch.device(device) if device is not None else default_device()
-        if cdt is not None and dev.type != "cuda":
-            cdt = None if cdt == torch.bfloat16 and False else cdt
         return LayerCtx(dt, cdt, dev, getattr(self, "_seed", 12345))
 
     def _alloc_params(self, params=None, clone=True):

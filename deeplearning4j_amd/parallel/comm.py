@@ -168,9 +168,18 @@ class CommWatchdog:
                 if exc is not None:
                     reason = "collective failed: %r" % (exc,)
                     break
-            if reason is None and self._busy and time.monotonic() - self._last > self.timeout_s:
+            # "no progress" only counts while a watched collective is still incomplete: a long first iteration (native build,
+            # graph capture, warm-up), a slow listener or an evaluation pass with nothing outstanding is not a dead peer
+            pending = 0
+            for w in works:
+                try:
+                    if not w.is_completed():
+                        pending += 1
+                except Exception:
+                    pending += 1
+            if reason is None and self._busy and pending > 0 and time.monotonic() - self._last > self.timeout_s:
                 reason = "no progress for %.0f s with %d collective(s) outstanding (a peer rank is gone or a link is down)" % (
-                    time.monotonic() - self._last, len(works))
+                    time.monotonic() - self._last, pending)
             if reason is not None:
                 self.failure = reason
                 self._fail(reason)
@@ -196,8 +205,17 @@ class GradientBuckets:
     launched as soon as every parameter at offset >= bucket_start has its gradient — the overlap
     hook calls :meth:`ready` with the lowest finished offset."""
 
-    def __init__(self, flat_grads: torch.Tensor, bucket_bytes: int = 32 << 20, head_bytes: int = 4 << 20, wire_dtype=None,
+    def __init__(self, flat_grads: torch.Tensor, bucket_bytes: Optional[int] = None, head_bytes: Optional[int] = None, wire_dtype=None,
                  watchdog: Optional["CommWatchdog"] = None):
+        # sizes are tunable without code changes (the 8-GPU node is only seen by the round-end driver): DL4J_AMD_DP_BUCKET_MB /
+        # DL4J_AMD_DP_HEAD_MB in MiB; an explicit argument wins
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get("DL4J_AMD_DP_BUCKET_MB", "32")) * (1 << 20))
+        if head_bytes is None:
+            head_bytes = int(float(os.environ.get("DL4J_AMD_DP_HEAD_MB", "4")) * (1 << 20))
+        self.bucket_bytes, self.head_bytes = int(bucket_bytes), int(head_bytes)
+        self.bytes_launched = 0          # wire bytes handed to collectives since construction (bench.py reports per step)
+        self.collectives = 0
         # wire_dtype=torch.bfloat16: the buckets travel as bf16 (half the xGMI bytes; every rank rounds its own gradient once,
         # RCCL sums in bf16, the average lands back in the fp32 vector) — an option, the default wire format is the vector's own
         self.wire_dtype = wire_dtype if (wire_dtype is not None and wire_dtype != flat_grads.dtype) else None
@@ -257,7 +275,12 @@ class GradientBuckets:
                     st.copy_(seg)
                 w = all_reduce_avg_(st if st is not None else seg, async_op=True)
                 if st is not None:
-                    seg.copy_(st)              # stream-ordered after the collective on the comm stream
+                    # An async collective runs on the process group's own stream, not on comm_stream: only Work.wait() orders
+                    # the CURRENT stream (comm_stream here) after it. On the stream-ordered backend wait() does not block the
+                    # host, so the copy-back is queued behind the reduce and the next bucket can still be launched at once.
+                    if w is not None:
+                        w.wait()
+                    seg.copy_(st)
         else:
             if st is not None:
                 st.copy_(seg)
@@ -267,10 +290,14 @@ class GradientBuckets:
                     w.wait()
                     w = None
                 seg.copy_(st)
+        self.bytes_launched += (e - s) * (st if st is not None else seg).element_size()
+        self.collectives += 1
         if w is not None:
             self._works.append(w)
             if self.watchdog is not None:
                 self.watchdog.watch(w)
+        if self.watchdog is not None:
+            self.watchdog.tick()
 
     def finish(self):
         self.ready(0)
@@ -278,6 +305,7 @@ class GradientBuckets:
             w.wait()
         if self.watchdog is not None:
             self.watchdog.clear()
+            self.watchdog.tick()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.begin()          # self-resetting: the next iteration starts from the tail bucket again
@@ -285,6 +313,8 @@ class GradientBuckets:
     def reduce_all(self):
         """Non-overlapped path: reduce every bucket on the current stream."""
         for s, e in self.ranges:
+            self.bytes_launched += (e - s) * (self._stage if self._stage is not None else self.flat).element_size()
+            self.collectives += 1
             if self._stage is not None:
                 st = self._stage[s:e]
                 st.copy_(self.flat[s:e])

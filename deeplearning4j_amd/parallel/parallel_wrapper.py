@@ -90,7 +90,7 @@ class ParallelWrapper:
 
     def __init__(self, model, workers=None, prefetchBuffer=2, averagingFrequency=1, reportScoreAfterAveraging=True,
                  averageUpdaters=True, trainingMode=TrainingMode.SHARED_GRADIENTS, thresholdAlgorithm=None,
-                 residualPostProcessor=None, gradientsAccumulator=None, bucketBytes=32 << 20, overlap=True,
+                 residualPostProcessor=None, gradientsAccumulator=None, bucketBytes=None, overlap=True,
                  modelParamsSupplier=None, updaterParamsSupplier=None, compatEncoding=False, wireDataType=None, watchdogTimeout=120.0):
         self.model = model
         self.averagingFrequency = max(1, int(averagingFrequency))
@@ -197,6 +197,43 @@ class ParallelWrapper:
         self.model._dp_buckets = None
 
     close = shutdown
+
+    def params_checksum(self):
+        """Bit-exact digest of the flat parameter vector: int64 wrap-around sum of the raw 32-bit words plus a position-weighted
+        sum (catches permuted values). One [2] int64 tensor per rank instead of the whole vector."""
+        p = self.model._params.detach().contiguous()
+        w = p.view(torch.int32).to(torch.int64) if p.element_size() == 4 else p.view(torch.int16).to(torch.int64)
+        idx = torch.arange(1, w.numel() + 1, device=w.device, dtype=torch.int64) & 0xFFFF
+        return torch.stack([w.sum(), (w * idx).sum()])
+
+    def checksums_in_sync(self):
+        """All-gather of :meth:`params_checksum`; True when every rank holds bit-identical parameters."""
+        d = self.params_checksum()
+        if self.world == 1:
+            return True
+        ds = comm.all_gather(d)
+        return all(bool(torch.equal(x, ds[0])) for x in ds[1:])
+
+    def comm_report(self, steps=None):
+        """What bench.py prints so an N-GPU run can be verified from its output line alone: backend, the world size an all-reduce
+        of ones actually saw, bucket layout, wire bytes per step and the parameter digest agreement."""
+        import torch.distributed as dist
+        seen = 1
+        backend = "none"
+        if dist.is_initialized():
+            backend = dist.get_backend()
+            one = torch.ones(1, device=self.model._params.device, dtype=torch.float32)
+            dist.all_reduce(one, op=dist.ReduceOp.SUM)
+            seen = int(round(float(one.item())))
+        b = self.buckets
+        rep = {"backend": "rccl" if backend == "nccl" and torch.version.hip else backend, "world_size_seen": seen,
+               "buckets": len(b.ranges), "bucket_mb": round(b.bucket_bytes / float(1 << 20), 2),
+               "head_mb": round(b.head_bytes / float(1 << 20), 2),
+               "wire_dtype": str(b.wire_dtype or self.model._grads.dtype).replace("torch.", ""),
+               "bytes_per_step": int(b.bytes_launched // steps) if steps else int(b.bytes_launched),
+               "collectives_per_step": (b.collectives // steps) if steps else b.collectives,
+               "params_in_sync": bool(self.checksums_in_sync())}
+        return rep
 
     def params_in_sync(self, atol=0.0):
         """Debug check: parameters bitwise (or atol) equal across ranks."""

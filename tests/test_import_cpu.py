@@ -544,3 +544,36 @@ def test_onnx_second_tranche_rules_execute_with_onnx_semantics():
     assert o.shape == (1, 1, 1, 1) and abs(float(o) - 10.0) < 1e-4         # samples at (1,1) (1,3) (3,1) (3,3): 5, 7, 13, 15
     (o,) = _run_onnx([ox_node("RandomUniform", [], ["y"], shape=[16, 4], low=2.0, high=3.0)], [], [], ["y"], {})
     assert o.shape == (16, 4) and float(o.min()) >= 2.0 and float(o.max()) <= 3.0
+
+
+def test_attention_fusion_leaves_causal_additive_mask_unfused():
+    """A [Tq, Tk] additive mask broadcast over batch and heads ((1 - tril) * -1e9) is not a per-batch key mask: the rewrite into
+    dot_product_attention_v2 with singleMaskIsKeyMask must not fire, while the [B, 1, 1, Tk] padding form still fuses."""
+    torch.manual_seed(5)
+    T, D = 4, 8
+    for B in (4, 3):                                   # B == Tq is the silently-wrong case, B != Tq the reshape-error case
+        sd = SameDiff.create()
+        x = sd.placeHolder("x", "FLOAT", B, 2, T, D)
+        tril = sd.constant("tril", torch.tril(torch.ones(T, T)))
+        neg = sd._op("subtract", [sd.constant("one", torch.tensor(1.0)), tril])[0].mul(-1e9)
+        att = sd.nn.softmax(x.mmul(x, transposeB=True).mul(1.0 / math.sqrt(D)).add(neg), -1).mmul(x)
+        sd.base.identity(att, name="out")
+        xv = torch.randn(B, 2, T, D)
+        before = _t(sd.output({"x": xv}, ["out"])["out"]).clone()
+        GraphOptimizer.optimize(sd, ["out"])
+        assert all(o.opName != "dot_product_attention_v2" for o in sd.ops.values())
+        assert torch.allclose(before, _t(sd.output({"x": xv}, ["out"])["out"]), atol=1e-6)
+    # the padding-mask form is still recognised
+    sd = SameDiff.create()
+    x = sd.placeHolder("x", "FLOAT", 3, 2, T, D)
+    m = sd.placeHolder("m", "FLOAT", 3, T)
+    m4 = sd._op("reshape", [m], iArgs=[3, 1, 1, T])[0]
+    neg = sd._op("subtract", [sd.constant("one", torch.tensor(1.0)), m4])[0].mul(-10000.0)
+    att = sd.nn.softmax(x.mmul(x, transposeB=True).mul(1.0 / math.sqrt(D)).add(neg), -1).mmul(x)
+    sd.base.identity(att, name="out")
+    xv, mv = torch.randn(3, 2, T, D), torch.ones(3, T)
+    mv[1, 2:] = 0
+    before = _t(sd.output({"x": xv, "m": mv}, ["out"])["out"]).clone()
+    GraphOptimizer.optimize(sd, ["out"])
+    assert any(o.opName == "dot_product_attention_v2" for o in sd.ops.values())
+    assert torch.allclose(before, _t(sd.output({"x": xv, "m": mv}, ["out"])["out"]), atol=1e-5)

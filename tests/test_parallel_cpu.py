@@ -80,6 +80,7 @@ def _worker(rank, world, port, mode, out_dir):
         net.fit(x[rank * h:(rank + 1) * h], y[rank * h:(rank + 1) * h])
         pw._maybe_average_params()
     assert pw.params_in_sync()
+    assert pw.checksums_in_sync()
     torch.save({"params": net.params().clone(), "state": net.getUpdaterState().clone()}, os.path.join(out_dir, "r%d.pt" % rank))
     comm.barrier()
     torch.distributed.destroy_process_group()
@@ -232,6 +233,8 @@ def _tail_worker(rank, world, port, n_batches, out_dir):
         pw.fit(it, 1)
         assert net.iterationCount == n_batches // world, (net.iterationCount, n_batches, world)
         assert pw.params_in_sync()
+        rep = pw.comm_report()
+        assert rep["params_in_sync"] and rep["world_size_seen"] == pw.world and rep["backend"] == "gloo"
         pw.shutdown()
     torch.save({"params": net.params().clone()}, os.path.join(out_dir, "r%d.pt" % rank))
     comm.barrier()
@@ -404,3 +407,61 @@ def test_watchdog_ends_the_surviving_rank_with_a_clean_nonzero_exit(tmp_path):
     assert (tmp_path / "alive").exists() and not (tmp_path / "unreachable").exists()
     assert procs[0].exitcode not in (0, None) and took < 90
     assert procs[0].exitcode in (CommWatchdog.EXIT_CODE, 1) or procs[0].exitcode < 0
+
+
+class _FakeBuckets:
+    """Stand-in for comm.GradientBuckets: ranges + count_ready only (what nn/graph_capture.CutPlanner reads)."""
+
+    def __init__(self, bounds):
+        self.ranges = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
+
+    def count_ready(self, min_done_offset):
+        n = 0
+        for s, _ in reversed(self.ranges):
+            if s < min_done_offset:
+                break
+            n += 1
+        return n
+
+
+def _walk(planner, offsets):
+    out = []
+    for off in offsets:
+        nb = planner.release(off)
+        if nb:
+            out.append((off, nb))
+    return out
+
+
+def test_capture_cut_planner_groups_buckets():
+    from deeplearning4j_amd.nn.graph_capture import CutPlanner
+    fb = _FakeBuckets([0, 10, 100, 200, 300, 400])          # head bucket [0,10) + 4 cuttable
+    offsets = [400, 350, 300, 250, 200, 150, 100, 50, 10, 0]  # backward progress, tail to head
+    # two cuts of two buckets each; the head bucket is never released by a cut
+    cuts = _walk(CutPlanner(fb, max_cuts=2, world=8), offsets)
+    assert cuts == [(200, 2), (10, 2)]
+    # one cut per bucket when allowed
+    cuts = _walk(CutPlanner(fb, max_cuts=8, world=8), offsets)
+    assert [nb for _, nb in cuts] == [1, 1, 1, 1]
+    # odd remainder: 3 cuttable, 2 cuts -> 2 + 1
+    fb3 = _FakeBuckets([0, 10, 100, 200, 300])
+    cuts = _walk(CutPlanner(fb3, max_cuts=2, world=2), [300, 200, 100, 10, 0])
+    assert [nb for _, nb in cuts] == [2, 1]
+    # a single rank: no cuts at all, everything is left to finish()
+    p1 = CutPlanner(fb, max_cuts=2, world=1)
+    assert _walk(p1, offsets) == [] and p1.cuts == 0
+    # released counts never exceed the cuttable buckets and never repeat
+    p = CutPlanner(fb, max_cuts=3, world=4)
+    total = sum(nb for _, nb in _walk(p, offsets + offsets))
+    assert total == 4 and p.cuts <= 3
+
+
+def test_gradient_bucket_sizes_from_env(monkeypatch):
+    from deeplearning4j_amd.parallel import comm
+    g = torch.zeros(1 << 20)
+    monkeypatch.setenv("DL4J_AMD_DP_BUCKET_MB", "1")
+    monkeypatch.setenv("DL4J_AMD_DP_HEAD_MB", "0.25")
+    b = comm.GradientBuckets(g)
+    assert b.ranges[0] == (0, 65536) and b.ranges[1] == (65536, 262144) and b.ranges[-1][1] == g.numel()
+    b2 = comm.GradientBuckets(g, bucket_bytes=2 << 20, head_bytes=1 << 30)
+    assert b2.ranges == [(0, 524288), (524288, 1048576)]
