@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
     const float* __restrict__ mscale, const float* __restrict__ mshift,
     float* __restrict__ partial, int64_t M, int C, int cpb, int rpi,
     float* __restrict__ sums, float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ gpart,
-    unsigned* __restrict__ cnt, int G) {
+    unsigned* __restrict__ cnt, int G, const uint8_t* __restrict__ bits) {
   __shared__ float red[2 * V * 256];
   const int cv = C / V;
   const int tid = threadIdx.x;
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
   if (active) {
     const int c0 = cvec * V;
     float mu[V], is[V], ms[V], mt[V];
-    const bool xmask = (MODE == 1) && (out == nullptr) && (mscale != nullptr);
+    const bool xmask = (MODE == 1) && (out == nullptr) && (bits == nullptr) && (mscale != nullptr);
     if (MODE == 1) {
       load_coef<V>(mean, c0, mu);
       load_coef<V>(invstd, c0, is);
@@ -138,7 +138,12 @@ __global__ void __launch_bounds__(256) bn_colreduce_kernel(
       } else {
         float dv[V];
         load_vec<T, V>(dy + off, dv);
-        if (out != nullptr) {
+        if (bits != nullptr) {
+          // ReLU mask saved by the forward apply as one byte per V-channel vector (1/16 of re-reading the bf16 output)
+          const unsigned mb = bits[r * cv + cvec];
+#pragma unroll
+          for (int j = 0; j < V; ++j) dv[j] = ((mb >> j) & 1u) ? dv[j] : 0.f;
+        } else if (out != nullptr) {
           float ov[V];
           load_vec<T, V>(out + off, ov);
 #pragma unroll
@@ -240,7 +245,7 @@ template <typename T, int MODE>
 static int launch_colreduce(const void* x, const void* dy, const void* out, const float* mean,
                             const float* invstd, const float* mscale, const float* mshift, float* partial, float* sums,
                             float* out0, float* out1, int64_t M, int C, hipStream_t st, float* gpart = nullptr,
-                            unsigned* cnt = nullptr) {
+                            unsigned* cnt = nullptr, const uint8_t* bits = nullptr) {
   constexpr int VFULL = VecOf<T>::N;
   const bool vec_ok = (C % VFULL) == 0;
   const int V = vec_ok ? VFULL : 1;
@@ -260,7 +265,7 @@ static int launch_colreduce(const void* x, const void* dy, const void* out, cons
   unsigned* c = fused ? cnt : nullptr;
 #define COLREDUCE_LAUNCH(VV, FF)                                                                                             \
   hipLaunchKernelGGL((bn_colreduce_kernel<T, VV, MODE, FF>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, (const T*)out, mean, \
-                     invstd, mscale, mshift, partial, M, C, cpb, rpi, sums, out0, out1, gpart, c, G)
+                     invstd, mscale, mshift, partial, M, C, cpb, rpi, sums, out0, out1, gpart, c, G, bits)
   // the hand-off code is a template parameter: carried in the plain kernel it costs registers the bandwidth-bound loop wants
   if (vec_ok) { if (fused) COLREDUCE_LAUNCH(VFULL, true); else COLREDUCE_LAUNCH(VFULL, false); }
   else { if (fused) COLREDUCE_LAUNCH(1, true); else COLREDUCE_LAUNCH(1, false); }
@@ -406,7 +411,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ shift, const T* __restrict__ res,
                                                        const float* __restrict__ rscale,
                                                        const float* __restrict__ rshift, T* __restrict__ y,
-                                                       int64_t nvec, int cv, int relu) {
+                                                       int64_t nvec, int cv, int relu, uint8_t* __restrict__ mbits) {
   const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float sc[V], sh[V], rs[V], rt[V];
@@ -434,6 +439,13 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
       for (int j = 0; j < V; ++j) xv[j] += rv[j] * rs[j] + rt[j];
     }
     if (relu) {
+      if (mbits != nullptr) {
+        // one mask byte per vector for the backward pass (bit j: channel j of the vector passed the ReLU)
+        unsigned mb = 0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) mb |= (xv[j] > 0.f ? 1u : 0u) << j;
+        mbits[i] = (uint8_t)mb;
+      }
 #pragma unroll
       for (int j = 0; j < V; ++j) xv[j] = fmaxf(xv[j], 0.f);
     }
@@ -443,7 +455,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
 
 template <typename T>
 static int launch_apply(const void* x, const float* scale, const float* shift, const void* res, const float* rscale,
-                        const float* rshift, void* y, int64_t M, int C, int relu, hipStream_t st) {
+                        const float* rshift, void* y, int64_t M, int C, int relu, hipStream_t st, uint8_t* mbits = nullptr) {
   constexpr int VFULL = VecOf<T>::N;
   if (C % VFULL == 0) {
     const int64_t nvec = M * C / VFULL;
@@ -451,14 +463,14 @@ static int launch_apply(const void* x, const float* scale, const float* shift, c
     const int g = hoist_grid(nvec, C / VFULL, &hoist);
     if (hoist)
       hipLaunchKernelGGL((bn_apply_kernel<T, VFULL, true>), dim3(g), dim3(256), 0, st, (const T*)x, scale, shift,
-                         (const T*)res, rscale, rshift, (T*)y, nvec, C / VFULL, relu);
+                         (const T*)res, rscale, rshift, (T*)y, nvec, C / VFULL, relu, mbits);
     else
       hipLaunchKernelGGL((bn_apply_kernel<T, VFULL, false>), dim3(g), dim3(256), 0, st, (const T*)x, scale, shift,
-                         (const T*)res, rscale, rshift, (T*)y, nvec, C / VFULL, relu);
+                         (const T*)res, rscale, rshift, (T*)y, nvec, C / VFULL, relu, mbits);
   } else {
     const int64_t nvec = M * C;
     hipLaunchKernelGGL((bn_apply_kernel<T, 1, false>), dim3(launch_grid(LS_BATCHNORM, grid_for(nvec, 256))), dim3(256), 0, st, (const T*)x, scale,
-                       shift, (const T*)res, rscale, rshift, (T*)y, nvec, C, relu);
+                       shift, (const T*)res, rscale, rshift, (T*)y, nvec, C, relu, mbits);
   }
   DL4J_RET_LAST();
 }
@@ -477,11 +489,11 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
                                                         const float* __restrict__ mscale,
                                                         const float* __restrict__ mshift, T* __restrict__ dx,
                                                         T* __restrict__ dz_out, int64_t nvec, int cv, int C,
-                                                        float invM) {
+                                                        float invM, const uint8_t* __restrict__ bits) {
   const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   float A[V], B[V], K[V], ms[V], mt[V];
-  const bool xmask = (out == nullptr) && (mscale != nullptr);
+  const bool xmask = (out == nullptr) && (bits == nullptr) && (mscale != nullptr);
   auto coeffs = [&](int c0) {
     float is[V], g[V], s0[V], s1[V], mu[V];
     load_coef<V>(invstd, c0, is);
@@ -503,7 +515,11 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
     float xv[V], dv[V];
     load_vec<T, V>(x + i * V, xv);
     load_vec<T, V>(dy + i * V, dv);
-    if (out != nullptr) {
+    if (bits != nullptr) {
+      const unsigned mb = bits[i];
+#pragma unroll
+      for (int j = 0; j < V; ++j) dv[j] = ((mb >> j) & 1u) ? dv[j] : 0.f;
+    } else if (out != nullptr) {
       float ov[V];
       load_vec<T, V>(out + i * V, ov);
 #pragma unroll
@@ -523,7 +539,7 @@ __global__ void __launch_bounds__(256) bn_bwd_dx_kernel(const T* __restrict__ x,
 template <typename T>
 static int launch_bwd_dx(const void* x, const void* dy, const void* out, const float* mean, const float* invstd,
                          const float* gamma, const float* sums, const float* mscale, const float* mshift, void* dx,
-                         void* dz, int64_t M, int C, hipStream_t st) {
+                         void* dz, int64_t M, int C, hipStream_t st, const uint8_t* bits = nullptr) {
   constexpr int VFULL = VecOf<T>::N;
   const float invM = 1.f / (float)M;
   if (C % VFULL == 0) {
@@ -532,14 +548,14 @@ static int launch_bwd_dx(const void* x, const void* dy, const void* out, const f
     const int g = hoist_grid(nvec, C / VFULL, &hoist);
     if (hoist)
       hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VFULL, true>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)dy,
-                         (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM);
+                         (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM, bits);
     else
       hipLaunchKernelGGL((bn_bwd_dx_kernel<T, VFULL, false>), dim3(g), dim3(256), 0, st, (const T*)x, (const T*)dy,
-                         (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM);
+                         (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C / VFULL, C, invM, bits);
   } else {
     const int64_t nvec = M * C;
     hipLaunchKernelGGL((bn_bwd_dx_kernel<T, 1, false>), dim3(launch_grid(LS_BATCHNORM, grid_for(nvec, 256))), dim3(256), 0, st, (const T*)x,
-                       (const T*)dy, (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C, C, invM);
+                       (const T*)dy, (const T*)out, mean, invstd, gamma, sums, mscale, mshift, (T*)dx, (T*)dz, nvec, C, C, invM, bits);
   }
   DL4J_RET_LAST();
 }
@@ -642,4 +658,42 @@ DL4J_API int dl4j_bn_bwd_dx(const void* x, const void* dy, const void* out, cons
   if (dtype == 1) return launch_bwd_dx<bf16_t>(x, dy, out, mean, invstd, gamma, sums, mscale, mshift, dx, dz, M, C, st);
   if (dtype == 2) return launch_bwd_dx<f16_t>(x, dy, out, mean, invstd, gamma, sums, mscale, mshift, dx, dz, M, C, st);
   return launch_bwd_dx<float>(x, dy, out, mean, invstd, gamma, sums, mscale, mshift, dx, dz, M, C, st);
+}
+
+// ---- ReLU mask as bits: one byte per V-channel vector (V = 8 for bf16 / fp16, 4 for fp32, 1 when C is not a multiple of that),
+// written by the forward apply and read by both backward passes instead of the stored activation: 1/16 of the bytes for bf16.
+DL4J_API int dl4j_bn_mask_vec(int C, int dtype) {
+  const int v = dtype == 0 ? 4 : 8;
+  return (C % v == 0) ? v : 1;
+}
+
+DL4J_API int dl4j_bn_apply_mask(const void* x, const float* scale, const float* shift, const void* res,
+                                const float* rscale, const float* rshift, void* y, void* mask_bits, int64_t M, int C, int relu,
+                                int dtype, hipStream_t st) {
+  if (dtype == 1) return launch_apply<bf16_t>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st, (uint8_t*)mask_bits);
+  if (dtype == 2) return launch_apply<f16_t>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st, (uint8_t*)mask_bits);
+  return launch_apply<float>(x, scale, shift, res, rscale, rshift, y, M, C, relu, st, (uint8_t*)mask_bits);
+}
+
+DL4J_API int dl4j_bn_bwd_reduce_mask(const void* x, const void* dy, const void* mask_bits, const float* mean,
+                                     const float* invstd, float* partial_ws, float* sums, float* dbeta_out, float* dgamma_out,
+                                     int64_t M, int C, int dtype, hipStream_t st) {
+  const uint8_t* b = (const uint8_t*)mask_bits;
+  if (dtype == 1)
+    return launch_colreduce<bf16_t, 1>(x, dy, nullptr, mean, invstd, nullptr, nullptr, partial_ws, sums, dbeta_out, dgamma_out, M, C, st,
+                                       nullptr, nullptr, b);
+  if (dtype == 2)
+    return launch_colreduce<f16_t, 1>(x, dy, nullptr, mean, invstd, nullptr, nullptr, partial_ws, sums, dbeta_out, dgamma_out, M, C, st,
+                                      nullptr, nullptr, b);
+  return launch_colreduce<float, 1>(x, dy, nullptr, mean, invstd, nullptr, nullptr, partial_ws, sums, dbeta_out, dgamma_out, M, C, st,
+                                    nullptr, nullptr, b);
+}
+
+DL4J_API int dl4j_bn_bwd_dx_mask(const void* x, const void* dy, const void* mask_bits, const float* mean, const float* invstd,
+                                 const float* gamma, const float* sums, void* dx, void* dz, int64_t M, int C, int dtype,
+                                 hipStream_t st) {
+  const uint8_t* b = (const uint8_t*)mask_bits;
+  if (dtype == 1) return launch_bwd_dx<bf16_t>(x, dy, nullptr, mean, invstd, gamma, sums, nullptr, nullptr, dx, dz, M, C, st, b);
+  if (dtype == 2) return launch_bwd_dx<f16_t>(x, dy, nullptr, mean, invstd, gamma, sums, nullptr, nullptr, dx, dz, M, C, st, b);
+  return launch_bwd_dx<float>(x, dy, nullptr, mean, invstd, gamma, sums, nullptr, nullptr, dx, dz, M, C, st, b);
 }

@@ -350,12 +350,18 @@ class BatchNormalizationImpl(LayerImpl):
         # ReLU only comes from the graph fusion planner
         fuse_relu = relu
         rs, rt = res_coeffs if res_coeffs is not None else (None, None)
-        y2 = BN.apply(x2, scale, shift, r2, rs, rt, fuse_relu)
+        bits = None
+        if train and fuse_relu and residual is not None and BN.mask_supported(x2):
+            y2, bits = BN.apply(x2, scale, shift, r2, rs, rt, fuse_relu, want_mask=True)
+        else:
+            y2 = BN.apply(x2, scale, shift, r2, rs, rt, fuse_relu)
         if train:
             self._x2, self._shp = x2, shp
             # without a residual the ReLU mask is recomputable from x (x*scale+shift > 0): the backward kernels then skip
-            # re-reading the output tensor; with a residual the mask needs the stored output
-            self._out2 = y2 if (fuse_relu and residual is not None) else None
+            # re-reading the output tensor; with a residual the mask is kept as bits (1/16 of the bf16 output) or, on the
+            # library / CPU path, read back from the stored output
+            self._mask_bits = bits
+            self._out2 = y2 if (fuse_relu and residual is not None and bits is None) else None
             self._mask_coeffs = (scale, shift) if (fuse_relu and residual is None) else None
             self._want_dz = residual is not None
         self._z2 = None
@@ -371,7 +377,8 @@ class BatchNormalizationImpl(LayerImpl):
         dg = self.grads["gamma"].reshape(-1) if "gamma" in self.grads else None
         db = self.grads["beta"].reshape(-1) if "beta" in self.grads else None
         dx2, dz2 = BN.backward(self._x2, d2, self._out2, self._mean, self._invstd, gamma, dg, db,
-                               want_dz=return_dz or self._want_dz, mask_coeffs=getattr(self, "_mask_coeffs", None))
+                               want_dz=return_dz or self._want_dz, mask_coeffs=getattr(self, "_mask_coeffs", None),
+                               mask_bits=getattr(self, "_mask_bits", None))
         dx = self._from2d(dx2, self._shp)
         if return_dz or self._want_dz:
             return dx, self._from2d(dz2, self._shp)
@@ -379,7 +386,7 @@ class BatchNormalizationImpl(LayerImpl):
 
     def clear(self):
         super().clear()
-        self._x2 = self._out2 = self._z2 = self._mask_coeffs = None
+        self._x2 = self._out2 = self._z2 = self._mask_coeffs = self._mask_bits = None
 
 
 # ------------------------------------------------------------------ convolution

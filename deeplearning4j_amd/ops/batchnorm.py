@@ -121,15 +121,32 @@ def infer_coeffs(gamma, beta, gmean, gvar, eps, log_std, conv_bias=None):
     return scale, b - m * scale
 
 
-def apply(x2d, scale, shift, residual=None, rscale=None, rshift=None, relu=False):
-    """y = act(x*scale + shift [+ residual(*rscale + rshift)])."""
+# ReLU mask of a residual block output as BITS (one byte per 8-channel vector) instead of the stored activation: both backward
+# passes then read 1/16 of the bytes (the activation tensor itself stays alive as the next block's input, but is not re-read).
+# DL4J_AMD_BN_BITMASK=0 restores the stored-output form.
+_BITMASK = __import__("os").environ.get("DL4J_AMD_BN_BITMASK", "1") == "1"
+
+
+def mask_supported(x2d):
+    return _BITMASK and _hip_ok(x2d)
+
+
+def apply(x2d, scale, shift, residual=None, rscale=None, rshift=None, relu=False, want_mask=False):
+    """y = act(x*scale + shift [+ residual(*rscale + rshift)]). With ``want_mask`` (HIP path, relu) returns (y, mask_bits)."""
     M, C = x2d.shape
     if _hip_ok(x2d):
         y = torch.empty_like(x2d)
+        if want_mask and relu and _BITMASK:
+            v = int(L.hip().dl4j_bn_mask_vec(L.c_int(C), L.c_int(L.dtype_code(x2d))))
+            bits = torch.empty((M * C) // v, device=x2d.device, dtype=torch.uint8)
+            L.check(L.hip().dl4j_bn_apply_mask(L.ptr(x2d), L.ptr(scale), L.ptr(shift), L.ptr(residual), L.ptr(rscale),
+                                               L.ptr(rshift), L.ptr(y), L.ptr(bits), L.c_int64(M), L.c_int(C), L.c_int(1),
+                                               L.c_int(L.dtype_code(x2d)), L.stream()), "bn_apply_mask")
+            return y, bits
         L.check(L.hip().dl4j_bn_apply(L.ptr(x2d), L.ptr(scale), L.ptr(shift), L.ptr(residual), L.ptr(rscale),
                                       L.ptr(rshift), L.ptr(y), L.c_int64(M), L.c_int(C), L.c_int(1 if relu else 0),
                                       L.c_int(L.dtype_code(x2d)), L.stream()), "bn_apply")
-        return y
+        return (y, None) if want_mask else y
     cd = torch.float32 if x2d.dtype in (torch.bfloat16, torch.float16) else x2d.dtype
     y = x2d.to(cd) * scale.to(cd) + shift.to(cd)
     if residual is not None:
@@ -139,7 +156,7 @@ def apply(x2d, scale, shift, residual=None, rscale=None, rshift=None, relu=False
         y = y + r
     if relu:
         y = torch.relu(y)
-    return y.to(x2d.dtype)
+    return (y.to(x2d.dtype), None) if want_mask else y.to(x2d.dtype)
 
 
 def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std=False, conv_bias=None,
@@ -192,7 +209,7 @@ def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std
     return mean, invstd, scale, shift
 
 
-def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_dz=False, mask_coeffs=None):
+def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_dz=False, mask_coeffs=None, mask_bits=None):
     """BatchNorm backward. ``out2d`` (optional) is the fused ReLU output used as mask; alternatively ``mask_coeffs`` =
     (scale, shift) lets the kernels recompute the mask as [x*scale + shift > 0] (valid when no residual was added), which
     saves re-reading the activation tensor in both backward passes.
@@ -201,6 +218,8 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
     dgamma/dbeta are written into the given fp32 gradient views (may be None for lockGammaBeta).
     """
     M, C = x2d.shape
+    if mask_bits is not None and not (_hip_ok(x2d) and dy2d.is_contiguous()):
+        raise ValueError("mask_bits is a HIP-path artefact: contiguous device tensors required")
     if _hip_ok(x2d) and dy2d.is_contiguous() and (out2d is None or out2d.is_contiguous()):
         h = L.hip()
         sums = torch.empty(2 * C, device=x2d.device, dtype=torch.float32)
@@ -210,7 +229,11 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
                  (dgamma_out is None or (dgamma_out.is_contiguous() and dgamma_out.dtype == torch.float32))
         ms, mt = mask_coeffs if (mask_coeffs is not None and out2d is None) else (None, None)
         tk = ticket_ws(x2d.device) if (_FUSE_STAGE2 and 128 * C <= TICKET_GPART) else None
-        if tk is not None:
+        if mask_bits is not None:
+            L.check(h.dl4j_bn_bwd_reduce_mask(L.ptr(x2d), L.ptr(dy2d), L.ptr(mask_bits), L.ptr(mean), L.ptr(invstd), L.ptr(ws),
+                                              L.ptr(sums), L.ptr(dbeta_out if direct else None), L.ptr(dgamma_out if direct else None),
+                                              L.c_int64(M), L.c_int(C), dt, L.stream()), "bn_bwd_reduce_mask")
+        elif tk is not None:
             L.check(h.dl4j_bn_bwd_reduce_fused(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(ms), L.ptr(mt),
                                                L.ptr(ws), L.ptr(sums), L.ptr(dbeta_out if direct else None),
                                                L.ptr(dgamma_out if direct else None), L.c_int64(M), L.c_int(C), dt, L.ptr(tk[1]),
@@ -222,10 +245,15 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
                     "bn_bwd_reduce")
         dx = torch.empty_like(x2d)
         dz = torch.empty_like(x2d) if want_dz else None
-        L.check(h.dl4j_bn_bwd_dx(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
-                                 L.ptr(sums), L.ptr(ms), L.ptr(mt), L.ptr(dx), L.ptr(dz), L.c_int64(M), L.c_int(C), dt,
-                                 L.stream()),
-                "bn_bwd_dx")
+        if mask_bits is not None:
+            L.check(h.dl4j_bn_bwd_dx_mask(L.ptr(x2d), L.ptr(dy2d), L.ptr(mask_bits), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                          L.ptr(sums), L.ptr(dx), L.ptr(dz), L.c_int64(M), L.c_int(C), dt, L.stream()),
+                    "bn_bwd_dx_mask")
+        else:
+            L.check(h.dl4j_bn_bwd_dx(L.ptr(x2d), L.ptr(dy2d), L.ptr(out2d), L.ptr(mean), L.ptr(invstd), L.ptr(gamma),
+                                     L.ptr(sums), L.ptr(ms), L.ptr(mt), L.ptr(dx), L.ptr(dz), L.c_int64(M), L.c_int(C), dt,
+                                     L.stream()),
+                    "bn_bwd_dx")
         if not direct:
             if dbeta_out is not None:
                 dbeta_out.copy_(sums[:C])

@@ -63,6 +63,12 @@ def test_batchnorm_forward_backward(dtype, M, C):
     dxb, dzb = BN.backward(x, dy, None, mean, invstd, gamma, dg2, db2, want_dz=True, mask_coeffs=(scale, shift))
     assert torch.equal(dxa, dxb) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
     assert torch.equal(dzb, torch.where(y1 > 0, dy, torch.zeros_like(dy)))
+    # ReLU mask of a residual block kept as bits (one byte per channel vector): identical results to the stored-output mask
+    ym, bits = BN.apply(x, scale, shift, res, None, None, True, want_mask=True)
+    assert bits is not None and bits.dtype == torch.uint8 and torch.equal(ym, y)
+    dg3, db3 = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    dxm, dzm = BN.backward(x, dy, None, mean, invstd, gamma, dg3, db3, want_dz=True, mask_bits=bits)
+    assert torch.equal(dxm, dx) and torch.equal(dzm, dz) and torch.equal(dg3, dg) and torch.equal(db3, db)
 
 
 @pytest.mark.parametrize("kind", ["NoOp", "Sgd", "Nesterovs", "Adam", "RmsProp", "AdaGrad", "AdaDelta", "AdaMax", "Nadam",
@@ -190,10 +196,13 @@ def test_lenet_bf16_graph_capture_trains():
     assert net.getIterationCount() == 61
 
 
-def test_segmented_graph_capture_matches_eager():
+def test_segmented_graph_capture_matches_eager(monkeypatch):
     """DP overlap path: forward+backward captured as a chain of graphs cut at gradient-bucket boundaries
     (world size 1, so the bucket launches are no-ops) must produce the gradients of the eager step, replay after replay."""
     from tests.test_networks_cpu import _onehot
+    # one rank normally gets no cuts (nothing to overlap with): rehearse the cut path itself, two groups of buckets
+    monkeypatch.setenv("DL4J_AMD_DP_CUTS_AT_ONE_RANK", "1")
+    monkeypatch.setenv("DL4J_AMD_DP_MAX_CUTS", "2")
     from deeplearning4j_amd.models.resnet50 import ResNet50
     from deeplearning4j_amd.parallel.comm import GradientBuckets
     from deeplearning4j_amd.nd4j.learning import Sgd
@@ -225,7 +234,8 @@ def test_segmented_graph_capture_matches_eager():
             assert rel < 2e-2, (it, float(rel))
             assert abs(float(b._score) - s_ref) < 1e-2 * abs(s_ref)
     segs = b._graph_step.segments
-    assert len(segs) >= 3, "capture was not segmented"
+    assert len(segs) == 3, "capture was not cut into two bucket groups + the remainder"
+    assert sum(nb for _, nb in segs) == len(buckets.ranges) - 1
     # every bucket launched exactly once per replayed iteration, tail first
     per_iter = launched[-len(buckets.ranges):]
     assert per_iter == list(range(len(buckets.ranges) - 1, -1, -1))
