@@ -40,6 +40,18 @@ struct IGemmP {
                       // halves the LDS footprint so twice as many workgroups are resident to hide the load latency
   int accum;          // 1: y += result (in-place gradient accumulation at graph fan-out points, saves a separate add pass)
   ticket::BnFin fin;  // fin.cnt != null: the last workgroup of every N tile reduces the statistics and runs the BatchNorm finalize
+  // EPI == 1 (data-gradient launches): the output tile is the gradient flowing INTO a BatchNorm(+ReLU) whose input was `bnb_y`.
+  // The epilogue (a) optionally adds another gradient for the same tensor, masked by the ReLU bits of the block it came through
+  // (identity shortcut: dz = d_out * [out > 0] is never materialised), and (b) emits the per-tile partial sums of the BatchNorm
+  // backward reductions (sum dz, sum dz * xhat), so the separate column-reduction pass over dy and x disappears.
+  const bf16_t* acc_src;     // gradient to add (same physical layout as y), or null
+  const uint8_t* acc_bits;   // one byte per 8 channels: bit j set = element passes; null = plain add
+  const bf16_t* bnb_y;       // BatchNorm input (raw producer output), same layout as y; null = no partial sums
+  const float* bnb_mean; const float* bnb_invstd;
+  const float* bnb_ms; const float* bnb_mt;   // ReLU mask recomputed as [y*ms + mt > 0] (BatchNorm+ReLU without residual), or null
+  const uint8_t* bnb_bits;   // ReLU mask bits saved by the forward apply (residual blocks), or null
+  float* bnb_partial;        // [mtiles][2][K]
+  int bnb_mode;              // 0: no mask, 1: bnb_bits, 2: bnb_ms / bnb_mt (set by the host entry point)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -47,7 +59,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
 }
 
-template <int BM, int BN, bool FIN>
+template <int BM, int BN, bool FIN, int EPI = 0>
 __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA blocks per wave in M / N
   constexpr int AI = BM / 32, BI = BN / 32;   // 16-byte loads per thread per tile for A / B
@@ -205,6 +217,81 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
     if (tid == 0) tk = ticket::take(f.cnt + p.ntiles + nt * ngroups + g);
   }
   constexpr int CPR = BN / 8;
+  if constexpr (EPI == 1) {
+    // thread -> fixed 8-channel chunk `ch`, rows r0, r0 + RPP, ...: per-channel partial sums stay in registers over the rows
+    constexpr int RPP = 256 / CPR;
+    const int ch = tid % CPR, r0 = tid / CPR;
+    const int cbase = n0 + ch * 8;
+    const bool want = p.bnb_partial != nullptr;
+    // coefficient pointers are always valid when `want` (the host substitutes the mean pointer for absent mask coefficients and
+    // says which mask form applies in bnb_mode): unconditional 16-byte loads, everything stays in registers
+    const int mode = p.bnb_mode;             // 0: no mask, 1: saved bits, 2: recompute [y*ms + mt > 0]
+    f32x4 mu0, mu1, is0, is1, ms0, ms1, mt0, mt1;
+    mu0 = mu1 = is0 = is1 = ms0 = ms1 = mt0 = mt1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (want) {
+      mu0 = *reinterpret_cast<const f32x4*>(p.bnb_mean + cbase);   mu1 = *reinterpret_cast<const f32x4*>(p.bnb_mean + cbase + 4);
+      is0 = *reinterpret_cast<const f32x4*>(p.bnb_invstd + cbase); is1 = *reinterpret_cast<const f32x4*>(p.bnb_invstd + cbase + 4);
+      ms0 = *reinterpret_cast<const f32x4*>(p.bnb_ms + cbase);     ms1 = *reinterpret_cast<const f32x4*>(p.bnb_ms + cbase + 4);
+      mt0 = *reinterpret_cast<const f32x4*>(p.bnb_mt + cbase);     mt1 = *reinterpret_cast<const f32x4*>(p.bnb_mt + cbase + 4);
+    }
+    f32x4 s0a = {0.f, 0.f, 0.f, 0.f}, s0b = s0a, s1a = s0a, s1b = s0a;      // sum dz / sum dz*xhat for channels 0-3 / 4-7
+    for (int row = r0; row < BM; row += RPP) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      const int n = m / OHW, rem = m - n * OHW;
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      const int64_t o = (((int64_t)n * p.OHs + oh * p.oys) * p.OWs + ow * p.oxs) * p.K + cbase;
+      s16x8 v = *reinterpret_cast<const s16x8*>(sC + row * PITCH_C + ch * 16);
+      if (p.acc_src != nullptr) {
+        const s16x8 prev = *reinterpret_cast<const s16x8*>(p.acc_src + o);
+        const unsigned ab = p.acc_bits != nullptr ? (unsigned)p.acc_bits[o >> 3] : 0xFFu;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)v[j]) + (((ab >> j) & 1u) ? bf2f((bf16_t)prev[j]) : 0.f));
+      } else if (p.accum) {
+        const s16x8 prev = *reinterpret_cast<const s16x8*>(p.y + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)v[j]) + bf2f((bf16_t)prev[j]));
+      }
+      *reinterpret_cast<s16x8*>(p.y + o) = v;
+      if (want) {
+        const s16x8 yv = *reinterpret_cast<const s16x8*>(p.bnb_y + o);
+        unsigned mb = 0xFFu;
+        if (mode == 1) mb = p.bnb_bits[o >> 3];
+#define BNB_LANE(J, MU, IS, MS, MT, S0, S1, E)                                  \
+        {                                                                      \
+          const float yf = bf2f((bf16_t)yv[J]);                                \
+          bool pass = (mb >> J) & 1u;                                          \
+          if (mode == 2) pass = (yf * MS[E] + MT[E]) > 0.f;                    \
+          const float dzv = pass ? bf2f((bf16_t)v[J]) : 0.f;                   \
+          S0[E] += dzv;                                                        \
+          S1[E] += dzv * (yf - MU[E]) * IS[E];                                 \
+        }
+        BNB_LANE(0, mu0, is0, ms0, mt0, s0a, s1a, 0) BNB_LANE(1, mu0, is0, ms0, mt0, s0a, s1a, 1)
+        BNB_LANE(2, mu0, is0, ms0, mt0, s0a, s1a, 2) BNB_LANE(3, mu0, is0, ms0, mt0, s0a, s1a, 3)
+        BNB_LANE(4, mu1, is1, ms1, mt1, s0b, s1b, 0) BNB_LANE(5, mu1, is1, ms1, mt1, s0b, s1b, 1)
+        BNB_LANE(6, mu1, is1, ms1, mt1, s0b, s1b, 2) BNB_LANE(7, mu1, is1, ms1, mt1, s0b, s1b, 3)
+#undef BNB_LANE
+      }
+    }
+    if (!want) return;
+    __syncthreads();                         // every thread is done reading the staged C tile: the buffer is reused below
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[j * 256 + tid] = s0a[j]; red[(4 + j) * 256 + tid] = s0b[j];
+      red[(8 + j) * 256 + tid] = s1a[j]; red[(12 + j) * 256 + tid] = s1b[j];
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int qs = tid / BN, col = tid - qs * BN;
+      const int chx = col >> 3, j = col & 7;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < RPP; ++r) acc += red[(qs * 8 + j) * 256 + r * CPR + chx];
+      p.bnb_partial[((int64_t)mt * 2 + qs) * p.K + n0 + col] = acc;
+    }
+    return;
+  }
   for (int idx = tid; idx < BM * CPR; idx += 256) {
     const int row = idx / CPR, ch = idx - row * CPR;
     const int m = m0 + row;
@@ -255,6 +342,14 @@ static int launch_fwd(IGemmP& p, hipStream_t st) {
     hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, true>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
     DL4J_RET_LAST();
   }
+  if (p.acc_src != nullptr || p.bnb_partial != nullptr) {
+    static DeviceOnceLds lds_attr_epi;
+    const int want1 = want > 16384 ? want : 16384;        // the partial-sum reduction needs 2 x 8 x 256 floats
+    if (smem < 16384) smem = 16384;
+    lds_attr_epi.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, false, 1>), want1);
+    hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, false, 1>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+    DL4J_RET_LAST();
+  }
   lds_attr.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, false>), want);
   hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, false>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
   DL4J_RET_LAST();
@@ -280,6 +375,8 @@ DL4J_API int dl4j_igemm_conv_fin(const void* x, const void* w, void* y, const fl
   IGemmP p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.bias = bias; p.stats = stats; p.accum = accum;
   p.fin = ticket::BnFin{};
+  p.acc_src = nullptr; p.acc_bits = nullptr; p.bnb_y = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_ms = p.bnb_mt = nullptr;
+  p.bnb_bits = nullptr; p.bnb_partial = nullptr; p.bnb_mode = 0;
   p.N = g[0]; p.H = g[1]; p.W = g[2]; p.C = g[3]; p.OH = g[4]; p.OW = g[5]; p.K = g[6]; p.R = g[7]; p.S = g[8];
   p.sh = g[9]; p.sw = g[10]; p.ph = g[11]; p.pw = g[12]; p.dh = g[13]; p.dw = g[14];
   p.OHs = g[15]; p.OWs = g[16]; p.oys = g[17]; p.oxs = g[18];
@@ -300,6 +397,36 @@ DL4J_API int dl4j_igemm_conv_fin(const void* x, const void* w, void* y, const fl
   else rc = launch_fwd<64, 64>(p, st);
   if (mtiles_out) *mtiles_out = p.mtiles;
   return rc;
+}
+
+// Data-gradient launch with the fused epilogue described at IGemmP (EPI == 1). ptrs = [acc_src, acc_bits, bnb_y, bnb_mean,
+// bnb_invstd, bnb_ms, bnb_mt, bnb_bits, bnb_partial] (any may be null; bnb_partial needs bnb_y / mean / invstd).
+// geom as dl4j_igemm_conv. bnb_partial holds dl4j_igemm_mtiles(M, tile) * 2 * K floats.
+DL4J_API int dl4j_igemm_dgrad_bn(const void* x, const void* w, void* y, const int* g, int tile, int accum, void* const* ptrs,
+                                 hipStream_t st) {
+  IGemmP p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y; p.bias = nullptr; p.stats = nullptr; p.accum = accum;
+  p.fin = ticket::BnFin{};
+  p.acc_src = (const bf16_t*)ptrs[0]; p.acc_bits = (const uint8_t*)ptrs[1]; p.bnb_y = (const bf16_t*)ptrs[2];
+  p.bnb_mean = (const float*)ptrs[3]; p.bnb_invstd = (const float*)ptrs[4]; p.bnb_ms = (const float*)ptrs[5];
+  p.bnb_mt = (const float*)ptrs[6]; p.bnb_bits = (const uint8_t*)ptrs[7]; p.bnb_partial = (float*)ptrs[8];
+  if (p.bnb_partial != nullptr && (p.bnb_y == nullptr || p.bnb_mean == nullptr || p.bnb_invstd == nullptr)) return -2;
+  if ((p.bnb_ms == nullptr) != (p.bnb_mt == nullptr)) return -2;
+  if (p.acc_src == nullptr && p.bnb_partial == nullptr) return -2;
+  p.bnb_mode = p.bnb_ms != nullptr ? 2 : (p.bnb_bits != nullptr ? 1 : 0);
+  if (p.bnb_ms == nullptr) { p.bnb_ms = p.bnb_mean; p.bnb_mt = p.bnb_mean; }     // always loadable (values unused in modes 0 / 1)
+  // 16-byte loads of the per-channel coefficients, 16-byte accesses of the tensors
+  for (const void* q : {(const void*)p.bnb_mean, (const void*)p.bnb_invstd, (const void*)p.bnb_ms, (const void*)p.bnb_mt,
+                        (const void*)p.acc_src, (const void*)p.bnb_y, (const void*)y})
+    if ((reinterpret_cast<uintptr_t>(q) & 15) != 0) return -2;
+  p.N = g[0]; p.H = g[1]; p.W = g[2]; p.C = g[3]; p.OH = g[4]; p.OW = g[5]; p.K = g[6]; p.R = g[7]; p.S = g[8];
+  p.sh = g[9]; p.sw = g[10]; p.ph = g[11]; p.pw = g[12]; p.dh = g[13]; p.dw = g[14];
+  p.OHs = g[15]; p.OWs = g[16]; p.oys = g[17]; p.oxs = g[18];
+  p.M = p.N * p.OH * p.OW;
+  if (p.C % 64 != 0 || p.K % 64 != 0) return -2;
+  if (tile == 0) { if (p.K % 128) return -2; return launch_fwd<128, 128>(p, st); }
+  if (tile == 1) return launch_fwd<128, 64>(p, st);
+  return launch_fwd<64, 64>(p, st);
 }
 
 // number of M tiles for a tile id (so the caller can size the stats workspace before launching)

@@ -16,6 +16,7 @@ reference issues.
 from __future__ import annotations
 
 import copy
+import os
 import time
 from collections import OrderedDict
 from typing import Dict, List, Optional
@@ -31,6 +32,7 @@ from ..layers import registry
 from ..layers.core import BatchNormalizationImpl, ConvolutionLayerImpl, ActivationLayerImpl
 from ..layers.recurrent import LSTMImpl, SimpleRnnImpl
 from ..network_base import BaseNetwork
+from ...ops.conv_igemm import MaskedGrad
 from .vertices import create_vertex, VertexImpl, ElementWiseVertexImpl, LastTimeStepVertexImpl, \
     DuplicateToTimeSeriesVertexImpl, ReverseTimeSeriesVertexImpl
 
@@ -91,9 +93,15 @@ class _FusedBNNode(_Node):
     def backward(self, eps, mb):
         if not self.has_res:
             return [self.bn.backward(eps)]
-        dxa, dz = self.bn.backward(eps, return_dz=True)
+        # dz = eps * [out > 0] is not written when the mask exists as bits: the identity shortcut receives a MaskedGrad
+        # (consumed by the epilogue of the data-gradient launch that accumulates into it), a shortcut BatchNorm reads eps
+        # through the bits
+        dxa, dz = self.bn.backward(eps, return_dz=True, lazy_dz=True)
         if self.bn2 is None:
             return [dxa, dz]
+        from ...ops.conv_igemm import MaskedGrad
+        if isinstance(dz, MaskedGrad):
+            return [dxa, self.bn2.backward(dz.src, ext_mask_bits=dz.bits)]
         return [dxa, self.bn2.backward(dz)]
 
 
@@ -160,6 +168,7 @@ class ComputationGraph(BaseNetwork):
         self.vertices: "OrderedDict[str, object]" = OrderedDict()
         self._inputs = self._labels = None
         self.fusion_enabled = True
+        self._bn_sinks_enabled = os.environ.get("DL4J_AMD_BN_DGRAD_SINK", "1") == "1"
 
     # ------------------------------------------------------------------ init
     def init(self, params=None, cloneParametersArray=True):
@@ -300,6 +309,20 @@ class ComputationGraph(BaseNetwork):
         if self.fusion_enabled:
             plan = self._merge_lstm_chains(plan, cons, outs, fused_away)
         self._fused_alias = fused_away
+        # backward bookkeeping for the fused dgrad epilogue: for every tensor name the plan index of its FIRST consumer (the
+        # last one to contribute a gradient in the reversed sweep) and, when the tensor is the output of a BatchNorm node, that
+        # BatchNorm implementation
+        first, bn_of = {}, {}
+        for k, nd in enumerate(plan):
+            for i in nd.inputs:
+                first.setdefault(i, k)
+            if isinstance(nd, _FusedBNNode):
+                bn_of[nd.out] = nd.bn
+            elif type(nd) is _Node and nd.is_layer and nd.pre is None and type(nd.impl) is BatchNormalizationImpl:
+                bn_of[nd.out] = nd.impl
+        for o in outs:
+            first.pop(o, None)                       # a network output also receives the loss gradient
+        self._plan_first_consumer, self._plan_bn_of = first, bn_of
         # last-use table for freeing activations in inference
         last = {}
         for k, nd in enumerate(plan):
@@ -543,23 +566,38 @@ class ComputationGraph(BaseNetwork):
                 e = eps.pop(nd.out, None)
                 if e is None:
                     continue
+                if isinstance(e, MaskedGrad):
+                    e = e.materialize()
                 # fan-out accumulation fused into the conv dgrad epilogue: the gradient already collected for this node's
                 # input is updated in place instead of materialising dx and running a separate add
-                acc_in = None
+                acc_in = sink = sink_bn = None
                 if (type(nd) is _Node and nd.is_layer and nd.pre is None and len(nd.inputs) == 1
                         and isinstance(nd.impl, ConvolutionLayerImpl) and type(nd.impl) is ConvolutionLayerImpl
                         and nd.impl.supports_accum()):
-                    acc_in = eps.get(nd.inputs[0])
-                    if acc_in is not None:
+                    inp = nd.inputs[0]
+                    acc_in = eps.get(inp)
+                    if acc_in is not None and not isinstance(acc_in, MaskedGrad):
                         # the target must be exclusively owned: vertices such as Add hand the *same* tensor to several inputs
                         sp = acc_in.untyped_storage().data_ptr()
                         if sp == e.untyped_storage().data_ptr() or any(
-                                t is not acc_in and t.untyped_storage().data_ptr() == sp for t in eps.values()):
+                                isinstance(t, torch.Tensor) and t is not acc_in and t.untyped_storage().data_ptr() == sp
+                                for t in eps.values()):
                             acc_in = None
-                if acc_in is not None:
-                    dx = nd.impl.backward(e, accum=acc_in)
+                    # this conv is the LAST contributor to its input's gradient and that input comes out of a BatchNorm node:
+                    # the dgrad epilogue then also emits that BatchNorm's backward partial sums (no column-reduction pass)
+                    k_fwd = len(self._plan) - 1 - k_rev
+                    if (self._bn_sinks_enabled and self._plan_first_consumer.get(inp) == k_fwd
+                            and (acc_in is not None) == (eps.get(inp) is not None)):
+                        sink_bn = self._plan_bn_of.get(inp)
+                        if sink_bn is not None:
+                            sink = sink_bn.backward_sink()
+                if acc_in is not None or sink is not None:
+                    dx = nd.impl.backward(e, accum=acc_in, bn_sink=sink)
+                    if sink is not None and sink.partial is not None:
+                        sink_bn._bwd_sink = sink
                     if dx is not None:
-                        eps[nd.inputs[0]] = dx
+                        prev = eps.get(inp) if acc_in is None else None
+                        eps[inp] = dx if prev is None else prev + dx
                     continue
                 dxs = nd.backward(e, mb)
             for inp, dx in zip(nd.inputs, dxs):

@@ -367,7 +367,23 @@ class BatchNormalizationImpl(LayerImpl):
         self._z2 = None
         return self._from2d(y2, shp)
 
-    def backward(self, eps, return_dz=False):
+    def backward_sink(self):
+        """What the data-gradient launch producing this layer's dy needs to emit the backward partial sums in its epilogue
+        (ops/conv_igemm.BnBackwardSink), or None when this call's state does not allow it (CPU / fp32 / stored-output mask)."""
+        x2 = getattr(self, "_x2", None)
+        if x2 is None or not x2.is_cuda or x2.dtype != torch.bfloat16 or self._out2 is not None or self._shp is None \
+                or len(self._shp) != 4 or getattr(self, "_ext_mask", False):
+            return None
+        from ...ops.conv_igemm import BnBackwardSink
+        mc = getattr(self, "_mask_coeffs", None)
+        return BnBackwardSink(x2, self._mean, self._invstd, mc[0] if mc else None, mc[1] if mc else None,
+                              getattr(self, "_mask_bits", None))
+
+    def backward(self, eps, return_dz=False, lazy_dz=False, ext_mask_bits=None):
+        """``lazy_dz``: return dz = eps * [out > 0] as a MaskedGrad (eps + the saved mask bits) instead of writing it.
+        ``ext_mask_bits``: eps is to be read through these mask bits (the shortcut BatchNorm of a downsampling block receives
+        the block's masked gradient without it ever being materialised)."""
+        from ...ops.conv_igemm import MaskedGrad
         d2, _ = self._to2d(eps)
         if not d2.is_contiguous():
             d2 = d2.contiguous()
@@ -376,17 +392,27 @@ class BatchNormalizationImpl(LayerImpl):
         gamma = self.params["gamma"].reshape(-1) if "gamma" in self.params else None
         dg = self.grads["gamma"].reshape(-1) if "gamma" in self.grads else None
         db = self.grads["beta"].reshape(-1) if "beta" in self.grads else None
+        bits = getattr(self, "_mask_bits", None)
+        if ext_mask_bits is not None:
+            assert bits is None and self._out2 is None and getattr(self, "_mask_coeffs", None) is None
+            bits = ext_mask_bits
+        want_dz = return_dz or self._want_dz
+        lazy = lazy_dz and want_dz and bits is not None and MaskedGrad.ok(eps, bits)
+        sink, self._bwd_sink = getattr(self, "_bwd_sink", None), None
+        pre = (sink.partial, sink.gy) if (sink is not None and sink.partial is not None) else None
         dx2, dz2 = BN.backward(self._x2, d2, self._out2, self._mean, self._invstd, gamma, dg, db,
-                               want_dz=return_dz or self._want_dz, mask_coeffs=getattr(self, "_mask_coeffs", None),
-                               mask_bits=getattr(self, "_mask_bits", None))
+                               want_dz=want_dz and not lazy, mask_coeffs=getattr(self, "_mask_coeffs", None),
+                               mask_bits=bits, pre_partials=pre)
         dx = self._from2d(dx2, self._shp)
-        if return_dz or self._want_dz:
+        if lazy:
+            return dx, MaskedGrad(eps, bits)
+        if want_dz:
             return dx, self._from2d(dz2, self._shp)
         return dx
 
     def clear(self):
         super().clear()
-        self._x2 = self._out2 = self._z2 = self._mask_coeffs = self._mask_bits = None
+        self._x2 = self._out2 = self._z2 = self._mask_coeffs = self._mask_bits = self._bwd_sink = None
 
 
 # ------------------------------------------------------------------ convolution
@@ -442,17 +468,24 @@ class ConvolutionLayerImpl(LayerImpl):
         """True when backward(eps, accum=g) can add the input gradient into ``g`` (graph fan-out accumulation)."""
         return self._extra is None and self.conf.idropout is None
 
-    def backward(self, eps, accum=None):
+    def backward(self, eps, accum=None, bn_sink=None):
+        """``accum``: gradient already collected for this layer's input — a tensor (added in place by the dgrad epilogue) or a
+        MaskedGrad (added from its source through the mask bits). ``bn_sink``: see ops/conv_igemm.BnBackwardSink."""
+        from ...ops.conv_igemm import MaskedGrad
         c = self.conf
         dz = eps if self.z is None else c.activationFn.backprop(self.z, eps)
         if dz.dtype != self.input.dtype:
             dz = dz.to(self.input.dtype)
         has_b = "b" in self.params and not self.fold_bias
         need_dx = getattr(self, "needs_input_grad", True)
+        masked = accum if isinstance(accum, MaskedGrad) else None
+        if masked is not None:
+            accum = None
         dx, dW, db = CONV.conv2d_backward(dz, self.input, self.w("W"), c.stride, self._pad, c.dilation,
                                           need_dx, True, has_b, w_dgrad=self.cparams.get("W_dgrad"),
                                           dw_out=self.grads["W"], dx_accum=accum if need_dx else None,
-                                          dw_prezeroed=getattr(self.ctx, "grads_zeroed", False))
+                                          dw_prezeroed=getattr(self.ctx, "grads_zeroed", False),
+                                          dx_acc_masked=masked if need_dx else None, bn_sink=bn_sink if need_dx else None)
         if dW is not None:
             self.grads["W"].copy_(dW)
         if "b" in self.grads:

@@ -209,7 +209,8 @@ def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std
     return mean, invstd, scale, shift
 
 
-def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_dz=False, mask_coeffs=None, mask_bits=None):
+def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_dz=False, mask_coeffs=None, mask_bits=None,
+             pre_partials=None):
     """BatchNorm backward. ``out2d`` (optional) is the fused ReLU output used as mask; alternatively ``mask_coeffs`` =
     (scale, shift) lets the kernels recompute the mask as [x*scale + shift > 0] (valid when no residual was added), which
     saves re-reading the activation tensor in both backward passes.
@@ -229,7 +230,14 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
                  (dgamma_out is None or (dgamma_out.is_contiguous() and dgamma_out.dtype == torch.float32))
         ms, mt = mask_coeffs if (mask_coeffs is not None and out2d is None) else (None, None)
         tk = ticket_ws(x2d.device) if (_FUSE_STAGE2 and 128 * C <= TICKET_GPART) else None
-        if mask_bits is not None:
+        if pre_partials is not None:
+            # (partial [gy, 2, C], gy): per-tile sum dz / sum dz*xhat rows emitted by the epilogue of the data-gradient launch
+            # that produced dy (ops/conv_igemm.BnBackwardSink): only the tiny second stage runs here
+            part, gy = pre_partials
+            assert part.numel() >= gy * 2 * C
+            L.check(h.dl4j_bn_sum_partials(L.ptr(part), L.c_int(gy), L.c_int(C), L.ptr(sums), L.ptr(dbeta_out if direct else None),
+                                           L.ptr(dgamma_out if direct else None), L.stream()), "bn_sum_partials")
+        elif mask_bits is not None:
             L.check(h.dl4j_bn_bwd_reduce_mask(L.ptr(x2d), L.ptr(dy2d), L.ptr(mask_bits), L.ptr(mean), L.ptr(invstd), L.ptr(ws),
                                               L.ptr(sums), L.ptr(dbeta_out if direct else None), L.ptr(dgamma_out if direct else None),
                                               L.c_int64(M), L.c_int(C), dt, L.stream()), "bn_bwd_reduce_mask")

@@ -88,10 +88,37 @@ def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False, bn_fin=
     return F.conv2d(x, w, b, tuple(stride), tuple(padding), tuple(dilation)), None
 
 
+def dgrad_epilogue_ok(dz, x, w, stride, padding, dilation, w_dgrad):
+    """True when the data gradient of this call runs on the implicit-GEMM kernel whose epilogue can add a masked gradient and
+    emit BatchNorm-backward partial sums (ops/conv_igemm.dgrad acc_masked / bn_sink)."""
+    if w_dgrad is None or dz.dtype != torch.bfloat16:
+        return False
+    if not (_hip_eligible(x, w, stride, padding, dilation) and _prefer_r1(x, w, stride, padding, dilation)):
+        return False
+    if _stem_eligible(x, w, stride, padding, dilation) and x.shape[1] < 8:
+        return False
+    from . import conv_igemm as IG
+    return IG.dgrad_supported(w, stride, padding, dz)
+
+
 def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=True, need_db=False, w_dgrad=None,
-                    dw_out=None, dx_accum=None, dw_prezeroed=False):
+                    dw_out=None, dx_accum=None, dw_prezeroed=False, dx_acc_masked=None, bn_sink=None):
     """Returns (dx, dW, db); dW has logical shape [nOut, nIn, kH, kW] — or None when it was written
-    straight into ``dw_out`` (fp32 gradient view) by the HIP wgrad kernel."""
+    straight into ``dw_out`` (fp32 gradient view) by the HIP wgrad kernel.
+    ``dx_acc_masked`` (conv_igemm.MaskedGrad): another gradient for x, added in the dgrad epilogue (materialised here when the
+    kernel cannot take it). ``bn_sink`` (conv_igemm.BnBackwardSink): filled when the dgrad epilogue emitted the partial sums —
+    the caller checks ``bn_sink.partial``."""
+    if dx_acc_masked is not None or bn_sink is not None:
+        fus = need_dx and dgrad_epilogue_ok(dz, x, w, stride, padding, dilation, w_dgrad)
+        from . import conv_igemm as IG
+        if dx_acc_masked is not None and not (fus and tuple(stride) == (1, 1) and dx_accum is None
+                                              and tuple(dx_acc_masked.shape) == tuple(x.shape)
+                                              and IG.MaskedGrad.ok(dx_acc_masked.src, dx_acc_masked.bits)):
+            m = dx_acc_masked.materialize()
+            dx_accum = m if dx_accum is None else dx_accum + m
+            dx_acc_masked = None
+        if bn_sink is not None and not (fus and bn_sink.ok(x.shape)):
+            bn_sink = None
     if _mfma_eligible(x, w) and dz.dtype == x.dtype and not _prefer_r1(x, w, stride, padding, dilation) \
             and not (_stem_eligible(x, w, stride, padding, dilation) and x.shape[1] < 8):
         return _backward_mfma(dz, x, w, stride, padding, dilation, need_dx, need_dw, need_db, w_dgrad, dw_out, dx_accum,
@@ -113,7 +140,10 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
         if need_dx:
             if w_dgrad is not None and IG.dgrad_supported(w, stride, padding, dz):
                 acc = dx_accum if IG.accum_ok(dx_accum, x.shape) else None
-                dx = IG.dgrad(dz, x.shape, w_dgrad, stride, padding, dilation, accum_into=acc)
+                if dx_accum is not None and acc is None:
+                    bn_sink = None               # the sum is finished outside the kernel: its partial sums would be of a part only
+                dx = IG.dgrad(dz, x.shape, w_dgrad, stride, padding, dilation, accum_into=acc, acc_masked=dx_acc_masked,
+                              bn_sink=bn_sink)
                 if dx_accum is not None and acc is None:
                     dx = dx_accum + dx
             else:

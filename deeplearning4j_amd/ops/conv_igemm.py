@@ -88,6 +88,91 @@ class StatPartials:
         return out
 
 
+class MaskedGrad:
+    """A gradient that is ``src * mask`` with the mask kept as bits (one byte per 8 channels, channels-last element order):
+    dz = d_out * [out > 0] of a residual block, handed to the identity shortcut WITHOUT being written — the data-gradient
+    launch that accumulates into the shortcut reads ``src`` and the bits in its epilogue. ``materialize()`` is the fallback for
+    any other consumer."""
+    __slots__ = ("src", "bits")
+
+    def __init__(self, src, bits):
+        self.src, self.bits = src, bits
+
+    @property
+    def shape(self):
+        return self.src.shape
+
+    @property
+    def dtype(self):
+        return self.src.dtype
+
+    def materialize(self):
+        s = self.src
+        N, C, H, W = s.shape
+        phys = s.permute(0, 2, 3, 1)                           # [N,H,W,C] contiguous view of the channels-last tensor
+        sh = torch.arange(8, device=s.device, dtype=torch.uint8)
+        m = ((self.bits.view(-1, 1) >> sh) & 1).to(torch.bool).reshape(N, H, W, C)
+        return torch.where(m, phys, torch.zeros((), device=s.device, dtype=s.dtype)).permute(0, 3, 1, 2)
+
+    def __add__(self, other):
+        o = other.materialize() if isinstance(other, MaskedGrad) else other
+        return self.materialize() + o
+
+    __radd__ = __add__
+
+    @staticmethod
+    def ok(src, bits):
+        return (src is not None and bits is not None and src.dim() == 4 and src.dtype == torch.bfloat16 and src.shape[1] % 8 == 0
+                and src.is_contiguous(memory_format=torch.channels_last) and bits.numel() * 8 == src.numel()
+                and src.data_ptr() % 16 == 0)
+
+
+class BnBackwardSink:
+    """Request to a data-gradient launch: "your output is dy of this BatchNorm(+ReLU): emit its backward partial sums".
+    ``y`` is the BatchNorm input as [M, C] (the memory of the channels-last tensor), ``ms``/``mt`` recompute a fused ReLU's
+    mask from y, ``bits`` is the saved mask of a residual block. After the launch ``partial`` ([gy, 2, C] fp32: per-tile sum dz and
+    sum dz * xhat) and ``gy`` are set; ops/batchnorm.backward(pre_partials=...) then skips its column-reduction pass."""
+    __slots__ = ("y", "mean", "invstd", "ms", "mt", "bits", "partial", "gy")
+
+    def __init__(self, y, mean, invstd, ms=None, mt=None, bits=None):
+        self.y, self.mean, self.invstd, self.ms, self.mt, self.bits = y, mean, invstd, ms, mt, bits
+        self.partial, self.gy = None, 0
+
+    def ok(self, x_shape):
+        N, C, H, W = x_shape
+        y = self.y
+        if not (y is not None and y.dtype == torch.bfloat16 and y.is_contiguous() and y.numel() == N * C * H * W
+                and y.shape[-1] == C and y.data_ptr() % 16 == 0):
+            return False
+        for t in (self.mean, self.invstd, self.ms, self.mt):
+            if t is not None and not (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == C and t.data_ptr() % 16 == 0):
+                return False
+        if self.mean is None or self.invstd is None or (self.ms is None) != (self.mt is None):
+            return False
+        if self.bits is not None and not (self.bits.dtype == torch.uint8 and self.bits.numel() * 8 == y.numel()):
+            return False
+        return True
+
+
+def _launch_epi(x_t, w_t, y_t, geom, Kout, M, accum, acc, sink):
+    """Data-gradient launch with the fused epilogue (masked accumulate and / or BatchNorm-backward partial sums)."""
+    tile = pick_tile(M, Kout)
+    mt = int(L.hip().dl4j_igemm_mtiles(L.c_int64(M), L.c_int(tile)))
+    g = (ctypes.c_int * 19)(*geom)
+    partial = None
+    if sink is not None:
+        partial = torch.empty(mt * 2 * Kout, device=x_t.device, dtype=torch.float32)
+    ts = (acc.src if acc is not None else None, acc.bits if acc is not None else None,
+          sink.y if sink is not None else None, sink.mean if sink is not None else None,
+          sink.invstd if sink is not None else None, sink.ms if sink is not None else None,
+          sink.mt if sink is not None else None, sink.bits if sink is not None else None, partial)
+    ptrs = (ctypes.c_void_p * 9)(*[0 if t is None else t.data_ptr() for t in ts])
+    L.check(L.hip().dl4j_igemm_dgrad_bn(L.ptr(x_t), L.ptr(w_t), L.ptr(y_t), g, L.c_int(tile), L.c_int(1 if accum else 0), ptrs,
+                                        L.stream()), "igemm_dgrad_bn")
+    if sink is not None:
+        sink.partial, sink.gy = partial, mt
+
+
 def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False, bn_fin=None):
     tile = pick_tile(M, Kout)
     stats = None
@@ -163,28 +248,40 @@ def accum_ok(t, x_shape):
             and t.is_contiguous(memory_format=torch.channels_last) and t.data_ptr() % 16 == 0)
 
 
-def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation, accum_into=None):
+def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation, accum_into=None, acc_masked=None, bn_sink=None):
     """dx for y = conv(x, w). ``w_dgrad``: [C][R][S][K] spatially flipped filters (bf16, contiguous).
-    ``accum_into``: existing gradient tensor for x (see accum_ok); the epilogue adds into it in place and it is returned."""
+    ``accum_into``: existing gradient tensor for x (see accum_ok); the epilogue adds into it in place and it is returned.
+    ``acc_masked``: a MaskedGrad for x, added in the epilogue into a NEW tensor (never materialised on its own).
+    ``bn_sink``: BnBackwardSink — dx is the gradient into that BatchNorm; the epilogue emits its backward partial sums."""
     N, C, H, W = x_shape
     _, K, OH, OW = dz.shape
     R, S = w_dgrad.shape[1], w_dgrad.shape[2]
     if not dz.is_contiguous(memory_format=torch.channels_last):
         dz = dz.contiguous(memory_format=torch.channels_last)
     acc = accum_into is not None
+    assert not (acc and acc_masked is not None)
+    epi = acc_masked is not None or bn_sink is not None
     if tuple(stride) == (1, 1):
         dx = accum_into if acc else torch.empty((N, C, H, W), device=dz.device, dtype=torch.bfloat16,
                                                 memory_format=torch.channels_last)
         ph = (R - 1) * dilation[0] - padding[0]
         pw = (S - 1) * dilation[1] - padding[1]
         geom = (N, OH, OW, K, H, W, C, R, S, 1, 1, ph, pw, dilation[0], dilation[1], H, W, 1, 1)
-        _launch(dz, w_dgrad, dx, None, geom, False, C, N * H * W, accum=acc)
+        if epi:
+            _launch_epi(dz, w_dgrad, dx, geom, C, N * H * W, acc, acc_masked, bn_sink)
+        else:
+            _launch(dz, w_dgrad, dx, None, geom, False, C, N * H * W, accum=acc)
         return dx
-    # 1x1 strided: rows scatter into a zeroed dx (or add into the positions they hit of an existing gradient)
+    # 1x1 strided: rows scatter into a zeroed dx (or add into the positions they hit of an existing gradient). A masked
+    # accumulate would have to touch the rows this launch skips as well: the caller materialises it instead.
+    assert acc_masked is None
     dx = accum_into if acc else torch.empty((N, C, H, W), device=dz.device, dtype=torch.bfloat16,
                                             memory_format=torch.channels_last).zero_()
     geom = (N, OH, OW, K, OH, OW, C, 1, 1, 1, 1, 0, 0, 1, 1, H, W, stride[0], stride[1])
-    _launch(dz, w_dgrad, dx, None, geom, False, C, N * OH * OW, accum=acc)
+    if epi:
+        _launch_epi(dz, w_dgrad, dx, geom, C, N * OH * OW, acc, None, bn_sink)
+    else:
+        _launch(dz, w_dgrad, dx, None, geom, False, C, N * OH * OW, accum=acc)
     return dx
 
 

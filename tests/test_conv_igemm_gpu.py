@@ -72,6 +72,73 @@ def test_dgrad(case):
 
 
 @pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mask", ["bits", "coeffs", "none"])
+def test_dgrad_fused_epilogue_masked_accumulate_and_bn_backward_sums(case, mask):
+    """dgrad epilogue (EPI == 1): adds a gradient through ReLU mask bits without it being materialised and emits the partial sums
+    of the BatchNorm backward reductions of the layer its output flows into; both against plain fp32 PyTorch on the same tensors."""
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    from deeplearning4j_amd.ops import batchnorm as BN
+    N, C, H, W, K, R, s, p, d = case
+    x, w = _mk(N, C, H, W, K, R, 3)
+    if not IG.dgrad_supported(w, (s, s), (p, p)):
+        pytest.skip("strided non-1x1 dgrad uses the library path")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    OH = (H + 2 * p - d * (R - 1) - 1) // s + 1
+    dz = torch.randn(N, K, OH, OH if H == W else (W + 2 * p - d * (R - 1) - 1) // s + 1, device="cuda", generator=g).bfloat16()
+    dz = dz.contiguous(memory_format=torch.channels_last)
+    w_dgrad = torch.flip(w, dims=[2, 3]).permute(1, 2, 3, 0).contiguous()
+    base = IG.dgrad(dz, x.shape, w_dgrad, (s, s), (p, p), (d, d))                   # plain kernel
+    M = N * H * W
+    # the BatchNorm this gradient flows into: input y (|mean| >> std on some channels), mean / invstd, ReLU mask
+    y = (torch.randn(M, C, device="cuda", generator=g) * 0.5 + torch.linspace(-20, 20, C, device="cuda")).bfloat16()
+    mean = y.float().mean(0)
+    invstd = torch.rsqrt(y.float().var(0, unbiased=False) + 1e-5)
+    ms = torch.rand(C, device="cuda", generator=g) + 0.5
+    mt = -mean * ms + torch.randn(C, device="cuda", generator=g) * 0.1
+    mbits = (torch.rand(M, C, device="cuda", generator=g) > 0.4)
+    packed = (mbits.view(M, C // 8, 8).to(torch.uint8) << torch.arange(8, device="cuda", dtype=torch.uint8)).sum(-1).to(torch.uint8)
+    sink = IG.BnBackwardSink(y, mean, invstd, ms if mask == "coeffs" else None, mt if mask == "coeffs" else None,
+                             packed.reshape(-1) if mask == "bits" else None)
+    assert sink.ok(x.shape)
+    # the gradient added through mask bits (stride-1 launches only: a scatter launch skips rows)
+    acc = None
+    if s == 1:
+        src = torch.randn(x.shape, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        abits = (torch.rand(M, C, device="cuda", generator=g) > 0.5)
+        apacked = (abits.view(M, C // 8, 8).to(torch.uint8) << torch.arange(8, device="cuda", dtype=torch.uint8)).sum(-1).to(torch.uint8)
+        acc = IG.MaskedGrad(src, apacked.reshape(-1))
+        assert IG.MaskedGrad.ok(acc.src, acc.bits)
+        want_mat = torch.where(abits.view(N, H, W, C), src.permute(0, 2, 3, 1), torch.zeros((), device="cuda", dtype=torch.bfloat16))
+        assert torch.equal(acc.materialize().permute(0, 2, 3, 1), want_mat)
+    dx = IG.dgrad(dz, x.shape, w_dgrad, (s, s), (p, p), (d, d), acc_masked=acc, bn_sink=sink)
+    want = base if acc is None else (base.float() + acc.materialize().float()).bfloat16()
+    assert torch.equal(dx, want)
+    assert sink.partial is not None and sink.gy > 0
+    # reference sums in fp32 from the tensor the kernel stored
+    d2 = dx.permute(0, 2, 3, 1).reshape(M, C).float()
+    if mask == "bits":
+        d2 = d2 * mbits
+    elif mask == "coeffs":
+        d2 = d2 * ((y.float() * ms + mt) > 0)
+    r0 = d2.sum(0)
+    r1 = (d2 * (y.float() - mean) * invstd).sum(0)
+    got = sink.partial.view(sink.gy, 2, C).sum(0)
+    scale0 = d2.abs().sum(0).max().item()
+    assert torch.allclose(got[0], r0, rtol=1e-4, atol=1e-5 * scale0), (got[0] - r0).abs().max()
+    scale1 = (d2 * (y.float() - mean) * invstd).abs().sum(0).max().item()
+    assert torch.allclose(got[1], r1, rtol=1e-4, atol=1e-5 * scale1), (got[1] - r1).abs().max()
+    # and through the BatchNorm backward: identical dx / dgamma / dbeta to the column-reduction form on the same dy
+    gamma = torch.rand(C, device="cuda", generator=g) + 0.5
+    dy2 = dx.permute(0, 2, 3, 1).reshape(M, C)
+    kw = dict(mask_bits=packed.reshape(-1)) if mask == "bits" else (dict(mask_coeffs=(ms, mt)) if mask == "coeffs" else {})
+    dg1, db1, dg2, db2 = (torch.empty(C, device="cuda") for _ in range(4))
+    a, _ = BN.backward(y, dy2, None, mean, invstd, gamma, dg1, db1, **kw)
+    b, _ = BN.backward(y, dy2, None, mean, invstd, gamma, dg2, db2, pre_partials=(sink.partial, sink.gy), **kw)
+    assert torch.allclose(dg1, dg2, rtol=1e-4, atol=1e-5 * scale1) and torch.allclose(db1, db2, rtol=1e-4, atol=1e-5 * scale0)
+    assert (a.float() - b.float()).abs().max().item() <= 2e-2 * max(1.0, a.float().abs().max().item())
+
+
+@pytest.mark.parametrize("case", CASES)
 def test_wgrad(case):
     from deeplearning4j_amd.ops import conv_igemm as IG
     N, C, H, W, K, R, s, p, d = case
