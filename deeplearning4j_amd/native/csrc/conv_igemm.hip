@@ -165,6 +165,41 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
     __syncthreads();
   }
 
+  // EPI == 1: everything the fused epilogue reads from global memory is requested HERE, for all of this thread's rows at once,
+  // so the latencies overlap each other and the accumulator staging below (issued row by row inside the store loop they were
+  // exposed once per row: +11 us per launch)
+  constexpr int E_CPR = BN / 8, E_RPP = 256 / E_CPR, E_NIT = EPI == 1 ? BM / E_RPP : 1;
+  int64_t e_o[E_NIT];
+  s16x8 e_y[E_NIT], e_prev[E_NIT];
+  unsigned e_mb[E_NIT], e_ab[E_NIT];
+  if constexpr (EPI == 1) {
+    const int ch = tid % E_CPR, r0 = tid / E_CPR;
+    const bool want = p.bnb_partial != nullptr;
+#pragma unroll
+    for (int i = 0; i < E_NIT; ++i) {
+      const int m = m0 + r0 + i * E_RPP;
+      e_o[i] = -1;
+      e_y[i] = s16x8{0, 0, 0, 0, 0, 0, 0, 0}; e_prev[i] = e_y[i];
+      e_mb[i] = 0xFFu; e_ab[i] = 0xFFu;
+      if (m < p.M) {
+        const int n = m / OHW, rem = m - n * OHW;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int64_t o = (((int64_t)n * p.OHs + oh * p.oys) * p.OWs + ow * p.oxs) * p.K + n0 + ch * 8;
+        e_o[i] = o;
+        if (p.acc_src != nullptr) {
+          e_prev[i] = *reinterpret_cast<const s16x8*>(p.acc_src + o);
+          if (p.acc_bits != nullptr) e_ab[i] = p.acc_bits[o >> 3];
+        } else if (p.accum) {
+          e_prev[i] = *reinterpret_cast<const s16x8*>(p.y + o);
+        }
+        if (want) {
+          e_y[i] = *reinterpret_cast<const s16x8*>(p.bnb_y + o);
+          if (p.bnb_mode == 1) e_mb[i] = p.bnb_bits[o >> 3];
+        }
+      }
+    }
+  }
+
   // ---------------- epilogue: bias, bf16 rounding, BN-stat partials, LDS transpose, coalesced store
   char* sC = smem;
   float* sS = reinterpret_cast<float*>(smem + ((BM * PITCH_C + 255) & ~255));
@@ -235,28 +270,23 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
       mt0 = *reinterpret_cast<const f32x4*>(p.bnb_mt + cbase);     mt1 = *reinterpret_cast<const f32x4*>(p.bnb_mt + cbase + 4);
     }
     f32x4 s0a = {0.f, 0.f, 0.f, 0.f}, s0b = s0a, s1a = s0a, s1b = s0a;      // sum dz / sum dz*xhat for channels 0-3 / 4-7
-    for (int row = r0; row < BM; row += RPP) {
-      const int m = m0 + row;
-      if (m >= p.M) break;
-      const int n = m / OHW, rem = m - n * OHW;
-      const int oh = rem / p.OW, ow = rem - oh * p.OW;
-      const int64_t o = (((int64_t)n * p.OHs + oh * p.oys) * p.OWs + ow * p.oxs) * p.K + cbase;
+    const bool have_prev = p.acc_src != nullptr || p.accum;
+#pragma unroll
+    for (int i = 0; i < E_NIT; ++i) {
+      const int row = r0 + i * RPP;
+      const int64_t o = e_o[i];
+      if (o < 0) continue;
       s16x8 v = *reinterpret_cast<const s16x8*>(sC + row * PITCH_C + ch * 16);
-      if (p.acc_src != nullptr) {
-        const s16x8 prev = *reinterpret_cast<const s16x8*>(p.acc_src + o);
-        const unsigned ab = p.acc_bits != nullptr ? (unsigned)p.acc_bits[o >> 3] : 0xFFu;
+      if (have_prev) {
+        const s16x8 prev = e_prev[i];
+        const unsigned ab = e_ab[i];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)v[j]) + (((ab >> j) & 1u) ? bf2f((bf16_t)prev[j]) : 0.f));
-      } else if (p.accum) {
-        const s16x8 prev = *reinterpret_cast<const s16x8*>(p.y + o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((bf16_t)v[j]) + bf2f((bf16_t)prev[j]));
       }
       *reinterpret_cast<s16x8*>(p.y + o) = v;
       if (want) {
-        const s16x8 yv = *reinterpret_cast<const s16x8*>(p.bnb_y + o);
-        unsigned mb = 0xFFu;
-        if (mode == 1) mb = p.bnb_bits[o >> 3];
+        const s16x8 yv = e_y[i];
+        const unsigned mb = e_mb[i];
 #define BNB_LANE(J, MU, IS, MS, MT, S0, S1, E)                                  \
         {                                                                      \
           const float yf = bf2f((bf16_t)yv[J]);                                \

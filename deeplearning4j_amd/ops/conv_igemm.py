@@ -154,9 +154,14 @@ class BnBackwardSink:
         return True
 
 
+_EPI_TILE = int(__import__("os").environ.get("DL4J_AMD_EPI_TILE", "-1"))
+
+
 def _launch_epi(x_t, w_t, y_t, geom, Kout, M, accum, acc, sink):
     """Data-gradient launch with the fused epilogue (masked accumulate and / or BatchNorm-backward partial sums)."""
     tile = pick_tile(M, Kout)
+    if _EPI_TILE >= 0 and Kout % _TILES[_EPI_TILE][1] == 0 and tile < _EPI_TILE:
+        tile = _EPI_TILE
     mt = int(L.hip().dl4j_igemm_mtiles(L.c_int64(M), L.c_int(tile)))
     g = (ctypes.c_int * 19)(*geom)
     partial = None
