@@ -19,3 +19,9 @@ from .transform_ext import (BooleanColumnCondition, FloatColumnCondition, TimeCo
                             NDArrayColumnsMathOpTransform, NDArrayDistanceTransform, Distance, SequenceDifferenceTransform, SequenceTrimToLength,
                             ReduceSequenceTransform, SequenceSplitTimeSeparation, TimeWindowFunction, OverlappingTimeWindowFunction,
                             ReduceSequenceByWindowTransform, SequenceMerge, RandomSplit, StringReduceOp, StringReducer)
+from .analysis import (AnalyzeLocal, DataAnalysis, SequenceDataAnalysis, SequenceLengthAnalysis, IntegerAnalysis, LongAnalysis,  # noqa: F401,E402,F811
+                       DoubleAnalysis, TimeAnalysis, StringAnalysis, CategoricalAnalysis, BytesAnalysis, NDArrayAnalysis,
+                       NumericalColumnAnalysis, DataQualityAnalysis, ColumnQuality, DoubleQuality, IntegerQuality, LongQuality,
+                       StringQuality, CategoricalQuality, TimeQuality, BytesQuality, HtmlAnalysis, HtmlSequencePlotting,
+                       CalculateSortedRank, WritableComparator, DoubleWritableComparator, FloatWritableComparator,
+                       IntWritableComparator, LongWritableComparator, TextWritableComparator, ReverseComparator)

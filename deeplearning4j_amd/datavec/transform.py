@@ -91,6 +91,7 @@ class Schema:
         def addColumnBoolean(self, *n): return self._add(ColumnType.Boolean, n)
         def addColumnTime(self, name, tz="UTC"): return self._add(ColumnType.Time, [name])
         def addColumnNDArray(self, name, shape=None): return self._add(ColumnType.NDArray, [name])
+        def addColumnBytes(self, *n): return self._add(ColumnType.Bytes, n)
 
         def addColumnCategorical(self, name, *states):
             st = list(states[0]) if len(states) == 1 and isinstance(states[0], (list, tuple)) else list(states)
@@ -547,6 +548,8 @@ class TransformProcess:
                 s = st.outputSchema(s)
             elif isinstance(st, _SortedRank):
                 s.getIndexOfColumn(st.sortCol)
+                if hasattr(st, "setInputSchema"):
+                    st.setInputSchema(s)
                 s = Schema(list(s.columns) + [ColumnMetaData(st.newCol, ColumnType.Long)])
             self._schemas.append(s)
         self.finalSchema = s
@@ -583,6 +586,8 @@ class TransformProcess:
 
     def toJson(self):
         def enc(o):
+            if hasattr(o, "to_json") and isinstance(o, _SortedRank):
+                return o.to_json()
             d = {"@class": type(o).__name__}
             for k, v in vars(o).items():
                 if k.startswith("_") or k in ("inputSchema", "schema"):
@@ -681,7 +686,13 @@ class TransformProcess:
         def splitSequence(self, maxLen): return self._add(SplitMaxLength(maxLen))
         # -- reduce
         def reduce(self, reducer): return self._add(reducer)
-        def calculateSortedRank(self, newCol, sortCol, ascending=True): return self._add(_SortedRank(newCol, sortCol, ascending))
+        def calculateSortedRank(self, newCol, sortCol, comparator=None, ascending=True):
+            """CalculateSortedRank (TransformProcess.java:1211-1246): ``comparator`` is a datavec.analysis.WritableComparator
+            (default: by the column's type); a bool in its place is taken as ``ascending`` (earlier signature)."""
+            from .analysis import CalculateSortedRank
+            if isinstance(comparator, bool):
+                comparator, ascending = None, comparator
+            return self._add(CalculateSortedRank(newCol, sortCol, comparator, ascending))
 
 
 # -- concrete steps
@@ -1127,12 +1138,14 @@ class LocalTransformExecutor:
                     raise ValueError("Cannot reduce sequences")
                 data = st.reduce(schema, data)
             elif isinstance(st, _SortedRank):
-                i = schema.getIndexOfColumn(st.sortCol)
-                order = sorted(range(len(data)), key=lambda j: data[j][i].toDouble(), reverse=not st.ascending)
-                ranks = [0] * len(data)
-                for rk, j in enumerate(order):
-                    ranks[j] = rk
-                data = [r + [LongWritable(ranks[j])] for j, r in enumerate(data)]
+                if is_seq:
+                    raise ValueError("CalculateSortedRank on sequences: not supported (LocalTransformExecutor.java:472-476)")
+                if hasattr(st, "execute"):
+                    data = st.execute(data, schema)           # sorted order + rank column, as the reference executor
+                else:
+                    i = schema.getIndexOfColumn(st.sortCol)
+                    order = sorted(range(len(data)), key=lambda j: data[j][i].toDouble(), reverse=not st.ascending)
+                    data = [data[j] + [LongWritable(rk)] for rk, j in enumerate(order)]
             elif isinstance(st, SplitMaxLength):
                 data = [seq[i:i + st.maxLen] for seq in data for i in range(0, len(seq), st.maxLen)]
             elif hasattr(st, "runAll"):              # steps that change the number of sequences (transform_ext.py)
@@ -1184,8 +1197,16 @@ class DataAnalysis:
 
 
 class AnalyzeLocal:
+    """Kept for imports of the first implementation; datavec.analysis.AnalyzeLocal is the full one (typed column analyses, quality
+    classes, sequences) and is what ``deeplearning4j_amd.datavec.AnalyzeLocal`` resolves to."""
+
     @staticmethod
     def analyze(schema: Schema, reader_or_records, maxHistogramBuckets=20) -> DataAnalysis:
+        from . import analysis
+        return analysis.AnalyzeLocal.analyze(schema, reader_or_records, maxHistogramBuckets)
+
+    @staticmethod
+    def _analyze_basic(schema: Schema, reader_or_records, maxHistogramBuckets=20) -> DataAnalysis:
         recs = list(reader_or_records)
         out = []
         for i, c in enumerate(schema.columns):
@@ -1221,6 +1242,5 @@ class AnalyzeLocal:
 
     @staticmethod
     def analyzeQuality(schema: Schema, reader_or_records):
-        recs = list(reader_or_records)
-        return {c.name: {"valid": sum(c.isValid(r[i]) for r in recs), "invalid": sum(not c.isValid(r[i]) for r in recs)}
-                for i, c in enumerate(schema.columns)}
+        from . import analysis
+        return analysis.AnalyzeLocal.analyzeQuality(schema, reader_or_records)

@@ -449,6 +449,18 @@ class Nd4j:
     def getBlasWrapper():
         return Nd4j
 
+    @staticmethod
+    def lapack():
+        """LAPACK interface (linalg/api/blas/Lapack.java): getrf / geqrf / potrf / syev / gesvd / factor extraction."""
+        from . import linalg
+        return linalg.lapack()
+
+    @staticmethod
+    def syev(jobz, uplo, A, V):
+        """BlasWrapper.syev: eigenvalues into V, eigenvectors overwrite A (jobz == 'V')."""
+        from . import linalg
+        return linalg.lapack().syev(jobz, uplo, A, V)
+
     # ---- multi-array DP primitives (NativeOps average / accumulate)
     @staticmethod
     def _multi_reduce(arrays, target, scale, propagate):
