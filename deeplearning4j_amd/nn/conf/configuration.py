@@ -59,7 +59,10 @@ class NeuralNetConfiguration:
         return json.dumps(self.to_json(), indent=2, sort_keys=True)
 
     @staticmethod
-    def from_json_obj(d):
+    def from_json_obj(d, _upgraded=False):
+        if not _upgraded:
+            from . import legacy_json
+            d = legacy_json.upgrade(d)            # wrapper-object subtypes / enum-era fields of old releases (idempotent)
         layer = Layer.from_json(d["layer"]) if d.get("layer") else None
         kw = {k: d[k] for k in ("seed", "miniBatch", "minimize", "maxNumLineSearchIterations", "optimizationAlgo",
                                 "cacheMode", "dataType", "iterationCount", "epochCount", "variables") if k in d}
@@ -361,7 +364,9 @@ class MultiLayerConfiguration:
         d = json.loads(s) if isinstance(s, (str, bytes)) else s
         if "confs" not in d:
             raise ValueError("Not a MultiLayerConfiguration JSON (no 'confs')")
-        confs = [NeuralNetConfiguration.from_json_obj(c) for c in d["confs"]]
+        from . import legacy_json
+        d = legacy_json.upgrade(d)                # LegacyJsonFormat / BaseNetConfigDeserializer eras -> current layout
+        confs = [NeuralNetConfiguration.from_json_obj(c, True) for c in d["confs"]]
         pre = {int(k): preprocessor_from_json(v) for k, v in (d.get("inputPreProcessors") or {}).items()}
         kw = {k: d[k] for k in ("backpropType", "tbpttFwdLength", "tbpttBackLength", "trainingWorkspaceMode",
                                 "inferenceWorkspaceMode", "cacheMode", "dataType", "computeDataType",
@@ -659,6 +664,8 @@ class ComputationGraphConfiguration:
         d = json.loads(s, object_pairs_hook=OrderedDict) if isinstance(s, (str, bytes)) else s
         if "vertices" not in d:
             raise ValueError("Not a ComputationGraphConfiguration JSON (no 'vertices')")
+        from . import legacy_json
+        d = legacy_json.upgrade(d)
         verts = OrderedDict((k, G.vertex_from_json(v)) for k, v in d["vertices"].items())
         vin = OrderedDict((k, list(v)) for k, v in d["vertexInputs"].items())
         # keep vertices in vertexInputs order when present (stable param layout)
