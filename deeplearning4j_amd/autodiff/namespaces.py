@@ -11,7 +11,12 @@ from typing import Sequence
 
 from ..nd4j.ops import legacy as LG
 from ..nd4j.ops.custom import describe
+from .generated.sd_base import GenSDBase
 from .generated.sd_bitwise import GenSDBitwise
+from .generated.sd_cnn import GenSDCNN
+from .generated.sd_math import GenSDMath
+from .generated.sd_nn import GenSDNN
+from .generated.sd_rnn import GenSDRNN
 from .generated.sd_image import GenSDImage
 from .generated.sd_linalg import GenSDLinalg
 from .generated.sd_loss import GenSDLoss
@@ -52,7 +57,7 @@ def _dims(d):
     return list(d[0]) if len(d) == 1 and isinstance(d[0], (list, tuple)) else list(d)
 
 
-class SDBaseOps(_NS):
+class SDBaseOps(GenSDBase, _NS):       # generated surface (codegen/ops/base.py) + the hand-written forms below (they win)
     def identity(self, x, name=None): return self._o("identity", [x], name)
     def concat(self, dim, *xs, name=None): return self._o("concat", xs, name, iArgs=[dim])
     def stack(self, axis, *xs, name=None): return self._o("stack", xs, name, iArgs=[axis])
@@ -116,7 +121,7 @@ class SDBaseOps(_NS):
     def dynamicStitch(self, indices, xs, name=None): return self._o("dynamic_stitch", list(indices) + list(xs), name)
 
 
-class SDMath(SDBaseOps):
+class SDMath(GenSDMath, SDBaseOps):       # generated surface (codegen/ops/math.py); the legacy-table loop below only fills names it lacks
     pass
 
 
@@ -173,7 +178,7 @@ def _math_extra():
 _math_extra()
 
 
-class SDNN(_NS):
+class SDNN(GenSDNN, _NS):       # generated surface (codegen/ops/nn.py) + overrides
     def linear(self, x, w, b=None, name=None): return self._o("xw_plus_b", [x, w, b], name) if b is not None else self._o("matmul", [x, w], name, iArgs=[0, 0, 0])
     def reluLayer(self, x, w, b, name=None): return self._o("relu_layer", [x, w, b], name)
     def biasAdd(self, x, b, nchw=False, name=None): return self._o("biasadd", [x, b], name, bArgs=[nchw])
@@ -218,7 +223,7 @@ class SDNN(_NS):
                        2 if withWeights else 1, iArgs=[int(scaled), int(withWeights)])
 
 
-class SDCNN(_NS):
+class SDCNN(GenSDCNN, _NS):       # generated surface (codegen/ops/cnn.py) + overrides
     @staticmethod
     def _c2(kH, kW, sH, sW, pH, pW, dH, dW, same, nhwc, wfmt=None):
         a = [kH, kW, sH, sW, pH, pW, dH, dW, int(same), int(nhwc)]
@@ -256,7 +261,7 @@ class SDCNN(_NS):
     def localResponseNormalization(self, x, depth=5, bias=1.0, alpha=1.0, beta=0.5, name=None): return self._o("lrn", [x], name, iArgs=[depth], tArgs=[bias, alpha, beta])
 
 
-class SDRNN(_NS):
+class SDRNN(GenSDRNN, _NS):       # generated surface (codegen/ops/rnn.py) + the configurable lstmLayer front end
     def lstmLayer(self, x, Wx, Wr, b=None, seqLen=None, hI=None, cI=None, Wp=None, dataFormat=0, directionMode=0, gateAct=2, cellAct=0, outAct=0,
                   cellClip=0.0, retFullSequence=True, retLastH=False, retLastC=False, name=None):
         ins = [x, Wx, Wr] + [v for v in (b, seqLen, hI, cI, Wp) if v is not None]

@@ -78,11 +78,15 @@ _NO_DEFAULT = object()
 
 
 class Arg(_Param):
-    def __init__(self, name, type_, doc, default=_NO_DEFAULT, count: Optional[Count] = None, slot=None, convert=None, possibleValues=None):
+    def __init__(self, name, type_, doc, default=_NO_DEFAULT, count: Optional[Count] = None, slot=None, convert=None, possibleValues=None,
+                 pos: Optional[int] = None):
+        """``pos``: position inside the argument vector when it differs from the declaration order (the signature lists required
+        arguments before defaulted ones; a native op may want them the other way round: onehot takes [axis, depth])."""
         super().__init__(name, type_, doc)
+        self.pos = pos
         self.default, self.count = default, count or Count.Exactly(1)
         self.slot = slot or DataType.DEFAULT_SLOT.get(type_)
-        if self.slot not in ("i", "t", "b", "d"):
+        if self.slot not in ("i", "t", "b", "d", "dims", "scalar"):
             raise ValueError("argument %s: no argument vector for type %s (give slot=)" % (name, type_))
         if convert not in (None, "int", "ord", "dtype", "float"):
             raise ValueError("argument %s: unknown conversion %r" % (name, convert))
@@ -116,8 +120,8 @@ class Op:
         self.order = list(names)
         return self
 
-    def arg(self, name, type_, doc, default=_NO_DEFAULT, count=None, slot=None, convert=None, possibleValues=None):
-        self.args.append(Arg(name, type_, doc, default, count, slot, convert, possibleValues))
+    def arg(self, name, type_, doc, default=_NO_DEFAULT, count=None, slot=None, convert=None, possibleValues=None, pos=None):
+        self.args.append(Arg(name, type_, doc, default, count, slot, convert, possibleValues, pos))
         return self
 
     def output(self, name, type_, doc):
@@ -126,6 +130,15 @@ class Op:
 
     def alias(self, *names):
         self.aliases += list(names)
+        return self
+
+    def legacyOp(self, family: str, opName: str):
+        """The op is one of the LEGACY families (transform_* / scalar / pairwise / reduce_* / reduce3 / index_reduce / summary_stats of
+        libnd4j's loops, addressed by (family, opNum)) instead of a declarable custom op. Arguments may then use slot ``dims`` (the
+        reduction dimensions, one variable-length argument) and slot ``scalar`` (the scalar operand of a scalar op); ``t`` arguments
+        become the op's extra parameters."""
+        self.legacy = (family, opName)
+        self.libnd4j = opName
         return self
 
     def numOutputs(self, expr: str):
@@ -141,6 +154,12 @@ class Op:
         where = "%s.%s" % (self.namespace.name, self.name)
         if not self.outputs:
             raise ValueError("%s: an op needs at least one output" % where)
+        if self.legacy:
+            bad = [a.name for a in self.args if a.slot in ("i", "b", "d")]
+            if bad:
+                raise ValueError("%s: a legacy op takes t / dims / scalar arguments only (got %s)" % (where, bad))
+        elif any(a.slot in ("dims", "scalar") for a in self.args):
+            raise ValueError("%s: slots dims / scalar belong to legacy ops" % where)
         names = [p.name for p in self.inputs + self.args]
         if len(set(names)) != len(names):
             raise ValueError("%s: duplicate parameter names" % where)

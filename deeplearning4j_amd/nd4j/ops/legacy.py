@@ -670,3 +670,30 @@ _EXEC = LegacyOpExecutioner()
 
 def executioner() -> LegacyOpExecutioner:
     return _EXEC
+
+
+def exec_legacy(family: str, opName: str, inputs, tArgs=None, dimensions=None, scalar=None, keepDims=False):
+    """Run one legacy op by (family, name) on tensors — the eager counterpart of SameDiff's legacy nodes, used by the generated
+    ND* namespaces (codegen/generator.py)."""
+    lg = executioner()
+    n = op_num(family, opName)
+    x = inputs[0] if inputs else None
+    ext = list(tArgs) if tArgs else None
+    dims = list(dimensions) if dimensions else None
+    if family == "transform_same": return lg.execTransformSame(n, x, None, ext)
+    if family == "transform_strict": return lg.execTransformStrict(n, x, None, ext)
+    if family == "transform_float": return lg.execTransformFloat(n, x, None, ext)
+    if family == "transform_bool": return lg.execTransformBool(n, x, None, ext)
+    if family == "transform_any": return lg.execTransformAny(n, x, None, ext)
+    if family == "pairwise": return lg.execPairwiseTransform(n, x, inputs[1], None, ext)
+    if family == "pairwise_bool": return lg.execPairwiseTransformBool(n, x, inputs[1], None, ext)
+    if family == "scalar": return lg.execScalar(n, x, float(scalar if scalar is not None else (ext[0] if ext else 0.0)))
+    if family == "scalar_bool": return lg.execScalarBool(n, x, float(scalar if scalar is not None else (ext[0] if ext else 0.0)))
+    if family == "reduce_float": return lg.execReduceFloat(n, x, dims, keepDims, ext)
+    if family == "reduce_same": return lg.execReduceSame(n, x, dims, keepDims, ext)
+    if family == "reduce_bool": return lg.execReduceBool(n, x, dims, keepDims, ext)
+    if family == "reduce_long": return lg.execReduceLong(n, x, dims, keepDims, ext)
+    if family == "reduce3": return lg.execReduce3(n, x, inputs[1], dims, keepDims, ext)
+    if family == "index_reduce": return lg.execIndexReduce(n, x, dims, keepDims, ext)
+    if family == "summary_stats": return lg.execSummaryStats(n, x, dims, True, keepDims)
+    raise KeyError("unknown legacy family %r" % family)
