@@ -200,8 +200,11 @@ class SDNN(GenSDNN, _NS):       # generated surface (codegen/ops/nn.py) + overri
     def softmax(self, x, dim=-1, name=None): return self._o("softmax", [x], name, iArgs=[dim])
     def logSoftmax(self, x, dim=-1, name=None): return self._o("log_softmax", [x], name, iArgs=[dim])
     def dropout(self, x, p, name=None): return self._o("dropout", [x], name, 2, tArgs=[p])[0]
-    def layerNorm(self, x, gain, bias=None, channelsFirst=False, *dims, name=None):
-        return self._o("layer_norm", [x, gain] + ([bias] if bias is not None else []), name, iArgs=_dims(dims) or [-1], bArgs=[channelsFirst])
+    def layerNorm(self, x, gain, bias=None, channelsFirst=False, *dims, eps=None, name=None):
+        """``eps``: added to the variance (tArgs[0] of this framework's layer_norm; default 1e-5 — the reference op standardizes
+        without one). BERT checkpoints are trained with 1e-12: models/bert.py passes its configured value."""
+        return self._o("layer_norm", [x, gain] + ([bias] if bias is not None else []), name, iArgs=_dims(dims) or [-1], bArgs=[channelsFirst],
+                       tArgs=None if eps is None else [float(eps)])
     def batchNorm(self, x, mean, var, gamma, beta, eps=1e-5, *axis, name=None):
         return self._o("batchnorm", [x, mean, var, gamma, beta], name, iArgs=[1, 1] + (_dims(axis) or [1]), tArgs=[eps])
     def lrn(self, x, depth=5, bias=1.0, alpha=1.0, beta=0.5, name=None): return self._o("lrn", [x], name, iArgs=[depth], tArgs=[bias, alpha, beta])

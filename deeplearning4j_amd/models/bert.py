@@ -62,7 +62,7 @@ def build_bert_classifier(sd, cfg: BertConfig, seqLen: int, numLabels: int, comp
     pos = pemb.get(slice(0, seqLen), slice(None)) + temb.get(slice(0, 1), slice(None))        # [T, H] (+ segment 0)
     x = x + pos
     x = c(x).reshape(-1, H)                                                                   # [B*T, H]
-    x = sd.nn.layerNorm(x, c(param("embeddings/ln/gain", H, fill=1.0)), c(param("embeddings/ln/bias", H, fill=0.0)), False, 1)
+    x = sd.nn.layerNorm(x, c(param("embeddings/ln/gain", H, fill=1.0)), c(param("embeddings/ln/bias", H, fill=0.0)), False, 1, eps=cfg.layerNormEps)
 
     for li in range(cfg.numLayers):
         p = "layer%d/" % li
@@ -79,11 +79,11 @@ def build_bert_classifier(sd, cfg: BertConfig, seqLen: int, numLabels: int, comp
         a = sd.nn.dotProductAttentionV2(q, v, k, None, mask, scale=1.0 / math.sqrt(hd), withWeights=False)
         a = a.permute(0, 2, 1, 3).reshape(-1, H)
         a = sd.nn.linear(a, c(wo), c(bo))
-        x = sd.nn.layerNorm(x + a, c(param(p + "attn/ln/gain", H, fill=1.0)), c(param(p + "attn/ln/bias", H, fill=0.0)), False, 1)
+        x = sd.nn.layerNorm(x + a, c(param(p + "attn/ln/gain", H, fill=1.0)), c(param(p + "attn/ln/bias", H, fill=0.0)), False, 1, eps=cfg.layerNormEps)
         w1, b1 = param(p + "ffn/in/W", H, cfg.intermediateSize), param(p + "ffn/in/b", cfg.intermediateSize, fill=0.0)
         w2, b2 = param(p + "ffn/out/W", cfg.intermediateSize, H), param(p + "ffn/out/b", H, fill=0.0)
         f = sd.nn.linear(sd.nn.gelu(sd.nn.linear(x, c(w1), c(b1))), c(w2), c(b2))
-        x = sd.nn.layerNorm(x + f, c(param(p + "ffn/ln/gain", H, fill=1.0)), c(param(p + "ffn/ln/bias", H, fill=0.0)), False, 1)
+        x = sd.nn.layerNorm(x + f, c(param(p + "ffn/ln/gain", H, fill=1.0)), c(param(p + "ffn/ln/bias", H, fill=0.0)), False, 1, eps=cfg.layerNormEps)
 
     cls = x.reshape(-1, seqLen, H).get(slice(None), 0, slice(None))                           # [B, H]: the [CLS] position
     pooled = sd.nn.tanh(sd.nn.linear(cls, c(param("pooler/W", H, H)), c(param("pooler/b", H, fill=0.0))))

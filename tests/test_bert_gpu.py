@@ -107,3 +107,38 @@ def test_samediff_training_step_hip_graph_capture_matches_eager():
     for a, b in zip(le, lc):
         assert abs(a - b) < 2e-2 * max(1.0, abs(a)), (le, lc)
     assert lc[-1] < lc[0]
+
+
+@pytest.mark.parametrize("cdt,tol,cos_min", [("FLOAT", 2e-4, 0.9999), ("BFLOAT16", 2e-2, 0.99)])
+def test_bert_gpu_matches_transformers(cdt, tol, cos_min):
+    """The independent oracle of tests/test_bert_parity_cpu.py on the device paths: fp32 (library / own GEMMs, HIP layer norm) and the
+    bf16 flash-attention path against `transformers` in fp32 on the host."""
+    pytest.importorskip("transformers")
+    from deeplearning4j_amd.autodiff.samediff import SameDiff
+    from deeplearning4j_amd.models.bert import BertConfig, build_bert_classifier
+    from test_bert_parity_cpu import _batch, _hf, load_hf_weights
+    cfg = BertConfig(vocabSize=200, hiddenSize=128, numLayers=2, numHeads=2, intermediateSize=256, maxPositions=64)
+    B, T, L = 8, 32, 3
+    hf = _hf(cfg, T, L)
+    sd = SameDiff.create("cuda")
+    build_bert_classifier(sd, cfg, T, L, computeDataType=cdt)
+    mp = load_hf_weights(sd, cfg, hf)
+    ids, mask, y = _batch(cfg, B, T, L)
+    ref = hf(input_ids=ids, attention_mask=mask, labels=y)
+    ph = {"tokenIdx": ids.cuda(), "mask": mask.cuda(), "label": torch.eye(L)[y].cuda()}
+    out = sd.output(ph, ["logits", "loss"])
+    lg = out["logits"].tensor() if hasattr(out["logits"], "tensor") else out["logits"]
+    assert (lg.float().cpu() - ref.logits.detach()).abs().max().item() < tol
+    ref.loss.backward()
+    hp = dict(hf.named_parameters())
+    names = [n for n in sorted(mp) if not n.endswith("attn/k/b")]
+    grads = sd.calculateGradients(ph, names)
+    for n in names:
+        hn, tr = mp[n]
+        g_ref = (hp[hn].grad.t() if tr else hp[hn].grad).reshape(-1)
+        g = grads[n].tensor() if hasattr(grads[n], "tensor") else grads[n]
+        g = g.float().cpu().reshape(-1)
+        if n in ("embeddings/position", "embeddings/tokenType"):
+            g, g_ref = g[:T * cfg.hiddenSize], g_ref[:T * cfg.hiddenSize]
+        cos = float(torch.dot(g, g_ref) / (g.norm() * g_ref.norm() + 1e-30))
+        assert cos > cos_min, (n, cos)

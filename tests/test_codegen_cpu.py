@@ -210,8 +210,8 @@ def test_generated_eager_nn_cnn_rnn_match_torch():
     w, bias = torch.randn(6, 3), torch.randn(3)
     assert torch.allclose(_t(nn.linear(x, w, bias)), x @ w + bias, atol=1e-5) and torch.allclose(_t(nn.reluLayer(x, w, bias)), F.relu(x @ w + bias), atol=1e-5)
     g, be = torch.rand(6) + 0.5, torch.randn(6)
-    assert torch.allclose(_t(nn.layerNorm(x, g, be, False, 1)), F.layer_norm(x, (6,), g, be), atol=1e-5)
-    assert torch.allclose(_t(nn.layerNorm(x, g, None, False, 1)), F.layer_norm(x, (6,), g, None), atol=1e-5)
+    assert torch.allclose(_t(nn.layerNorm(x, g, be, False, 1e-5, 1)), F.layer_norm(x, (6,), g, be), atol=1e-5)
+    assert torch.allclose(_t(nn.layerNorm(x, g, None, False, 1e-5, 1)), F.layer_norm(x, (6,), g, None), atol=1e-5)
     img = torch.randn(2, 3, 8, 8)
     mean, var, gam, bet = torch.randn(3), torch.rand(3) + 0.5, torch.rand(3) + 0.5, torch.randn(3)
     assert torch.allclose(_t(nn.batchNorm(img, mean, var, gam, bet, 1e-5, True, True, 1)), F.batch_norm(img, mean, var, gam, bet, False, 0.0, 1e-5), atol=1e-5)
