@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(
     const float* __restrict__ partial, int gy, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ conv_bias, const float* __restrict__ gmean, const float* __restrict__ gvar, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ dgmean,
-    float* __restrict__ dgvar, int C, float invM, float eps, float decay, int stat_mode) {
+    float* __restrict__ dgvar, int C, float invM, float eps, float decay, int stat_mode, int shifted) {
   // 1024 threads = 8 channels x 128 row groups (was 32): the serial chain over the M tiles was the whole cost (~7 us)
   __shared__ float s0[128][9], s1[128][9];
   const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;
@@ -350,8 +350,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(
   float su = 0.f, sq = 0.f;
 #pragma unroll
   for (int k = 0; k < 32; ++k) { su += s0[k][cl]; sq += s1[k][cl]; }
-  const float m = su * invM;
-  float var = sq * invM - m * m;
+  // shifted: the partials are sums of (x - pivot), pivot = running mean - folded conv bias (conv_igemm.hip IGemmP::piv_mean)
+  const float piv = shifted ? gmean[c] - (conv_bias ? conv_bias[c] : 0.f) : 0.f;
+  const float md = su * invM;
+  const float m = piv + md;
+  float var = sq * invM - md * md;
   var = var < 0.f ? 0.f : var;
   const float is = rsqrtf(var + eps);
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -598,7 +601,19 @@ DL4J_API int dl4j_bn_finalize_partials(const float* partial, int gy, const float
                                        hipStream_t st) {
   if (C <= 0 || gy <= 0) return 0;
   hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((C + 7) / 8), dim3(1024), 0, st, partial, gy, gamma, beta, conv_bias, gmean,
-                     gvar, mean, invstd, scale, shift, dgmean, dgvar, C, 1.f / (float)M, eps, decay, stat_mode);
+                     gvar, mean, invstd, scale, shift, dgmean, dgvar, C, 1.f / (float)M, eps, decay, stat_mode, 0);
+  DL4J_RET_LAST();
+}
+
+// Same for partial sums of (x - pivot), pivot = gmean - conv_bias (needs gmean).
+DL4J_API int dl4j_bn_finalize_partials_shifted(const float* partial, int gy, const float* gamma, const float* beta, const float* conv_bias,
+                                               const float* gmean, const float* gvar, float* mean, float* invstd, float* scale, float* shift,
+                                               float* dgmean, float* dgvar, int C, int64_t M, float eps, float decay, int stat_mode,
+                                               hipStream_t st) {
+  if (C <= 0 || gy <= 0) return 0;
+  if (gmean == nullptr) return -2;
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((C + 7) / 8), dim3(1024), 0, st, partial, gy, gamma, beta, conv_bias, gmean,
+                     gvar, mean, invstd, scale, shift, dgmean, dgvar, C, 1.f / (float)M, eps, decay, stat_mode, 1);
   DL4J_RET_LAST();
 }
 

@@ -52,6 +52,9 @@ struct IGemmP {
   const uint8_t* bnb_bits;   // ReLU mask bits saved by the forward apply (residual blocks), or null
   float* bnb_partial;        // [mtiles][2][K]
   int bnb_mode;              // 0: no mask, 1: bnb_bits, 2: bnb_ms / bnb_mt (set by the host entry point)
+  // statistics pivot: the partial sums are of (y - pivot) with pivot[c] = piv_mean[c] - piv_bias[c] (the consuming BatchNorm's
+  // running mean, minus the folded conv bias): E[(y-p)^2] - E[y-p]^2 does not cancel when |mean| >> std. Null = no shift.
+  const float* piv_mean; const float* piv_bias;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -136,6 +139,13 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   swrite(0);
   __syncthreads();
   const int l31 = lane & 31, lh = lane >> 5;
+  // statistics pivot of this lane's output columns, requested before the K loop so the epilogue does not wait for it
+  float pvq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+    pvq[j] = p.piv_mean ? p.piv_mean[col] - (p.piv_bias ? p.piv_bias[col] : 0.f) : 0.f;
+  }
   for (int t = 0; t < KT; ++t) {
     const int cur = t & (p.nbuf - 1);
     if (t + 1 < KT) gload(t + 1);
@@ -208,6 +218,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   for (int j = 0; j < TN; ++j) {
     const int col = wn * (BN / 2) + j * 32 + l31;
     const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+    const float pv = pvq[j];
     float s = 0.f, q2 = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -216,7 +227,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
         const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         const bf16_t b = f2bf(acc[i][j][e] + bv);
         *reinterpret_cast<bf16_t*>(sC + row * PITCH_C + col * 2) = b;
-        const float v = (m0 + row < p.M) ? bf2f(b) : 0.f;
+        const float v = (m0 + row < p.M) ? bf2f(b) - pv : 0.f;
         s += v; q2 += v * v;
       }
     }
@@ -399,6 +410,9 @@ DL4J_API int dl4j_igemm_conv(const void* x, const void* w, void* y, const float*
 // Same, with the BatchNorm finalize of the consuming layer fused into the launch (ticket.h). ptrs: gamma, beta, conv_bias, gmean,
 // gvar (inputs, may be null), mean, invstd, scale, shift, dgmean, dgvar (outputs); fparams: eps, decay; stat_mode as bn_finalize.
 // cnt: zero-initialised counters (self-resetting), at least ntiles * (1 + ceil(mtiles / 32)) entries; gpart: >= ceil(mtiles/32)*2*K.
+static thread_local const float* g_piv_mean = nullptr;
+static thread_local const float* g_piv_bias = nullptr;
+
 DL4J_API int dl4j_igemm_conv_fin(const void* x, const void* w, void* y, const float* bias, float* stats,
                                  const int* g, int tile, int accum, int* mtiles_out, void* const* ptrs, const float* fparams,
                                  float* gpart, unsigned* cnt, hipStream_t st) {
@@ -407,6 +421,7 @@ DL4J_API int dl4j_igemm_conv_fin(const void* x, const void* w, void* y, const fl
   p.fin = ticket::BnFin{};
   p.acc_src = nullptr; p.acc_bits = nullptr; p.bnb_y = nullptr; p.bnb_mean = p.bnb_invstd = p.bnb_ms = p.bnb_mt = nullptr;
   p.bnb_bits = nullptr; p.bnb_partial = nullptr; p.bnb_mode = 0;
+  p.piv_mean = g_piv_mean; p.piv_bias = g_piv_bias;
   p.N = g[0]; p.H = g[1]; p.W = g[2]; p.C = g[3]; p.OH = g[4]; p.OW = g[5]; p.K = g[6]; p.R = g[7]; p.S = g[8];
   p.sh = g[9]; p.sw = g[10]; p.ph = g[11]; p.pw = g[12]; p.dh = g[13]; p.dw = g[14];
   p.OHs = g[15]; p.OWs = g[16]; p.oys = g[17]; p.oxs = g[18];
@@ -429,6 +444,15 @@ DL4J_API int dl4j_igemm_conv_fin(const void* x, const void* w, void* y, const fl
   return rc;
 }
 
+// dl4j_igemm_conv with the statistics pivot (see IGemmP::piv_mean): the partial rows hold sums of (y - pivot).
+DL4J_API int dl4j_igemm_conv_piv(const void* x, const void* w, void* y, const float* bias, float* stats, const int* g, int tile,
+                                 int accum, int* mtiles_out, const float* piv_mean, const float* piv_bias, hipStream_t st) {
+  g_piv_mean = piv_mean; g_piv_bias = piv_bias;
+  const int rc = dl4j_igemm_conv_fin(x, w, y, bias, stats, g, tile, accum, mtiles_out, nullptr, nullptr, nullptr, nullptr, st);
+  g_piv_mean = nullptr; g_piv_bias = nullptr;
+  return rc;
+}
+
 // Data-gradient launch with the fused epilogue described at IGemmP (EPI == 1). ptrs = [acc_src, acc_bits, bnb_y, bnb_mean,
 // bnb_invstd, bnb_ms, bnb_mt, bnb_bits, bnb_partial] (any may be null; bnb_partial needs bnb_y / mean / invstd).
 // geom as dl4j_igemm_conv. bnb_partial holds dl4j_igemm_mtiles(M, tile) * 2 * K floats.
@@ -440,6 +464,7 @@ DL4J_API int dl4j_igemm_dgrad_bn(const void* x, const void* w, void* y, const in
   p.acc_src = (const bf16_t*)ptrs[0]; p.acc_bits = (const uint8_t*)ptrs[1]; p.bnb_y = (const bf16_t*)ptrs[2];
   p.bnb_mean = (const float*)ptrs[3]; p.bnb_invstd = (const float*)ptrs[4]; p.bnb_ms = (const float*)ptrs[5];
   p.bnb_mt = (const float*)ptrs[6]; p.bnb_bits = (const uint8_t*)ptrs[7]; p.bnb_partial = (float*)ptrs[8];
+  p.piv_mean = nullptr; p.piv_bias = nullptr;
   if (p.bnb_partial != nullptr && (p.bnb_y == nullptr || p.bnb_mean == nullptr || p.bnb_invstd == nullptr)) return -2;
   if ((p.bnb_ms == nullptr) != (p.bnb_mt == nullptr)) return -2;
   if (p.acc_src == nullptr && p.bnb_partial == nullptr) return -2;

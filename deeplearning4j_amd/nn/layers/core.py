@@ -416,6 +416,9 @@ class BatchNormalizationImpl(LayerImpl):
 
 
 # ------------------------------------------------------------------ convolution
+_STAT_PIVOT = __import__("os").environ.get("DL4J_AMD_BN_STAT_PIVOT", "1") == "1"
+
+
 class ConvolutionLayerImpl(LayerImpl):
     def __init__(self, conf, ctx):
         super().__init__(conf, ctx)
@@ -452,11 +455,14 @@ class ConvolutionLayerImpl(LayerImpl):
         self.input, self._pad = x, pad
         c = self.conf
         b = None if (self.fold_bias or "b" not in self.params) else self.w("b").reshape(-1)
-        fin = None
+        fin = pivot = None
         if self.want_stats and train and getattr(self, "stats_consumer", None) is not None:
             fin = self.stats_consumer.finalize_request()
+            # statistics pivot = the consumer's running mean (minus the folded bias): sums of (z - pivot) do not cancel
+            if _STAT_PIVOT and fin.gmean is not None and fin.ok():
+                pivot = (fin.gmean, fin.conv_bias)
         z, self.out_sums = CONV.conv2d_forward(x, self.w("W"), b, c.stride, pad, c.dilation,
-                                               want_stats=self.want_stats and train, bn_fin=fin)
+                                               want_stats=self.want_stats and train, bn_fin=fin, stat_pivot=pivot)
         act = c.activationFn
         if act is None or isinstance(act, ActivationIdentity):
             self.z = None

@@ -177,6 +177,16 @@ def batch_stats(x2d, gamma, beta, eps, decay=0.9, gmean=None, gvar=None, log_std
         if sums is not None and hasattr(sums, "partial"):
             # conv-epilogue partials: reduce + finalize in one launch
             assert sums.K == C and sums.partial.numel() >= sums.gy * 2 * C
+            piv = getattr(sums, "pivot", None)
+            if piv is not None:
+                # rows are sums of (x - pivot): the pivot is recomputed in the kernel from the SAME running mean / folded bias
+                assert gmean is not None and piv[0].data_ptr() == gmean.data_ptr() and \
+                    (piv[1] is None) == (conv_bias is None) and (piv[1] is None or piv[1].data_ptr() == conv_bias.data_ptr())
+                L.check(h.dl4j_bn_finalize_partials_shifted(
+                    L.ptr(sums.partial), L.c_int(sums.gy), L.ptr(gamma), L.ptr(beta), L.ptr(conv_bias), L.ptr(gmean), L.ptr(gvar), L.ptr(mean),
+                    L.ptr(invstd), L.ptr(scale), L.ptr(shift), L.ptr(dgmean_out), L.ptr(dgvar_out), L.c_int(C), L.c_int64(M), L.c_float(eps),
+                    L.c_float(decay), L.c_int(stat_mode), L.stream()), "bn_finalize_partials_shifted")
+                return mean, invstd, scale, shift
             L.check(h.dl4j_bn_finalize_partials(L.ptr(sums.partial), L.c_int(sums.gy), L.ptr(gamma), L.ptr(beta), L.ptr(conv_bias),
                                                 L.ptr(gmean), L.ptr(gvar), L.ptr(mean), L.ptr(invstd), L.ptr(scale), L.ptr(shift),
                                                 L.ptr(dgmean_out), L.ptr(dgvar_out), L.c_int(C), L.c_int64(M), L.c_float(eps),

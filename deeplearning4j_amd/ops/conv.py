@@ -70,7 +70,7 @@ def _stem_eligible(x, w, stride, padding, dilation):
     return conv_stem.supported(x, w, stride, padding, dilation)
 
 
-def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False, bn_fin=None):
+def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False, bn_fin=None, stat_pivot=None):
     """x: [N,C,H,W] logical (channels_last memory on GPU). Returns (z, sums): ``sums`` is the [2K] fp32
     per-channel (sum, sum of squares) of z when the HIP path fused it into its epilogue, else None."""
     if _stem_eligible(x, w, stride, padding, dilation) and x.shape[1] < 8:
@@ -81,7 +81,7 @@ def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False, bn_fin=
         return conv_mfma.forward(x, w, b, stride, padding, dilation, want_stats)
     if _hip_eligible(x, w, stride, padding, dilation):
         from . import conv_igemm
-        return conv_igemm.forward(x, w, b, stride, padding, dilation, want_stats, bn_fin=bn_fin)
+        return conv_igemm.forward(x, w, b, stride, padding, dilation, want_stats, bn_fin=bn_fin, stat_pivot=stat_pivot)
     if _stem_eligible(x, w, stride, padding, dilation):
         from . import conv_stem
         return conv_stem.forward(x, w, b, stride, padding, dilation, want_stats)

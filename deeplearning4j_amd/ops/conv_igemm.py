@@ -76,12 +76,15 @@ def _out_hw(H, W, R, S, stride, padding, dilation):
 class StatPartials:
     """Per-M-tile (sum, sum of squares) rows written by the conv epilogue: tensor [gy, 2, K] fp32. The consuming BatchNorm
     reduces them inside its finalize kernel (ops/batchnorm.batch_stats), so no separate reduction launch is needed."""
-    __slots__ = ("partial", "gy", "K")
+    __slots__ = ("partial", "gy", "K", "pivot")
 
-    def __init__(self, partial, gy, K):
-        self.partial, self.gy, self.K = partial, gy, K
+    def __init__(self, partial, gy, K, pivot=None):
+        """``pivot``: (running mean, folded conv bias or None) when the rows hold sums of (y - pivot), pivot = mean - bias."""
+        self.partial, self.gy, self.K, self.pivot = partial, gy, K, pivot
 
     def sums(self):
+        if self.pivot is not None:
+            raise ValueError("shifted partial sums are finalized by ops/batchnorm.batch_stats, not summed raw")
         out = torch.empty(2 * self.K, device=self.partial.device, dtype=torch.float32)
         L.check(L.hip().dl4j_bn_sum_partials(L.ptr(self.partial), L.c_int(self.gy), L.c_int(self.K), L.ptr(out), None, None, L.stream()),
                 "bn_sum_partials")
@@ -178,7 +181,7 @@ def _launch_epi(x_t, w_t, y_t, geom, Kout, M, accum, acc, sink):
         sink.partial, sink.gy = partial, mt
 
 
-def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False, bn_fin=None):
+def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False, bn_fin=None, pivot=None):
     tile = pick_tile(M, Kout)
     stats = None
     mt = int(L.hip().dl4j_igemm_mtiles(L.c_int64(M), L.c_int(tile)))
@@ -204,6 +207,13 @@ def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False, bn_fin=
                                                 L.c_int(1 if accum else 0), None, ptrs, fp, L.ptr(tk[1]), L.ptr(tk[0]), L.stream()),
                     "igemm_conv_fin")
             return BN.Finalized(buf, Kout)
+    if want_stats and pivot is not None and pivot[0] is not None:
+        pm, pb = pivot
+        ok = all(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == Kout and t.device == x_t.device) for t in (pm, pb))
+        if ok:
+            L.check(L.hip().dl4j_igemm_conv_piv(L.ptr(x_t), L.ptr(w_t), L.ptr(y_t), L.ptr(bias), L.ptr(stats), g, L.c_int(tile),
+                                                L.c_int(1 if accum else 0), None, L.ptr(pm), L.ptr(pb), L.stream()), "igemm_conv_piv")
+            return StatPartials(stats, mt, Kout, (pm, pb))
     L.check(L.hip().dl4j_igemm_conv(L.ptr(x_t), L.ptr(w_t), L.ptr(y_t), L.ptr(bias), L.ptr(stats), g, L.c_int(tile),
                                     L.c_int(1 if accum else 0), None, L.stream()), "igemm_conv")
     if not want_stats:
@@ -211,7 +221,7 @@ def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False, bn_fin=
     return StatPartials(stats, mt, Kout)
 
 
-def forward(x, w, b, stride, padding, dilation, want_stats=False, bn_fin=None):
+def forward(x, w, b, stride, padding, dilation, want_stats=False, bn_fin=None, stat_pivot=None):
     """Returns (y, stats) — stats is a StatPartials (per-tile sum / sumsq rows) when want_stats, or a batchnorm.Finalized when
     ``bn_fin`` (batchnorm.FinalizeRequest of the consuming layer) was given and the finalize ran inside the conv launch."""
     N, C, H, W = x.shape
@@ -222,7 +232,7 @@ def forward(x, w, b, stride, padding, dilation, want_stats=False, bn_fin=None):
     geom = (N, H, W, C, OH, OW, K, R, S, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
             OH, OW, 1, 1)
     bias = b.float().contiguous() if b is not None else None
-    sums = _launch(x, w, y, bias, geom, want_stats, K, M, bn_fin=bn_fin)
+    sums = _launch(x, w, y, bias, geom, want_stats, K, M, bn_fin=bn_fin, pivot=stat_pivot)
     return y, sums
 
 

@@ -47,6 +47,35 @@ def test_forward_and_stats(case):
     assert torch.allclose(sums[K:], rq, rtol=1e-3, atol=1e-3 * rq.max().item())
 
 
+def test_forward_statistics_pivot_survives_large_mean():
+    """Statistics epilogue with a pivot (the consuming BatchNorm's running mean): outputs with |mean| >> std, where the unshifted
+    E[y^2] - E[y]^2 of fp32 partial sums loses the variance to cancellation. Reference: fp64 statistics of the stored bf16 outputs."""
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    from deeplearning4j_amd.ops import batchnorm as BN
+    g = torch.Generator(device="cuda").manual_seed(7)
+    N, C, H, K = 16, 64, 28, 64
+    x = (1.0 + 0.1 * torch.randn(N, C, H, H, device="cuda", generator=g)).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (100.0 / C + 0.02 * torch.randn(K, C, 1, 1, device="cuda", generator=g)).bfloat16().contiguous(memory_format=torch.channels_last)
+    M = N * H * H
+    gamma, beta = torch.ones(K, device="cuda"), torch.zeros(K, device="cuda")
+    gvar = torch.ones(K, device="cuda")
+    res = {}
+    for name, gmean in (("pivot", torch.full((K,), 100.0, device="cuda")), ("plain", None)):
+        y, st = IG.forward(x, w, None, (1, 1), (0, 0), (1, 1), want_stats=True, stat_pivot=None if gmean is None else (gmean, None))
+        assert (st.pivot is not None) == (gmean is not None)
+        y2 = y.permute(0, 2, 3, 1).reshape(M, K)
+        dgm, dgv = torch.empty(K, device="cuda"), torch.empty(K, device="cuda")
+        gm = gmean if gmean is not None else torch.zeros(K, device="cuda")
+        mean, invstd, _, _ = BN.batch_stats(y2, gamma, beta, 1e-5, 0.9, gm, gvar, False, None, dgm, dgv, sums=st)
+        yd = y2.double()
+        ref_mean, ref_var = yd.mean(0), yd.var(0, unbiased=False)
+        assert ref_mean.abs().min().item() > 50 * ref_var.sqrt().max().item()          # the regime this test is about
+        var = 1.0 / invstd.double() ** 2 - 1e-5
+        res[name] = ((mean.double() - ref_mean).abs().max().item(), ((var - ref_var).abs() / ref_var).max().item())
+    assert res["pivot"][0] < 1e-3 and res["pivot"][1] < 1e-3, res
+    assert res["plain"][1] > 5 * res["pivot"][1], res            # the cancellation the pivot removes
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_dgrad(case):
     from deeplearning4j_amd.ops import conv_igemm as IG

@@ -220,13 +220,15 @@ def test_segmented_graph_capture_matches_eager(monkeypatch):
     b._grad_sync = buckets.reduce_all
     x = torch.rand(8, 3, 160, 160, device=dev())
     y = _onehot(8, 5).float().to(dev())
-    a.computeGradientAndScore([x], [y])
-    g_ref, s_ref = a._grads.clone(), float(a._score)
-    wmask = torch.zeros_like(g_ref, dtype=torch.bool)       # weight / bias / gamma / beta slots (running stats drift with decay)
+    wmask = torch.zeros_like(a._grads, dtype=torch.bool)       # weight / bias / gamma / beta slots (running stats drift with decay)
     for e in a._entries:
         if e.spec.role != "stat":
             wmask[e.off:e.off + e.spec.numel] = True
     for it in range(7):
+        # the eager reference takes the same (lr = 0) steps: its running statistics — the pivots of the conv statistics epilogues —
+        # then match the captured network's, so both round the batch statistics the same way
+        a.fit(x, y)
+        g_ref, s_ref = a._grads.clone(), float(a._score)
         b.fit(x, y)
         if it >= 3:
             assert b._graph_step.segments is not None
@@ -250,6 +252,7 @@ def test_two_captured_networks_in_one_process():
     m = ResNet50(numClasses=5, inputShape=(3, 160, 160), computeDataType="BFLOAT16", updater=Sgd(0.0))
     a = m.init(device=dev())
     b = m.init(device=dev())
+    _well_conditioned(a, b)      # the untrained zoo init is chaotic (see _well_conditioned): rounding-level changes move its loss by 20 %
     a.enableGraphCapture(True)
     b.enableGraphCapture(True)
     x = torch.rand(8, 3, 160, 160, device=dev())
@@ -263,7 +266,10 @@ def test_two_captured_networks_in_one_process():
     assert a._graph_step.graph_a is not None and b._graph_step.graph_a is not None
     s0 = scores[0][0]
     for sa, sb in scores:
-        assert abs(sa - s0) < 1e-3 * abs(s0) and abs(sb - s0) < 1e-3 * abs(s0), scores
+        # the two networks go through identical arithmetic every iteration ...
+        assert abs(sa - sb) < 1e-4 * abs(s0), scores
+        # ... and across iterations only the statistics pivots (running means, lr = 0) move: rounding-level differences
+        assert abs(sa - s0) < 2e-2 * abs(s0), scores
     rel = (a._grads - b._grads).norm() / a._grads.norm()
     assert rel < 1e-3, float(rel)
 
@@ -321,6 +327,8 @@ def test_wgrad_side_stream_matches_main_stream_eager_and_captured():
     x = torch.rand(8, 3, 160, 160, device=dev())
     y = _onehot(8, 5).float().to(dev())
     ref = m.init(device=dev())
+    _well_conditioned(ref)
+    p0 = ref.params().clone()
     ref.computeGradientAndScore([x], [y])
     torch.cuda.synchronize()
     g_ref = ref._grads.clone()
@@ -328,22 +336,30 @@ def test_wgrad_side_stream_matches_main_stream_eager_and_captured():
     for e in ref._entries:
         if e.spec.role != "stat":
             wmask[e.off:e.off + e.spec.numel] = True
+    # single-stream reference after the same six (lr = 0) steps the captured network takes: same running statistics, hence the
+    # same statistics pivots in the conv epilogues
+    for it in range(6):
+        ref.fit(x, y)
+    torch.cuda.synchronize()
+    g_ref6 = ref._grads.clone()
     streams.set_enabled(True)
     try:
         a = m.init(device=dev())
+        a.setParams(p0)
         a.computeGradientAndScore([x], [y])
         assert streams._side is not None and not streams._pending and not streams._held      # forked, and joined at scope exit
         torch.cuda.synchronize()
         rel = ((a._grads - g_ref)[wmask]).norm() / g_ref[wmask].norm()
         assert rel < 1e-3, float(rel)
         b = m.init(device=dev())
+        b.setParams(p0)
         b.enableGraphCapture(True)
         for it in range(6):
             b.fit(x, y)
         assert b._graph_step.graph_a is not None
         torch.cuda.synchronize()
-        rel = ((b._grads - g_ref)[wmask]).norm() / g_ref[wmask].norm()
-        assert rel < 1e-3, float(rel)
+        rel = ((b._grads - g_ref6)[wmask]).norm() / g_ref6[wmask].norm()
+        assert rel < 5e-3, float(rel)
     finally:
         streams.set_enabled(False)
 
