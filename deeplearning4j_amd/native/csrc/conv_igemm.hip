@@ -18,6 +18,7 @@
 // double-buffered LDS with register staging (global loads for tile t+1 issued before the MFMAs of
 // tile t, LDS write after), XOR-swizzled 16-byte chunks so ds_read_b128 / tr reads are bank
 // conflict free, XCD-aware workgroup->tile map so tiles sharing an A panel share an L2.
+#include <type_traits>
 #include "common.h"
 #include "ticket.h"
 
@@ -62,8 +63,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
 }
 
-template <int BM, int BN, bool FIN, int EPI = 0>
+// BIG: the gathered operand has >= 2^31 elements (288 GB parts hold such activations): row base offsets are 64-bit. A template
+// parameter so the usual instantiation keeps its 32-bit address arithmetic (fewer VGPRs, no 64-bit adds per load).
+template <int BM, int BN, bool FIN, int EPI = 0, bool BIG = false>
 __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
+  typedef typename std::conditional<BIG, int64_t, int>::type aoff_t;
   constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA blocks per wave in M / N
   constexpr int AI = BM / 32, BI = BN / 32;   // 16-byte loads per thread per tile for A / B
   constexpr int PITCH_C = BN * 2 + 16;
@@ -78,7 +82,8 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   const int wm = wid >> 1, wn = wid & 1;
   const int chunk = tid & 7, lrow = tid >> 3;
 
-  int a_base[AI], a_ih0[AI], a_iw0[AI];
+  aoff_t a_base[AI];
+  int a_ih0[AI], a_iw0[AI];
   const int OHW = p.OH * p.OW;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
@@ -88,7 +93,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
       const int oh = rem / p.OW, ow = rem - oh * p.OW;
       a_ih0[i] = oh * p.sh - p.ph;
       a_iw0[i] = ow * p.sw - p.pw;
-      a_base[i] = ((n * p.H + a_ih0[i]) * p.W + a_iw0[i]) * p.C;
+      a_base[i] = (((aoff_t)n * p.H + a_ih0[i]) * p.W + a_iw0[i]) * p.C;
     } else {
       a_ih0[i] = -(1 << 20); a_iw0[i] = -(1 << 20); a_base[i] = 0;
     }
@@ -107,7 +112,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
       const int ih = a_ih0[i] + r * p.dh, iw = a_iw0[i] + s * p.dw;
       const bool ok = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
       s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok) v = *reinterpret_cast<const s16x8*>(p.x + (int64_t)(a_base[i] + doff));
+      if (ok) v = *reinterpret_cast<const s16x8*>(p.x + ((int64_t)a_base[i] + doff));
       ra[i] = v;
     }
 #pragma unroll
@@ -377,6 +382,9 @@ static int launch_fwd(IGemmP& p, hipStream_t st) {
   if (smem < epi) smem = epi;
   static DeviceOnceLds lds_attr;
   const int want = 2 * (BM + BN) * 128 > epi ? 2 * (BM + BN) * 128 : epi;
+  const bool big = (int64_t)p.N * p.H * p.W * p.C > 0x7fffffffLL;
+  if (big && (p.fin.cnt != nullptr || p.acc_src != nullptr || p.bnb_partial != nullptr)) return -2;   // 32-bit variants only
+  if ((int64_t)p.M * 1 > 0x7fffffffLL) return -2;
   if (p.fin.cnt != nullptr) {
     static DeviceOnceLds lds_attr_fin;
     lds_attr_fin.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, true>), want);
@@ -389,6 +397,12 @@ static int launch_fwd(IGemmP& p, hipStream_t st) {
     if (smem < 16384) smem = 16384;
     lds_attr_epi.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, false, 1>), want1);
     hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, false, 1>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+    DL4J_RET_LAST();
+  }
+  if ((int64_t)p.N * p.H * p.W * p.C > 0x7fffffffLL) {
+    static DeviceOnceLds lds_attr_big;
+    lds_attr_big.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, false, 0, true>), want);
+    hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, false, 0, true>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
     DL4J_RET_LAST();
   }
   lds_attr.ensure(reinterpret_cast<const void*>(&igemm_fwd_kernel<BM, BN, false>), want);

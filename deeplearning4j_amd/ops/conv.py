@@ -91,7 +91,7 @@ def conv2d_forward(x, w, b, stride, padding, dilation, want_stats=False, bn_fin=
 def dgrad_epilogue_ok(dz, x, w, stride, padding, dilation, w_dgrad):
     """True when the data gradient of this call runs on the implicit-GEMM kernel whose epilogue can add a masked gradient and
     emit BatchNorm-backward partial sums (ops/conv_igemm.dgrad acc_masked / bn_sink)."""
-    if w_dgrad is None or dz.dtype != torch.bfloat16:
+    if w_dgrad is None or dz.dtype != torch.bfloat16 or dz.numel() > (1 << 31) - 1:      # fused epilogue: 32-bit operand offsets only
         return False
     if not (_hip_eligible(x, w, stride, padding, dilation) and _prefer_r1(x, w, stride, padding, dilation)):
         return False

@@ -39,7 +39,9 @@ def supported(x, w, stride, padding, dilation):
         return False
     if not x.is_contiguous(memory_format=torch.channels_last) or not _ohwi_contig(w):
         return False
-    if x.numel() > _MAX_ELEMS:
+    # operands of 2^31 elements and more run on the 64-bit-offset instantiation of the kernel (native/csrc/conv_igemm.hip BIG);
+    # the row count N * OH * OW itself stays a 32-bit quantity
+    if x.shape[0] * x.shape[2] * x.shape[3] > _MAX_ELEMS:
         return False
     return True
 
@@ -189,7 +191,7 @@ def _launch(x_t, w_t, y_t, bias, geom, want_stats, Kout, M, accum=False, bn_fin=
         # own buffer per call (not the shared scratch): two convs may run before their fused BN node consumes both
         stats = torch.empty(mt * 2 * Kout, device=x_t.device, dtype=torch.float32)
     g = (ctypes.c_int * 19)(*geom)
-    if want_stats and bn_fin is not None and bn_fin.ok():
+    if want_stats and bn_fin is not None and bn_fin.ok() and x_t.numel() <= _MAX_ELEMS:
         from . import batchnorm as BN
         ngroups = (mt + 31) // 32
         ntiles = Kout // _TILES[tile][1]
@@ -249,7 +251,7 @@ def wgrad_supported(x, w):
 
 def dgrad_supported(w, stride, padding, dz=None):
     """``dz``: the incoming gradient; dgrad reuses the forward kernel with dz as the gathered operand, whose offsets are 32-bit."""
-    if dz is not None and dz.numel() > _MAX_ELEMS:
+    if dz is not None and dz.shape[0] * dz.shape[2] * dz.shape[3] > _MAX_ELEMS:
         return False
     R, S = w.shape[2], w.shape[3]
     if tuple(stride) == (1, 1):

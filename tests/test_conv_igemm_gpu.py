@@ -288,3 +288,38 @@ def test_bn_backward_fused_second_stage_equals_two_launch_form():
             assert torch.equal(a, b)                        # the fused form is deterministic
     cnt, _ = BN.ticket_ws(x.device)
     assert int(cnt.abs().sum()) == 0
+
+
+def test_forward_and_dgrad_with_more_than_2_31_operand_elements():
+    """64-bit operand offsets (the BIG instantiation): a 4.3 GB bf16 activation tensor. Every image of the big batch must equal, bit for
+    bit, what the 32-bit kernel computes on that image alone (same tile arithmetic, same reduction order)."""
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 << 30:
+        pytest.skip("needs ~20 GB of device memory")
+    N, C, H, K = 64, 64, 725, 64
+    assert N * C * H * H > 2 ** 31
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.empty((N, C, H, H), device="cuda", dtype=torch.bfloat16, memory_format=torch.channels_last)
+    for n in range(N):                                   # filled per image: no fp32 temporary of the whole tensor
+        x[n] = torch.randn(C, H, H, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(K, C, 1, 1, device="cuda", generator=g) / 8).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert IG.supported(x, w, (1, 1), (0, 0), (1, 1))
+    y, st = IG.forward(x, w, None, (1, 1), (0, 0), (1, 1), want_stats=True)
+    torch.cuda.synchronize()
+    for n in (0, 31, 63):
+        xs = x[n:n + 1].contiguous(memory_format=torch.channels_last)
+        ys, _ = IG.forward(xs, w, None, (1, 1), (0, 0), (1, 1))
+        assert torch.equal(y[n:n + 1], ys), n
+    s = st.partial.view(st.gy, 2, K).double().sum(0)
+    ref = torch.zeros(K, device="cuda", dtype=torch.float64)
+    for n in range(N):
+        ref += y[n].double().sum((1, 2))
+    assert torch.allclose(s[0], ref, rtol=1e-4, atol=1e-3 * ref.abs().max().item())
+    # data gradient: dz is the big operand now
+    w_dgrad = torch.flip(w, dims=[2, 3]).permute(1, 2, 3, 0).contiguous()
+    assert IG.dgrad_supported(w, (1, 1), (0, 0), y)
+    dx = IG.dgrad(y, x.shape, w_dgrad, (1, 1), (0, 0), (1, 1))
+    for n in (0, 63):
+        d1 = IG.dgrad(y[n:n + 1].contiguous(memory_format=torch.channels_last), (1, C, H, H), w_dgrad, (1, 1), (0, 0), (1, 1))
+        assert torch.equal(dx[n:n + 1], d1), n
