@@ -383,8 +383,12 @@ def _well_conditioned(*nets):
 
 def test_resnet50_bf16_gpu_gradients_match_fp32_cpu():
     """Full zoo ResNet-50 graph: bf16 compute on the GPU (own igemm / BN / pooling kernels) against the fp32 CPU network, same
-    parameters and batch: score within 1 %, flat gradient cosine > 0.995, every conv layer's weight-gradient cosine > 0.8 (the
-    earliest layers see the rounding of all 53 layers above them; a single bf16-sized parameter perturbation gives 0.97 there)."""
+    parameters and batch: score within 1 %, flat gradient cosine > 0.995. Per layer the bound is RELATIVE TO A FLOOR measured in the
+    same test: the fp32 CPU network with only its weights and input rounded to bf16 (activations and all arithmetic fp32 — the least
+    any bf16 implementation perturbs) already drops the worst per-layer weight-gradient cosine to 0.94 on this 53-layer graph at
+    batch 8, so "0.95 everywhere" is not reachable in bf16 at all; the GPU pipeline (activations bf16 as well) must stay within 0.08
+    of that floor on every layer and above 0.85 absolutely (measured: 0.88 worst, tools/debug_layer_cosines.py,
+    profiles/r3_bf16_layer_cosines.md)."""
     from tests.test_networks_cpu import _onehot
     from deeplearning4j_amd.models.resnet50 import ResNet50
     a = ResNet50(numClasses=10, inputShape=(3, 160, 160), weightInit="RELU").init(device="cpu")
@@ -402,13 +406,23 @@ def test_resnet50_bf16_gpu_gradients_match_fp32_cpu():
     print("bf16 vs fp32 gradient cosine %.5f, norm ratio %.4f" % (cos, float(gb.norm() / ga.norm())))
     assert cos > 0.995, cos
     assert 0.97 < float(gb.norm() / ga.norm()) < 1.03
-    worst = 1.0
+    # the floor: same fp32 CPU network, weights and input rounded to bf16 once
+    a2 = ResNet50(numClasses=10, inputShape=(3, 160, 160), weightInit="RELU").init(device="cpu")
+    a2.setParams(a.params().clone().view(-1).bfloat16().float())
+    a2.computeGradientAndScore([x.bfloat16().float()], [y])
+    g2 = a2._grads.double()
+
+    def _cos(u, v):
+        return float((u * v).sum() / (u.norm() * v.norm()).clamp_min(1e-30))
+    worst, worst_gap = 1.0, 0.0
     for e in a._entries:
         if e.spec.key == "W":
-            u, v = ga[e.off:e.off + e.spec.numel], gb[e.off:e.off + e.spec.numel]
-            worst = min(worst, float((u * v).sum() / (u.norm() * v.norm()).clamp_min(1e-30)))
-    print("worst per-layer weight-gradient cosine %.4f" % worst)
-    assert worst > 0.8, worst
+            sl = slice(e.off, e.off + e.spec.numel)
+            c_gpu, c_floor = _cos(ga[sl], gb[sl]), _cos(ga[sl], g2[sl])
+            worst, worst_gap = min(worst, c_gpu), max(worst_gap, c_floor - c_gpu)
+            assert c_gpu > c_floor - 0.08, (str(a._layer_key(e.layer_idx)), c_gpu, c_floor)
+    print("worst per-layer weight-gradient cosine %.4f, largest gap to the bf16-rounding floor %.4f" % (worst, worst_gap))
+    assert worst > 0.85, worst
 
 
 @pytest.mark.parametrize("cdt", [None, "HALF"])
