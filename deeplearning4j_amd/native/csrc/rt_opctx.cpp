@@ -14,6 +14,7 @@
 //   * Shape functions are native for every op in the table (calculateOutputShapes2 -> OpaqueShapeList).
 #include "rt_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <dlfcn.h>
 #include <map>
@@ -129,8 +130,11 @@ int legacy_code(DType d) { return d == DT_FLOAT ? 0 : d == DT_BF16 ? 1 : d == DT
 int nn_code(DType d) { return d == DT_FLOAT ? 0 : d == DT_BF16 ? 1 : d == DT_HALF ? 2 : -1; }
 
 // functor ids of legacy_ops.hip (same tables as nd4j/ops/legacy.py)
-enum { B_ADD = 0, B_SUB = 1, B_MUL = 2, B_DIV = 3, B_MAX = 8, B_MIN = 9, B_RELU = 46 };
-enum { U_IDENTITY = 11, U_EXP = 46, U_SIGMOID = 49, U_TANH = 52 };
+enum { B_ADD = 0, B_SUB = 1, B_MUL = 2, B_DIV = 3, B_RSUB = 4, B_RDIV = 5, B_POW = 7, B_MAX = 8, B_MIN = 9, B_FMOD = 16, B_FLOORDIV = 19,
+       B_FLOORMOD = 20, B_SQSUB = 21, B_ELU = 40, B_LRELU = 43, B_RELU = 46, B_RELU6 = 47, B_EQ = 53, B_GT = 54, B_LT = 55, B_GE = 57, B_NE = 59,
+       B_LE = 64 };
+enum { U_CUBE = 6, U_SQUARE = 9, U_IDENTITY = 11, U_EXP = 46, U_SIGMOID = 49, U_SOFTPLUS = 51, U_TANH = 52, U_HARDTANH = 56, U_SOFTSIGN = 57,
+       U_HARDSIGMOID = 58, U_RATIONALTANH = 59, U_RECTIFIEDTANH = 60, U_SELU = 64 };
 
 // ---------------------------------------------------------------------------------------------- helpers
 bool all_device(const OpaqueContext& c) {
@@ -216,6 +220,26 @@ void fill_strides3(const Arr& x, const Arr* y, const Arr& z, Strides3& s) {
 typedef int (*ExecFn)(OpaqueContext&);
 typedef int (*ShapeFn)(const std::vector<const LongType*>& in, const OpaqueContext& args, OpaqueShapeList& out);
 
+template <typename T, int FUNCTOR>
+inline T host_bin_eval(T x, T y) {
+  switch (FUNCTOR) {
+    case B_ADD: return (T)(x + y);
+    case B_SUB: return (T)(x - y);
+    case B_MUL: return (T)(x * y);
+    case B_DIV: return (T)(x / y);
+    case B_RSUB: return (T)(y - x);
+    case B_RDIV: return (T)(y / x);
+    case B_POW: return (T)std::pow((double)x, (double)y);
+    case B_MAX: return x > y ? x : y;
+    case B_MIN: return x < y ? x : y;
+    case B_FMOD: return (T)std::fmod((double)x, (double)y);
+    case B_FLOORDIV: return (T)std::floor((double)x / (double)y);
+    case B_FLOORMOD: { const double r = std::fmod((double)x, (double)y); return (T)((r != 0.0 && ((r < 0.0) != ((double)y < 0.0))) ? r + (double)y : r); }
+    case B_SQSUB: return (T)((x - y) * (x - y));
+    default: return x;
+  }
+}
+
 template <int FUNCTOR>
 int exec_binary(OpaqueContext& c) {
   if (c.in.size() < 2 || c.out.size() < 1) return fail(20, "binary op: 2 inputs and 1 output are required");
@@ -236,14 +260,7 @@ int exec_binary(OpaqueContext& c) {
   if (!all_host(c)) return fail(26, "arrays must be all host or all device");
   auto run = [&](auto tag) {
     typedef decltype(tag) T;
-    switch (FUNCTOR) {
-      case B_ADD: host_binary<T>(a, b, o, bc, [](T x, T y) { return (T)(x + y); }); break;
-      case B_SUB: host_binary<T>(a, b, o, bc, [](T x, T y) { return (T)(x - y); }); break;
-      case B_MUL: host_binary<T>(a, b, o, bc, [](T x, T y) { return (T)(x * y); }); break;
-      case B_DIV: host_binary<T>(a, b, o, bc, [](T x, T y) { return (T)(x / y); }); break;
-      case B_MAX: host_binary<T>(a, b, o, bc, [](T x, T y) { return x > y ? x : y; }); break;
-      default: host_binary<T>(a, b, o, bc, [](T x, T y) { return x < y ? x : y; }); break;
-    }
+    host_binary<T>(a, b, o, bc, [](T x, T y) { return host_bin_eval<T, FUNCTOR>(x, y); });
   };
   switch (dt) {
     case DT_FLOAT: run(float()); return 0;
@@ -317,18 +334,27 @@ int exec_softmax(OpaqueContext& c) {
   return fail(27, "host execution: unsupported data type");
 }
 
+int abi_matmul(OpaqueContext& c, bool ta, bool tb, bool tc, double alpha, double beta);      // rt_opctx_nn.inc: generic strided fp32 GEMM
+
 // matmul: iArgs [transA, transB, transC]; 2-D operands (the batched / higher-rank forms stay with the fallback)
 int exec_matmul(OpaqueContext& c) {
   if (c.in.size() < 2 || c.out.size() < 1) return fail(20, "matmul: 2 inputs and 1 output are required");
   Arr &a = c.in[0], &b = c.in[1], &o = c.out[0];
   if (a.rank() != 2 || b.rank() != 2 || o.rank() != 2) return fail(29, "matmul: the native executor takes rank-2 operands");
   const bool ta = c.i.size() > 0 && c.i[0], tb = c.i.size() > 1 && c.i[1], tc = c.i.size() > 2 && c.i[2];
-  if (tc) return fail(29, "matmul: transposed result is not handled natively");
   const DType dt = dtype_of(a.si);
   if (dtype_of(b.si) != dt || !contiguous_all(c)) return fail(21, "matmul: same-type c-contiguous operands are required");
   const LongType M = ta ? a.dim(1) : a.dim(0), K = ta ? a.dim(0) : a.dim(1), N = tb ? b.dim(0) : b.dim(1);
-  if ((tb ? b.dim(1) : b.dim(0)) != K || o.dim(0) != M || o.dim(1) != N) return fail(22, "matmul: inner / output dimensions do not match");
+  if ((tb ? b.dim(1) : b.dim(0)) != K || o.dim(tc ? 1 : 0) != M || o.dim(tc ? 0 : 1) != N) return fail(22, "matmul: inner / output dimensions do not match");
   const double alpha = c.t.size() > 0 ? c.t[0] : 1.0, beta = c.t.size() > 1 ? c.t[1] : 0.0;
+  {
+    // the MFMA kernel is the "NT" form on device buffers; every other fp32 form (and fp32 host arrays with a transposed result)
+    // runs the generic strided GEMM
+    const int chunk = dt == DT_FLOAT ? 4 : 8;
+    const bool mfma = all_device(c) && !ta && tb && !tc && beta == 0.0 && nn_code(dt) >= 0 && K % chunk == 0 && dtype_of(o.si) == dt;
+    if (!mfma && dt == DT_FLOAT && dtype_of(o.si) == DT_FLOAT && (all_device(c) || tc)) return abi_matmul(c, ta, tb, tc, alpha, beta);
+  }
+  if (tc) return fail(29, "matmul: transposed result is handled natively for fp32 only");
   if (all_device(c)) {
     Hip* h = hip();
     // the MFMA kernel is the "NT" form: A [M,K] row-major, B [N,K] row-major
@@ -470,18 +496,60 @@ int shape_reduce(const std::vector<const LongType*>& in, const OpaqueContext& a,
   return 0;
 }
 
-struct NativeOp { ExecFn exec; ShapeFn shape; };
+#include "rt_opctx_nn.inc"
+
+struct NativeOp { ExecFn exec; ShapeFn shape; std::string name; };
 std::map<LongType, NativeOp>& table() {
   static std::map<LongType, NativeOp> t = [] {
     std::map<LongType, NativeOp> m;
-    auto reg = [&](const char* n, ExecFn e, ShapeFn s) { m[ops_hash(n)] = NativeOp{e, s}; };
+    auto reg = [&](const char* n, ExecFn e, ShapeFn s) { m[ops_hash(n)] = NativeOp{e, s, n}; };
     reg("add", exec_binary<B_ADD>, shape_broadcast); reg("subtract", exec_binary<B_SUB>, shape_broadcast);
     reg("multiply", exec_binary<B_MUL>, shape_broadcast); reg("divide", exec_binary<B_DIV>, shape_broadcast);
     reg("maximum", exec_binary<B_MAX>, shape_broadcast); reg("minimum", exec_binary<B_MIN>, shape_broadcast);
     reg("relu", exec_unary<0>, shape_same); reg("sigmoid", exec_unary<1>, shape_same); reg("tanh", exec_unary<2>, shape_same);
     reg("identity", exec_unary<3>, shape_same);
     reg("softmax", exec_softmax, shape_same); reg("matmul", exec_matmul, shape_matmul); reg("biasadd", exec_biasadd, shape_same);
-    reg("reduce_sum", exec_reduce<0>, shape_reduce); reg("reduce_mean", exec_reduce<1>, shape_reduce);
+    reg("reduce_sum", exec_reduce_any<0>, shape_reduce); reg("reduce_mean", exec_reduce_any<1>, shape_reduce);
+    // ---- rt_opctx_nn.inc
+    reg("reversesubtract", exec_binary<B_RSUB>, shape_broadcast); reg("reversedivide", exec_binary<B_RDIV>, shape_broadcast);
+    reg("squaredsubtract", exec_binary<B_SQSUB>, shape_broadcast); reg("realdiv", exec_binary<B_DIV>, shape_broadcast);
+    reg("floordiv", exec_binary<B_FLOORDIV>, shape_broadcast); reg("floormod", exec_binary<B_FLOORMOD>, shape_broadcast);
+    reg("mod", exec_binary<B_FMOD>, shape_broadcast); reg("Pow", exec_binary<B_POW>, shape_broadcast);
+    reg("equals", exec_compare<B_EQ>, shape_broadcast_bool); reg("not_equals", exec_compare<B_NE>, shape_broadcast_bool);
+    reg("greater", exec_compare<B_GT>, shape_broadcast_bool); reg("greater_equal", exec_compare<B_GE>, shape_broadcast_bool);
+    reg("less", exec_compare<B_LT>, shape_broadcast_bool); reg("less_equal", exec_compare<B_LE>, shape_broadcast_bool);
+    reg("square", exec_act<U_SQUARE, false, 0>, shape_same); reg("cube", exec_act<U_CUBE, false, 0>, shape_same);
+    reg("softplus", exec_act<U_SOFTPLUS, false, 0>, shape_same); reg("softsign", exec_act<U_SOFTSIGN, false, 0>, shape_same);
+    reg("hardtanh", exec_act<U_HARDTANH, false, 0>, shape_same); reg("hardsigmoid", exec_act<U_HARDSIGMOID, false, 0>, shape_same);
+    reg("selu", exec_act<U_SELU, false, 0>, shape_same); reg("rationaltanh", exec_act<U_RATIONALTANH, false, 0>, shape_same);
+    reg("rectifiedtanh", exec_act<U_RECTIFIEDTANH, false, 0>, shape_same);
+    reg("relu6", exec_act<B_RELU6, true, 0>, shape_same); reg("lrelu", exec_act<B_LRELU, true, 10>, shape_same);
+    reg("elu", exec_act<B_ELU, true, 1000>, shape_same);
+    reg("relu_bp", exec_act_bp<0, 0>, shape_same); reg("sigmoid_bp", exec_act_bp<1, 0>, shape_same); reg("tanh_bp", exec_act_bp<2, 0>, shape_same);
+    reg("relu6_bp", exec_act_bp<3, 0>, shape_same); reg("lrelu_bp", exec_act_bp<4, 10>, shape_same); reg("softplus_bp", exec_act_bp<5, 0>, shape_same);
+    reg("softsign_bp", exec_act_bp<6, 0>, shape_same); reg("cube_bp", exec_act_bp<7, 0>, shape_same); reg("hardtanh_bp", exec_act_bp<8, 0>, shape_same);
+    reg("hardsigmoid_bp", exec_act_bp<9, 0>, shape_same); reg("elu_bp", exec_act_bp<10, 1000>, shape_same); reg("selu_bp", exec_act_bp<11, 0>, shape_same);
+    reg("softmax_bp", exec_softmax_bp<0>, shape_same); reg("log_softmax", exec_log_softmax, shape_same); reg("log_softmax_bp", exec_softmax_bp<1>, shape_same);
+    reg("reduce_max", exec_reduce_abi<2>, shape_reduce); reg("reduce_min", exec_reduce_abi<3>, shape_reduce);
+    reg("reduce_sqnorm", exec_reduce_abi<4>, shape_reduce); reg("reduce_norm1", exec_reduce_abi<5>, shape_reduce);
+    reg("reduce_norm2", exec_reduce_abi<6>, shape_reduce); reg("reduce_prod", exec_reduce_abi<7>, shape_reduce);
+    reg("argmax", exec_reduce_abi<8>, shape_reduce_index); reg("argmin", exec_reduce_abi<9>, shape_reduce_index);
+    reg("conv2d", exec_conv2d, shape_conv2d); reg("conv2d_bp", exec_conv2d_bp, shape_conv2d_bp);
+    reg("maxpool2d", exec_pool2d<1>, shape_pool2d<1>); reg("avgpool2d", exec_pool2d<0>, shape_pool2d<0>);
+    reg("maxpool2d_bp", exec_pool2d_bp<1>, shape_same); reg("avgpool2d_bp", exec_pool2d_bp<0>, shape_same);
+    reg("batchnorm", exec_batchnorm, shape_same); reg("batchnorm_bp", exec_batchnorm_bp, shape_like_inputs_but_last);
+    reg("layer_norm", exec_layer_norm, shape_same); reg("layer_norm_bp", exec_layer_norm_bp, shape_like_inputs_but_last);
+    reg("softmax_cross_entropy_loss", exec_sce, shape_sce); reg("softmax_cross_entropy_loss_grad", exec_sce_grad, shape_like_all_inputs);
+    reg("sgd_updater", exec_updater<1, 0>, shape_updater<0>); reg("nesterovs_updater", exec_updater<2, 1>, shape_updater<1>);
+    reg("adam_updater", exec_updater<3, 2>, shape_updater<2>); reg("rms_prop_updater", exec_updater<4, 1>, shape_updater<1>);
+    reg("ada_grad_updater", exec_updater<5, 1>, shape_updater<1>); reg("ada_delta_updater", exec_updater<6, 2>, shape_updater<2>);
+    reg("ada_max_updater", exec_updater<7, 2>, shape_updater<2>); reg("nadam_updater", exec_updater<8, 2>, shape_updater<2>);
+    reg("ams_grad_updater", exec_updater<9, 3>, shape_updater<3>); reg("adabelief_updater", exec_updater<10, 2>, shape_updater<2>);
+    reg("matmul_bp", exec_matmul_bp, shape_first_two); reg("xw_plus_b", exec_xw_plus_b, shape_xw_plus_b);
+    reg("xw_plus_b_bp", exec_xw_plus_b_bp, shape_first_three); reg("biasadd_bp", exec_biasadd_bp, shape_first_two);
+    reg("gather", exec_gather, shape_gather); reg("scatter_add", exec_scatter_add, shape_same); reg("concat", exec_concat, shape_concat);
+    reg("cast", exec_cast, shape_cast); reg("reshape", exec_reshape, shape_reshape); reg("permute", exec_permute, shape_permute);
+    reg("transpose", exec_permute, shape_permute); reg("onehot", exec_onehot, shape_onehot); reg("assign", exec_assign, shape_same);
     return m;
   }();
   return t;
@@ -567,6 +635,19 @@ RT_API int ctxBArg(OpaqueContext* ctx, int k) {
 RT_API void registerCustomOpFallback(void* fn, void* user) { g_fallback = (FallbackFn)fn; g_fallback_user = user; }
 RT_API int nativeOpImplemented(LongType hash) { return table().count(hash) ? 1 : 0; }
 RT_API int nativeOpCount() { return (int)table().size(); }
+// names of the ops with a native executor, '\n'-separated (the native half of a getAllCustomOps-style listing; the embedding
+// runtime marks every other registered op as served by its fallback)
+RT_API const char* nativeOpList() {
+  static std::string s = [] {
+    std::vector<std::string> names;
+    for (auto& kv : table()) names.push_back(kv.second.name);
+    std::sort(names.begin(), names.end());
+    std::string r;
+    for (auto& n : names) { r += n; r += '\n'; }
+    return r;
+  }();
+  return s.c_str();
+}
 
 // Status execCustomOp2(Pointer* extraPointers, LongType hash, OpaqueContext* opContext)   (NativeOps.h:1488)
 RT_API int execCustomOp2(void** /*extraPointers*/, LongType hash, OpaqueContext* ctx) {

@@ -45,7 +45,7 @@ def lib():
             "ctxNumTArgs": (i32, [vp]), "ctxNumIArgs": (i32, [vp]), "ctxNumBArgs": (i32, [vp]), "ctxTArg": (C.c_double, [vp, i32]),
             "ctxIArg": (i64, [vp, i32]), "ctxBArg": (i32, [vp, i32]),
             "registerCustomOpFallback": (None, [vp, vp]), "nativeOpImplemented": (i32, [i64]), "nativeOpCount": (i32, []),
-            "execCustomOp2": (i32, [VPP, i64, vp]),
+            "execCustomOp2": (i32, [VPP, i64, vp]), "nativeOpList": (C.c_char_p, []),
             "calculateOutputShapes2": (vp, [VPP, i64, VPP, VPP, i32, C.POINTER(C.c_double), i32, P64, i32, C.POINTER(C.c_bool), i32,
                                             C.POINTER(C.c_int), i32]),
             "getShapeListSize": (i64, [vp]), "getShape": (P64, [vp, i64]), "deleteShapeList": (None, [vp]),
@@ -78,7 +78,7 @@ def _describe(si):
     return shape, dt
 
 
-def calculate_output_shapes(name: str, inputs: Sequence[torch.Tensor], iArgs=(), tArgs=(), bArgs=()):
+def calculate_output_shapes(name: str, inputs: Sequence[torch.Tensor], iArgs=(), tArgs=(), bArgs=(), dArgs=()):
     """[(shape, dtype)] from the NATIVE shape function of ``name`` (None if the op has none)."""
     rt = lib()
     sis = [shape_info(t) for t in inputs]
@@ -86,8 +86,9 @@ def calculate_output_shapes(name: str, inputs: Sequence[torch.Tensor], iArgs=(),
     t = (C.c_double * max(len(tArgs), 1))(*[float(v) for v in tArgs])
     i = (C.c_int64 * max(len(iArgs), 1))(*[int(v) for v in iArgs])
     b = (C.c_bool * max(len(bArgs), 1))(*[bool(v) for v in bArgs])
+    d = (C.c_int * max(len(dArgs), 1))(*[int(v) for v in dArgs])
     lst = rt.calculateOutputShapes2(None, C.c_int64(rt.ops_hash(name.encode())), None, ips, len(sis), t, len(tArgs), i, len(iArgs), b,
-                                    len(bArgs), None, 0)
+                                    len(bArgs), d, len(dArgs))
     if not lst:
         return None
     try:
@@ -97,13 +98,13 @@ def calculate_output_shapes(name: str, inputs: Sequence[torch.Tensor], iArgs=(),
 
 
 def exec_custom_op(name: str, inputs: Sequence[torch.Tensor], outputs: Optional[Sequence[torch.Tensor]] = None, iArgs=(), tArgs=(),
-                   bArgs=(), stream=None) -> List[torch.Tensor]:
+                   bArgs=(), stream=None, dArgs=()) -> List[torch.Tensor]:
     """Run ``name`` through execCustomOp2. Host tensors travel as (buffer, shapeInfo), GPU tensors as special buffers. Without
     ``outputs`` they are allocated from the native shape function."""
     rt = lib()
     inputs = [t.contiguous() for t in inputs]
     if outputs is None:
-        shapes = calculate_output_shapes(name, inputs, iArgs, tArgs, bArgs)
+        shapes = calculate_output_shapes(name, inputs, iArgs, tArgs, bArgs, dArgs)
         if shapes is None:
             raise NotImplementedError("op '%s' has no native shape function: pass preallocated outputs" % name)
         outputs = [torch.empty(s, dtype=dt, device=inputs[0].device) for s, dt in shapes]
@@ -124,6 +125,8 @@ def exec_custom_op(name: str, inputs: Sequence[torch.Tensor], outputs: Optional[
             rt.setGraphContextIArguments(ctx, (C.c_int64 * len(iArgs))(*[int(v) for v in iArgs]), len(iArgs))
         if bArgs:
             rt.setGraphContextBArguments(ctx, (C.c_bool * len(bArgs))(*[bool(v) for v in bArgs]), len(bArgs))
+        if dArgs:
+            rt.setGraphContextDArguments(ctx, (C.c_int * len(dArgs))(*[int(v) for v in dArgs]), len(dArgs))
         if inputs and inputs[0].is_cuda:
             s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
             rt.setGraphContextCudaContext(ctx, C.c_void_p(s), None, None)
@@ -133,6 +136,21 @@ def exec_custom_op(name: str, inputs: Sequence[torch.Tensor], outputs: Optional[
         return list(outputs)
     finally:
         rt.deleteGraphContext(ctx)
+
+
+def native_op_names() -> List[str]:
+    """Names of the ops that execCustomOp2 runs in C++ / HIP without any fallback."""
+    return [n for n in (lib().nativeOpList() or b"").decode().split("\n") if n]
+
+
+def list_custom_ops() -> dict:
+    """getAllCustomOps-style listing (NativeOps.h getAllCustomOps): every registered op name -> "native" (C++ executor and shape
+    function behind execCustomOp2 / calculateOutputShapes2) or "fallback" (served by the Python op library through
+    registerCustomOpFallback)."""
+    from .ops import custom
+    custom._load_impls()
+    native = set(native_op_names())
+    return {n: ("native" if n in native else "fallback") for n in sorted(set(custom._IMPL) | native)}
 
 
 # ---------------------------------------------------------------------------------------------- fallback into the Python op library
