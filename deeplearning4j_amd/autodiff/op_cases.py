@@ -23,10 +23,12 @@ class Case:
     inputs that are differentiated."""
 
     def __init__(self, ins, i=(), t=(), b=(), d=(), ref=None, check=None, grad=False, gin=None, rtol=1e-5, atol=1e-6, tag="",
-                 bp_out=False):
+                 bp_out=False, canon=None):
         self.ins, self.i, self.t, self.b, self.d = list(ins), list(i), list(t), list(b), list(d)
         self.ref, self.check, self.grad, self.gin, self.rtol, self.atol, self.tag = ref, check, grad, gin, rtol, atol, tag
         self.bp_out = bp_out          # the _bp op also takes the forward output after the incoming gradient (softmax_bp)
+        self.canon = canon            # outputs -> canonical form, applied to the op's and the reference's outputs alike (eigenvector
+        #                               order / phase, ...) before they are compared
 
 
 def _g(seed=0):
@@ -478,8 +480,6 @@ def cases() -> Dict[str, List[Case]]:
     add("non_max_suppression_v3", Case([boxes, scores], i=[3], t=[0.5, 0.0], ref=lambda b, s: torch.tensor([0, 2])))
     add("non_max_suppression_overlaps", Case([torch.tensor([[1.0, 0.9, 0.0], [0.9, 1.0, 0.0], [0.0, 0.0, 1.0]]), scores], i=[3], t=[0.5, 0.0], ref=lambda o, s: torch.tensor([0, 2])))
     add("draw_bounding_boxes", Case([rgb, torch.tensor([[[0.1, 0.1, 0.8, 0.8]], [[0.2, 0.2, 0.6, 0.6]]]), torch.tensor([[1.0, 0.0, 0.0]])], ref=None))
-    add("fake_quant_with_min_max_vars", Case([x34, torch.tensor(-1.0), torch.tensor(1.0)], i=[8], b=[False], ref=None))
-    add("fake_quant_with_min_max_vars_per_channel", Case([x34, -torch.ones(4), torch.ones(4)], i=[8], b=[False], ref=None))
     add("compare_and_bitpack", Case([R(2, 8, seed=116), torch.tensor(0.0)], ref=lambda x, t: torch.tensor([[sum(int(x[r, c] > 0) << (7 - c) for c in range(8))] for r in range(2)], dtype=torch.uint8)))
     add("conv2d_input_bp", Case([I(2, 3, 8, 8), w_khwio, R(2, 5, 8, 8, seed=123)], i=[3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0],
                                 ref=lambda s_, w, gy: F.conv_transpose2d(d64(gy), d64(w).permute(3, 2, 0, 1), padding=1), rtol=1e-4, atol=1e-5))
@@ -501,6 +501,8 @@ def cases() -> Dict[str, List[Case]]:
     add("print_variable", Case([x34]))
     add("print_affinity", Case([x34]))
     add("expose", Case([x34]))
+    from .op_cases_extra import extend
+    extend(C, add)
     return C
 
 

@@ -178,6 +178,8 @@ def _as_list(o):
 
 
 def _cmp(a, e, rtol, atol):
+    if hasattr(a, "values") and hasattr(e, "values") and not isinstance(a, torch.Tensor):      # StringArray
+        return None if (a.values == e.values) else "strings differ: %s vs %s" % (a.values[:6], e.values[:6])
     if not isinstance(a, torch.Tensor):
         return "output is not a tensor"
     e = e if isinstance(e, torch.Tensor) else torch.as_tensor(e)
@@ -262,6 +264,10 @@ def sweep(device="cpu", names=None, check_grad=True):
                 level = "executed"
                 if c.ref is not None:
                     want = _as_list(c.ref(*c.ins))
+                    if getattr(c, "canon", None) is not None:
+                        outs, want = c.canon(list(outs)), c.canon(list(want))
+                    if len(want) > len(outs):
+                        entry["errors"].append("%s: %d outputs, reference has %d" % (c.tag or "case", len(outs), len(want)))
                     for k, e in enumerate(want):
                         if k >= len(outs):
                             entry["errors"].append("%s: %d outputs, reference has %d" % (c.tag or "case", len(outs), len(want)))
@@ -291,14 +297,15 @@ def sweep(device="cpu", names=None, check_grad=True):
                 entry["errors"].append("%s: %s: %s" % (c.tag or "case", type(ex).__name__, str(ex)[:160]))
         entry["status"] = "failed" if entry["errors"] else (best or "uncovered")
     from .op_cases import SCENARIOS, EXTERNAL
-    for names_, fn in SCENARIOS:
+    from .op_cases_extra import EXTRA_SCENARIOS
+    for names_, fn in SCENARIOS + EXTRA_SCENARIOS:
         try:
             err = fn(device)
         except Exception as ex:                           # noqa: BLE001
             err = "%s: %s" % (type(ex).__name__, str(ex)[:160])
         for n in names_:
-            if n in report and report[n]["status"] == "uncovered":
-                report[n].update(status="failed" if err else "property", cases=1, errors=[err] if err else [])
+            if n in report and report[n]["status"] in ("uncovered", "executed"):
+                report[n].update(status="failed" if err else "property", cases=max(1, report[n]["cases"]), errors=[err] if err else [])
     for n, where in EXTERNAL.items():
         if n in report and report[n]["status"] == "uncovered":
             report[n].update(status="external", errors=[], where=where)

@@ -65,6 +65,11 @@ def platform(name, usable, differentiable=False):
     return deco
 
 
+def _cost_model():
+    from . import cost_model
+    return cost_model
+
+
 def _load_impls():
     global _LOADED
     if not _LOADED:
@@ -174,8 +179,8 @@ class OpContext:
 def _t(x):
     if x is None:
         return None
-    if getattr(x, "_nd4j_opaque", False):
-        return x                      # NDArrayList handles travel through op inputs / outputs as they are
+    if getattr(x, "_nd4j_opaque", False) or type(x).__name__ == "StringArray":
+        return x                      # NDArrayList handles and string arrays travel through op inputs / outputs as they are
     if hasattr(x, "tensor"):
         return x.tensor()
     if isinstance(x, torch.Tensor):
@@ -336,11 +341,18 @@ class OpExecutioner:
             on_gpu = any(isinstance(x, torch.Tensor) and x.is_cuda for x in ins)
             if allow_helpers and self.env.helpersAllowed():
                 tracked = torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in ins)
+                declined = None
                 for usable, fn in _PLATFORM[name]:
                     if (not tracked or getattr(fn, "_differentiable", False)) and usable(ins, i, t, b, d):
+                        # measured cost model (cost_model.py): usable, but the generic route is faster for these arguments
+                        declined = None if tracked else _cost_model().prefer_generic(name, ins, i, t, b, d)
+                        if declined is not None:
+                            continue
                         HELPER_HIT[name] += 1
                         return fn(ins, i, t, b, d)
-                if not ins:
+                if declined is not None:
+                    _helper_fail(name, "cost model: " + declined)
+                elif not ins:
                     _helper_fail(name, "no array inputs: the helper cannot tell the device")
                 elif on_gpu:
                     _helper_fail(name, "autograd-tracked inputs" if tracked and not any(getattr(f, "_differentiable", False) for _, f in _PLATFORM[name])

@@ -904,6 +904,14 @@ class StringArray:
         self.values = list(values)
         self.shape = list(shape) if shape is not None else [len(self.values)]
 
+    def to(self, *a, **k):          # strings live on the host whatever device the numeric operands are on
+        return self
+
+    def __eq__(self, other):
+        return isinstance(other, StringArray) and self.values == other.values and self.shape == other.shape
+
+    __hash__ = None
+
 
 @op("split_string")
 def _split_string(ins, i, t, b, d):

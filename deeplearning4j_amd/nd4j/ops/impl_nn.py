@@ -925,12 +925,12 @@ def _lstm_cell(ins, i, t, b, d):
             zo = zo + c * Wco
         og = torch.sigmoid(zo)
         h = og * torch.tanh(c)
-        return ig, c, fg, og, zc, torch.tanh(c), h
+        return ig, c, fg, og, cc, torch.tanh(c), h          # 4: block input z = tanh(zz) (helpers/cpu/lstm.cpp:196-204)
     # classic lstmCell: x, hLast, cLast, Wx, Wh, Wc(peephole diag 3n), Wp(projection), b
     x, hLast, cLast, Wx, Wh, Wc, Wp, bias = ins[:8]
     n = cLast.shape[-1]
     z = x @ Wx + hLast @ Wh + bias
-    zi, zf, zo, zg = z[..., :n], z[..., n:2 * n], z[..., 2 * n:3 * n], z[..., 3 * n:]
+    zi, zf, zg, zo = z[..., :n], z[..., n:2 * n], z[..., 2 * n:3 * n], z[..., 3 * n:]      # i, f, c, o (helpers/cpu/lstm.cpp:81-84)
     peephole = bool(i[0]) if i else False
     if peephole:
         zi, zf = zi + cLast * Wc[:n], zf + cLast * Wc[n:2 * n]
@@ -952,6 +952,16 @@ def _lstm_block(ins, i, t, b, d):
     if ins[0].dim() == 0 or (ins[0].numel() == 1 and not ins[0].is_floating_point()):
         ins = ins[1:]        # leading maxTSLength
     x = ins[0]
+    if not (len(ins) >= 8 and ins[3].dim() == 2 and ins[3].shape[0] == x.shape[-1] + ins[2].shape[-1]):
+        # `lstm` (generic/nn/recurrent/lstm.cpp:35-60): x [time, bS, nIn], h0, c0, Wx, Wh, Wc, Wp, b -> h [time, bS, numProj],
+        # c [time, bS, numUnits]; one classic lstmCell per step
+        h, c = ins[1], ins[2]
+        hs, cs = [], []
+        for tt in range(x.shape[0]):
+            h, c = _lstm_cell([x[tt], h, c] + list(ins[3:]), i, t, b, d)
+            hs.append(h)
+            cs.append(c)
+        return torch.stack(hs), torch.stack(cs)
     fmt = int(i[1]) if len(i) > 1 else 0          # 0 TNS, 1 NST, 2 NTS
     xs = {0: lambda: x, 1: lambda: x.permute(2, 0, 1), 2: lambda: x.permute(1, 0, 2)}[fmt]()
     c, y = ins[1], ins[2]

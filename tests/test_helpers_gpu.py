@@ -6,6 +6,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _kernels_not_cost_model():
+    """These tests check the hand-written kernels themselves: the measured cost model (which would route some shapes to ATen) is off."""
+    from deeplearning4j_amd.nd4j.ops import cost_model
+    old, cost_model.ENABLED = cost_model.ENABLED, False
+    yield
+    cost_model.ENABLED = old
+
+
 def dev():
     return torch.device("cuda")
 

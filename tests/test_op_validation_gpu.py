@@ -7,6 +7,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _kernels_not_cost_model():
+    """These tests check the hand-written kernels themselves: the measured cost model (which would route some shapes to ATen) is off."""
+    from deeplearning4j_amd.nd4j.ops import cost_model
+    old, cost_model.ENABLED = cost_model.ENABLED, False
+    yield
+    cost_model.ENABLED = old
+
+
 def test_registry_sweep_on_gpu_and_helper_accounting():
     from deeplearning4j_amd.autodiff.validation import sweep, summarize
     from deeplearning4j_amd.nd4j.ops.custom import OpExecutioner, _PLATFORM
@@ -15,7 +24,7 @@ def test_registry_sweep_on_gpu_and_helper_accounting():
     s = summarize(rep)
     failed = {n: e["errors"] for n, e in rep.items() if e["status"] == "failed"}
     assert not failed, failed
-    assert s["covered_pct"] >= 93.0 and s["grad_failed"] == 0, s
+    assert s["covered_pct"] >= 99.9 and s["grad_failed"] == 0 and s["reference"] >= 480, s
     st = OpExecutioner.helperStatistics()
     ran = set(st["hit"])
     assert len(ran) >= 40, sorted(ran)                                  # hand-written routes really executed during the sweep

@@ -77,17 +77,26 @@ def cases():
 
 def main():
     ex = OpExecutioner.getInstance()
-    lines = ["# Custom-op micro-benchmarks on MI355X: HIP platform route vs generic (ATen) implementation, us per call (tools/op_microbench.py)", "",
-             "| case | HIP route us | generic us | speed-up | helper ran |", "|---|---:|---:|---:|---|"]
+    from deeplearning4j_amd.nd4j.ops import cost_model
+    lines = ["# Custom-op micro-benchmarks on MI355X: the route the executioner takes by default (platform helper unless the measured cost "
+             "model declines it) vs the generic (ATen) implementation, us per call (tools/op_microbench.py)", "",
+             "| case | default route us | generic us | default vs generic | route taken | forced helper us |", "|---|---:|---:|---:|---|---:|"]
     for label, name, ins, i, t, b in cases():
         row = [label]
         try:
+            cost_model.ENABLED = True
             hit0 = HELPER_HIT[name]
             ex._run(name, ins, i, t, b, [], True)
             ran = HELPER_HIT[name] > hit0
-            th = timed(lambda: ex._run(name, ins, i, t, b, [], True), 30)
+            why = cost_model.prefer_generic(name, ins, i, t, b, [])
+            td = timed(lambda: ex._run(name, ins, i, t, b, [], True), 30)
             tg = timed(lambda: ex._run(name, ins, i, t, b, [], False), 30)
-            row += ["%.1f" % th, "%.1f" % tg, "%.2fx" % (tg / th), "yes" if ran else "NO (generic both times)"]
+            if not ran:
+                td = tg = min(td, tg)          # the same code ran both times: one number, not two samples of its noise
+            cost_model.ENABLED = False
+            tf = timed(lambda: ex._run(name, ins, i, t, b, [], True), 30)
+            cost_model.ENABLED = True
+            row += ["%.1f" % td, "%.1f" % tg, "%.2fx" % (tg / td), "helper" if ran else "generic (cost model: %s)" % (why or "?")[:90], "%.1f" % tf]
         except Exception as e:                     # keep the table going; the failure is part of the report
             row += ["failed: %s" % (str(e)[:80].replace("|", "/"),), "", "", ""]
         lines.append("| " + " | ".join(row) + " |")
