@@ -122,6 +122,171 @@ def _sce_logits(sd, o, ins, outs, gs):
     return [sd._op("multiply", [dl, g], name=o.name + "_gl")[0], None]
 
 
+# ---- losses: <name>_grad(predictions, weights, labels) -> d/d(predictions, weights, labels) of the reduced loss, chained with the
+# incoming gradient (a scalar for the reduced forms, one value per example for reduction mode "none")
+def _loss_rule(sd, o, ins, outs, gs):
+    if len(ins) != 3:
+        return None
+    res = sd._op(o.opName + "_grad", list(ins), nOut=3, name=o.name + "_grad", **_args(o))
+    return [sd._op("multiply", [r, gs[0]], name="%s_g%d" % (o.name, k))[0] for k, r in enumerate(res)]
+
+
+for _n in ("softmax_cross_entropy_loss", "sigm_cross_entropy_loss", "mean_sqerr_loss", "absolute_difference_loss", "huber_loss", "log_loss",
+           "hinge_loss", "log_poisson_loss", "cosine_distance_loss", "mean_pairwssqerr_loss"):
+    RULES[_n] = _loss_rule
+
+
+def _static_shape(sd, v):
+    a = sd._arrays.get(v.name)
+    if a is not None:
+        return list(a.shape)
+    sh = getattr(v, "shape", None)
+    return list(sh) if sh is not None and all(s is not None and s >= 0 for s in sh) else None
+
+
+@rule("embedding_lookup", "gather")
+def _rows_lookup(sd, o, ins, outs, gs):
+    # table [V, D] indexed by integer ids along axis 0: d(table) = segment sum of the incoming rows by id (unsorted_segment_sum has
+    # a platform kernel); ids get no gradient
+    if len(ins) < 2 or (o.opName == "gather" and o.iArgs and int(o.iArgs[0]) != 0):
+        return None
+    shp = _static_shape(sd, ins[0])
+    if shp is None or len(shp) != 2:
+        return None
+    g2 = sd._op("reshape", [gs[0]], iArgs=[-1, int(shp[1])], name=o.name + "_g2d")[0]
+    i1 = sd._op("reshape", [ins[1]], iArgs=[-1], name=o.name + "_ids")[0]
+    dt = sd._op("unsorted_segment_sum", [g2, i1], iArgs=[int(shp[0])], name=o.name + "_bp")[0]
+    return [dt] + [None] * (len(ins) - 1)
+
+
+@rule("dot_product_attention_v2")
+def _attention_v2(sd, o, ins, outs, gs):
+    # dot_product_attention_v2_bp(q, v, k, dL/dout, masks...) -> dq, dv, dk (the fused flash backward on the GPU)
+    if len(ins) < 3:
+        return None
+    res = sd._op("dot_product_attention_v2_bp", list(ins[:3]) + [gs[0]] + list(ins[3:]), nOut=3, name=o.name + "_bp", **_args(o))
+    return list(res) + [None] * (len(ins) - 3)
+
+
+def _lstm_layer(sd, o, ins, outs, gs):
+    # lstmLayer_bp(inputs..., one gradient per returned output) -> gradients of the floating-point inputs in input order; the
+    # sequence-length input (bArgs[1]) is integral and gets none
+    bb = list(o.bArgs) + [False] * 8
+    gl = [g if g is not None else sd._op("zeros_as", [ov], name=ov.name + "-zgrad")[0] for g, ov in zip(gs, outs)]
+    pos = [0, 1, 2]
+    k = 3
+    for flag, differentiable in ((bb[0], True), (bb[1], False), (bb[2], True), (bb[3], True), (bb[4], True)):
+        if flag:
+            if differentiable:
+                pos.append(k)
+            k += 1
+    if k != len(ins):
+        return None
+    res = sd._op("lstmLayer_bp", list(ins) + gl, nOut=len(pos), name=o.name + "_bp", **_args(o))
+    out = [None] * len(ins)
+    for p_, r in zip(pos, res):
+        out[p_] = r
+    return out
+
+
+_lstm_layer.multi = True          # takes the gradients of all outputs (absent ones as zeros)
+RULES["lstmLayer"] = _lstm_layer
+
+
+# ---- legacy (opType, opNum) ops: derivative transforms of the same families or closed forms
+def _lg(sd, family, op_name, inputs, name, **kw):
+    from .samediff import OpType
+    from ..nd4j.ops import legacy as LG
+    fam_type = {"transform_same": OpType.TRANSFORM_SAME, "transform_strict": OpType.TRANSFORM_STRICT, "transform_float": OpType.TRANSFORM_FLOAT,
+                "scalar": OpType.SCALAR}[family]
+    return sd._op(op_name.lower(), list(inputs), name=name, opType=fam_type, opNum=LG.op_num(family, op_name), **kw)[0]
+
+
+def _mul(sd, a, b, name):
+    return sd._op("multiply", [a, b], name=name)[0]
+
+
+_STRICT_DERIVATIVE = {"tanh": "TanhDerivative", "sigmoid": "SigmoidDerivative", "hardtanh": "HardTanhDerivative", "softsign": "SoftSignDerivative",
+                      "selu": "SELUDerivative", "hardsigmoid": "HardSigmoidDerivative", "rationaltanh": "RationalTanhDerivative",
+                      "rectifiedtanh": "RectifiedTanhDerivative", "swish": "SwishDerivative", "logsigmoid": "LogSigmoidDerivative",
+                      "cube": "CubeDerivative", "gelu": "GELUDerivative", "precisegelu": "PreciseGELUDerivative", "mish": "MishDerivative"}
+
+
+def _legacy_rule(sd, o, ins, outs, gs):
+    """Gradient ops of a legacy transform / scalar / pairwise / reduce node, or None (-> generic VJP)."""
+    from .samediff import OpType
+    from ..nd4j.ops import legacy as LG
+    t, nm, g, x = o.opType, o.opName.lower(), gs[0], ins[0]
+    if t == OpType.TRANSFORM_STRICT:
+        fam = LG.TRANSFORM_STRICT.get(o.opNum, "")
+        if fam.lower() != nm:
+            return None
+        if nm in _STRICT_DERIVATIVE:
+            try:
+                d = _lg(sd, "transform_strict", _STRICT_DERIVATIVE[nm], [x], o.name + "_d")
+            except KeyError:
+                return None
+            return [_mul(sd, g, d, o.name + "_bp")]
+        if nm == "exp":
+            return [_mul(sd, g, outs[0], o.name + "_bp")]
+        if nm == "log":
+            return [sd._op("divide", [g, x], name=o.name + "_bp")[0]]
+        if nm == "softplus":
+            return [_mul(sd, g, _lg(sd, "transform_strict", "Sigmoid", [x], o.name + "_d"), o.name + "_bp")]
+        if nm == "sin":
+            return [_mul(sd, g, _lg(sd, "transform_strict", "Cosine", [x], o.name + "_d"), o.name + "_bp")]
+        if nm == "cosine":
+            return [_lg(sd, "transform_same", "Neg", [_mul(sd, g, _lg(sd, "transform_strict", "Sin", [x], o.name + "_d"), o.name + "_m")], o.name + "_bp")]
+        return None
+    if t == OpType.TRANSFORM_SAME:
+        fam = LG.TRANSFORM_SAME.get(o.opNum, "").lower()
+        if fam != nm:
+            return None
+        if nm == "neg":
+            return [_lg(sd, "transform_same", "Neg", [g], o.name + "_bp")]
+        if nm == "square":
+            return [_lg(sd, "scalar", "Multiply", [_mul(sd, g, x, o.name + "_m")], o.name + "_bp", tArgs=[2.0])]
+        if nm == "abs":
+            return [_mul(sd, g, _lg(sd, "transform_same", "Sign", [x], o.name + "_d"), o.name + "_bp")]
+        if nm in ("identity", "copy"):
+            return [g]
+        return None
+    if t == OpType.TRANSFORM_FLOAT:
+        if LG.TRANSFORM_FLOAT.get(o.opNum, "").lower() == nm == "sqrt":
+            q = sd._op("divide", [g, outs[0]], name=o.name + "_q")[0]
+            return [_lg(sd, "scalar", "Multiply", [q], o.name + "_bp", tArgs=[0.5])]
+        return None
+    if t == OpType.SCALAR and len(ins) == 1:
+        fam = LG.SCALAR.get(o.opNum, "").lower() if hasattr(LG, "SCALAR") else ""
+        sc = o.scalar if o.scalar is not None else (o.tArgs[0] if o.tArgs else None)
+        if fam != nm or sc is None or isinstance(sc, torch.Tensor):
+            return None
+        sc = float(sc)
+        if nm in ("add", "subtract"):
+            return [g]
+        if nm == "multiply":
+            return [_lg(sd, "scalar", "Multiply", [g], o.name + "_bp", tArgs=[sc])]
+        if nm == "divide" and sc != 0.0:
+            return [_lg(sd, "scalar", "Multiply", [g], o.name + "_bp", tArgs=[1.0 / sc])]
+        if nm == "reversesubtract":
+            return [_lg(sd, "transform_same", "Neg", [g], o.name + "_bp")]
+        return None
+    if t == OpType.PAIRWISE and len(ins) == 2:
+        fam = LG.PAIRWISE.get(o.opNum, "").lower()
+        if fam == nm and nm in ("add", "subtract", "multiply", "divide"):
+            return list(sd._op(nm + "_bp", [ins[0], ins[1], g], nOut=2, name=o.name + "_bp"))
+        return None
+    if t in (OpType.REDUCE_SAME, OpType.REDUCE_FLOAT) and len(ins) == 1:
+        table = LG.REDUCE_SAME if t == OpType.REDUCE_SAME else LG.REDUCE_FLOAT
+        fam = table.get(o.opNum, "").lower()
+        custom = {"sum": "reduce_sum_bp", "mean": "reduce_mean_bp", "max": "reduce_max_bp", "min": "reduce_min_bp", "norm2": "reduce_norm2_bp",
+                  "norm1": "reduce_norm1_bp", "squarednorm": "reduce_sqnorm_bp", "prod": "reduce_prod_bp"}.get(nm)
+        if fam != nm or custom is None:
+            return None
+        return [sd._op(custom, [x, g], iArgs=[int(d_) for d_ in (o.dimensions or [])], name=o.name + "_bp")[0]]
+    return None
+
+
 class GradFunction:
     """The differentiated graph: ``sd`` holds forward + backward ops, ``grads[name]`` is the variable holding dLoss/dname."""
 
@@ -131,10 +296,10 @@ class GradFunction:
     def gradient_names(self):
         return dict(self.grads)
 
-    def execute(self, placeholders, wrt: Sequence[str]):
+    def execute(self, placeholders, wrt: Sequence[str], listeners=(), at=None, training=False):
         names = [self.grads[n] for n in wrt if n in self.grads]
         with torch.no_grad():
-            res = self.sd._run_graph(self.sd._prep_placeholders(placeholders), names + list(self.sd.lossVariables), False)
+            res = self.sd._run_graph(self.sd._prep_placeholders(placeholders), names + list(self.sd.lossVariables), training, listeners, at)
         out = {}
         for n in wrt:
             g = res.get(self.grads.get(n))
@@ -209,10 +374,11 @@ def create_grad_function(src, wrt: Optional[Sequence[str]] = None) -> GradFuncti
         ins = [sd.variables[n] for n in o.inputs]
         outs = [sd.variables[n] for n in o.outputs]
         res = None
-        r = RULES.get(o.opName) if o.opType in (OpType.CUSTOM, OpType.BOOLEAN, OpType.SHAPE) else None
-        if r is not None and gs[0] is not None and all(g is None for g in gs[1:]):
+        r = RULES.get(o.opName) if o.opType in (OpType.CUSTOM, OpType.BOOLEAN, OpType.SHAPE) else _legacy_rule
+        if r is not None and (getattr(r, "multi", False) or (gs[0] is not None and all(g is None for g in gs[1:]))):
             res = r(sd, o, ins, outs, gs)
             if res is not None:
+                res = list(res) + [None] * (len(ins) - len(res))
                 rule_ops.append(on)
         if res is None:
             # generic vector-Jacobian product of this ONE op: inputs + one gradient per output (zeros where absent)

@@ -22,6 +22,8 @@ import time
 from collections import OrderedDict, defaultdict, deque
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Union
 
+import os
+
 import numpy as np
 import torch
 
@@ -944,9 +946,9 @@ class SameDiff:
                         shadow_ok=False):
         if not self.lossVariables:
             raise RuntimeError("no loss variables set: call setLossVariables / markAsLoss")
-        if getattr(self, "_grad_mode", "autograd") == "graph" and not extra_outputs and all(n in self._arrays for n in wrt):
-            gf = self.createGradFunction(list(wrt))
-            losses, gd = gf.execute(placeholders, list(wrt))
+        gf = self._gradient_graph_for(wrt, extra_outputs, shadow_ok)
+        if gf is not None:
+            losses, gd = gf.execute(placeholders, list(wrt), listeners, at, training=True)
             if device_losses:
                 return [l.detach().sum() for l in losses], gd, {}
             return [float(l.detach().sum()) for l in losses], gd, {}
@@ -1028,11 +1030,44 @@ class SameDiff:
         return self._gradfn_cache[1]
 
     def setGradientMode(self, mode):
-        """'autograd' (default: tape over the session interpreter) or 'graph' (execute the gradient graph of createGradFunction:
-        every backward op is a custom op, so the ``_bp`` platform kernels run)."""
-        assert mode in ("autograd", "graph")
+        """How gradients are computed (SameDiff.java:5013 createGradFunction is the reference's only way):
+
+        * ``'graph'``: execute the gradient graph of :meth:`createGradFunction` - every backward op is a node (``*_bp`` / ``*_grad``
+          custom ops, derivative transforms; ops without a rule as single-op ``__vjp__`` nodes);
+        * ``'autograd'``: a tape over the session interpreter;
+        * ``'auto'`` (default, also ``DL4J_AMD_SD_GRAD_MODE``): the gradient graph whenever EVERY op on the loss path has an analytic
+          rule (no ``__vjp__`` node: those re-run their forward op, which is wrong for random ops and wasteful otherwise), the graph
+          has no control-flow frames and the call does not run on the mixed-precision replicas of the fused GPU training step
+          (bf16 shadow weights with kernels accumulating straight into the flat gradient vector: that machinery hangs off autograd
+          Functions); the tape otherwise."""
+        assert mode in ("autograd", "graph", "auto")
         self._grad_mode = mode
         return self
+
+    def gradientMode(self):
+        return getattr(self, "_grad_mode", None) or os.environ.get("DL4J_AMD_SD_GRAD_MODE", "auto")
+
+    def _gradient_graph_for(self, wrt, extra_outputs=(), shadow_ok=False):
+        """The GradFunction to execute for this call, or None when the tape is the route (see setGradientMode)."""
+        mode = self.gradientMode()
+        if mode == "autograd" or extra_outputs or not wrt or not all(n in self._arrays for n in wrt):
+            return None
+        if mode == "auto":
+            if shadow_ok and getattr(self, "_fused", None) is not None and self.device.type == "cuda":
+                return None
+            key = (len(self.ops), len(self.variables), tuple(self.lossVariables), tuple(wrt))
+            c = getattr(self, "_auto_grad_cache", None)
+            if c is not None and c[0] == key:
+                return c[1]
+            try:
+                gf = self.createGradFunction(list(wrt))
+                if gf.vjp_ops:
+                    gf = None
+            except (NotImplementedError, KeyError, RuntimeError):
+                gf = None
+            self._auto_grad_cache = (key, gf)
+            return gf
+        return self.createGradFunction(list(wrt))
 
     def grad(self, name):
         """Gradient variable handle ``<name>-grad`` (values filled by calculateGradients / fit)."""

@@ -1,0 +1,275 @@
+// Fused GRU sequence kernels for gfx950 (bf16 activations / weights, fp32 gate math): ONE launch per time step does the recurrent
+// GEMM of all three gates, the gate non-linearities and the state blend - forward - and the recurrent gradient GEMM plus the whole
+// cell backward - backward. Between launches only h_t (and, backwards, the pre-activation gradients) exist in memory.
+//
+// Reference: libnd4j's gru layer (ops/declarable/helpers/impl/gru.cpp:123-160, gruTimeLoop -> gruCell per step: mmul(h, Wh), ~10
+// elementwise transforms, 3 temporaries per step) and its gruCellBp (:162-380, four more mmuls per step). The previous form here
+// (rnn_seq.hip: MFMA GEMM launch + cell launch per step) was launch-bound at [mb 64..128, n 512]: two launches and a [mb, 3n]
+// round trip per step. The decomposition below is the one of lstm_persist.hip's step kernels with three gates instead of four.
+//
+// Gate order [r | u | c] (libnd4j): r = sigmoid(xz_r + hz_r), u = sigmoid(xz_u + hz_u), c = tanh(xz_c + r * hz_c),
+// h = u * h_prev + (1 - u) * c, with xz = x . Wx + b (one big GEMM outside) and hz = h_prev . Wh.
+//
+// Forward step: workgroup w owns hidden units [8w, 8w + 8) = 24 gate columns {g * n + 8w + k} (rows 24..31 of the 32-row MFMA tile
+// are fed zeros); 16 waves = (K quarter) x (32-row batch tile); v_mfma_f32_32x32x16_bf16 with A = the gate rows of Wh^T [3n, n]
+// (K-contiguous) and B = h_{t-1} rows, both straight from L2 into registers. In the accumulator layout lane l holds, for batch row
+// l % 32, the three gates (register group = gate) of units 4 * (l / 32) + j, so the cell runs in registers and h_t leaves as one
+// 8-byte store per lane. K quarters 1..3 hand their partial sums to quarter 0 through LDS.
+//
+// Backward step: dh_t = E_t + u_{t+1} * dh_{t+1} (carried in fp32) + dHZ_{t+1} . Wh^T (v_mfma_f32_16x16x32_bf16, K = 3n), then the
+// cell backward in registers writes dXZ_t (gradient of the input projection, = of x . Wx + b) and dHZ_t (gradient of h_{t-1} . Wh).
+// Weight gradients are two large GEMMs over all steps afterwards (dWh = Hprev^T . dHZ, dWx = X^T . dXZ).
+//
+// Host-checked requirements: bf16, n % 128 == 0 (whole MFMA K-steps per K quarter in both directions), mb <= 128, 16-byte aligned
+// operands. Everything else stays on the generic loop.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float g_sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float g_tanh(float x) {
+  const float e = __expf(-2.f * fabsf(x));
+  const float t = (1.f - e) / (1.f + e);
+  return x < 0.f ? -t : t;
+}
+__device__ __forceinline__ uint64_t g_pack4(float a, float b, float c, float d) {
+  return (uint64_t)f2bf(a) | ((uint64_t)f2bf(b) << 16) | ((uint64_t)f2bf(c) << 32) | ((uint64_t)f2bf(d) << 48);
+}
+__device__ __forceinline__ void g_unpack4(uint64_t v, float o[4]) {
+  o[0] = bf2f((bf16_t)(v & 0xffff)); o[1] = bf2f((bf16_t)((v >> 16) & 0xffff));
+  o[2] = bf2f((bf16_t)((v >> 32) & 0xffff)); o[3] = bf2f((bf16_t)(v >> 48));
+}
+
+struct GruFwdP {
+  const bf16_t* xz;        // [mb, 3n] input projection + bias of THIS step
+  const bf16_t* wh_t;      // [3n, ld] recurrent weights transposed: row = gate column, K = n contiguous
+  int64_t ld;
+  const bf16_t* hprev;     // [mb, n]
+  bf16_t* H;               // [mb, n]
+  bf16_t* SV;              // [mb, 4n] saved r, u, c, hz_c - or null (inference)
+  int mb, n;
+};
+
+#define GRU_THREADS 1024
+#define GRU_KSTEPS 8         // 16-wide K-steps per wave held in registers at once (n <= 512 in one pass, longer n loops)
+
+__global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP p) {
+  __shared__ __attribute__((aligned(16))) f32x16 red[3 * 4 * 64];       // partial accumulators of K quarters 1..3 [3][4 tiles][64 lanes]
+  const int n = p.n, mb = p.mb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = wave & 3, kp = wave >> 2;
+  const int u0 = blockIdx.x * 8;
+  const int row = tile * 32 + (lane & 31);
+  const int kq = lane >> 5;
+  const int uq = u0 + kq * 4;
+  const bool tile_on = tile * 32 < mb;
+  const bool row_ok = row < mb;
+  const bool cell_lane = tile_on && row_ok && kp == 0;
+  const int Kq = n >> 2;
+  // everything this wave needs is requested back to back: one exposed memory latency per step
+  uint64_t xr = 0, xu = 0, xc = 0, hpv = 0;
+  if (cell_lane) {
+    const bf16_t* xp = p.xz + (int64_t)row * 3 * n + uq;
+    xr = *(const uint64_t*)(xp);
+    xu = *(const uint64_t*)(xp + n);
+    xc = *(const uint64_t*)(xp + 2 * (int64_t)n);
+    hpv = *(const uint64_t*)(p.hprev + (int64_t)row * n + uq);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (tile_on) {
+    const int gc = lane & 31;                                            // row of the MFMA tile: gate * 8 + unit; gate 3 is padding
+    const bool a_on = gc < 24;
+    const bf16_t* ap = p.wh_t + ((int64_t)(a_on ? (gc >> 3) : 0) * n + u0 + (gc & 7)) * p.ld + kp * Kq + kq * 8;
+    const bf16_t* bp = p.hprev + (int64_t)(row_ok ? row : 0) * n + kp * Kq + kq * 8;
+    const bf16x8_t zero = {};
+    for (int k0 = 0; k0 < Kq; k0 += 16 * GRU_KSTEPS) {
+      bf16x8_t a[GRU_KSTEPS], b[GRU_KSTEPS];
+#pragma unroll
+      for (int i = 0; i < GRU_KSTEPS; ++i) {
+        const int k = k0 + 16 * i;
+        a[i] = (k < Kq && a_on) ? *(const bf16x8_t*)(ap + k) : zero;
+        b[i] = (k < Kq && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < GRU_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+    }
+    if (kp > 0) red[((kp - 1) * 4 + tile) * 64 + lane] = acc;
+  }
+  __syncthreads();
+  if (!cell_lane) return;
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const f32x16 part = red[(kk * 4 + tile) * 64 + lane];
+    acc += part;
+  }
+  float fr[4], fu[4], fc[4], hp[4], hn[4], vr[4], vu[4], vc[4], vh[4];
+  g_unpack4(xr, fr); g_unpack4(xu, fu); g_unpack4(xc, fc); g_unpack4(hpv, hp);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float r = g_sigm(fr[j] + acc[j]);
+    const float u = g_sigm(fu[j] + acc[4 + j]);
+    const float hc = acc[8 + j];
+    const float c = g_tanh(fc[j] + r * hc);
+    vr[j] = r; vu[j] = u; vc[j] = c; vh[j] = hc;
+    hn[j] = u * hp[j] + (1.f - u) * c;
+  }
+  *(uint64_t*)(p.H + (int64_t)row * n + uq) = g_pack4(hn[0], hn[1], hn[2], hn[3]);
+  if (p.SV) {
+    bf16_t* sv = p.SV + (int64_t)row * 4 * n + uq;
+    *(uint64_t*)(sv) = g_pack4(vr[0], vr[1], vr[2], vr[3]);
+    *(uint64_t*)(sv + n) = g_pack4(vu[0], vu[1], vu[2], vu[3]);
+    *(uint64_t*)(sv + 2 * (int64_t)n) = g_pack4(vc[0], vc[1], vc[2], vc[3]);
+    *(uint64_t*)(sv + 3 * (int64_t)n) = g_pack4(vh[0], vh[1], vh[2], vh[3]);
+  }
+}
+
+struct GruBwdP {
+  const bf16_t* E;         // [mb, n] dL/dh_t from the layers above (this step)
+  const bf16_t* wh;        // [n, ld] row j = the 3n gate weights leaving hidden unit j (K = 3n contiguous)
+  int64_t ld;
+  const bf16_t* SV;        // [mb, 4n] of this step
+  const bf16_t* hprev;     // [mb, n]
+  const bf16_t* dhz_next;  // [mb, 3n] gradient of hz of the step processed before this one, or null
+  const float* dhp_in;     // [mb, n] fp32 u_{t+1} * dh_{t+1}, or null
+  bf16_t* dxz;             // [mb, 3n]
+  bf16_t* dhz;             // [mb, 3n]
+  float* dhp_out;          // [mb, n] fp32
+  int mb, n;
+};
+
+#define GRU_BWD_TILES 2      // 16-row batch tiles per wave: mb <= 4 waves * 2 * 16 = 128
+
+__global__ void __launch_bounds__(GRU_THREADS) gru_step_bwd_kernel(GruBwdP p) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[GRU_BWD_TILES * 3 * 4 * 64];
+  const int n = p.n, mb = p.mb, K = 3 * p.n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile0 = wave & 3, kq4 = wave >> 2;
+  const int u0 = blockIdx.x * 8;
+  const int bcol = lane & 15, q = lane >> 4;
+  const bool unit_lane = q < 2 && kq4 == 0;
+  const int uq = u0 + (q & 1) * 4;
+  const int Kq = K >> 2;
+  const bf16_t* ap = p.wh + (int64_t)(u0 + (bcol & 7)) * p.ld + kq4 * Kq + q * 8;
+  f32x4 acc[GRU_BWD_TILES];
+  uint64_t ev[GRU_BWD_TILES], svr[GRU_BWD_TILES], svu[GRU_BWD_TILES], svc[GRU_BWD_TILES], svh[GRU_BWD_TILES], hpv[GRU_BWD_TILES];
+  f32x4 carry[GRU_BWD_TILES];
+#pragma unroll
+  for (int tt = 0; tt < GRU_BWD_TILES; ++tt) {
+    const int tile = tile0 + 4 * tt;
+    acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    carry[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ev[tt] = svr[tt] = svu[tt] = svc[tt] = svh[tt] = hpv[tt] = 0ull;
+    if (tile * 16 >= mb) continue;
+    const int row = tile * 16 + bcol;
+    const bool row_ok = row < mb;
+    if (unit_lane && row_ok) {
+      const int64_t hidx = (int64_t)row * n + uq;
+      ev[tt] = *(const uint64_t*)(p.E + hidx);
+      const bf16_t* sv = p.SV + (int64_t)row * 4 * n + uq;
+      svr[tt] = *(const uint64_t*)(sv); svu[tt] = *(const uint64_t*)(sv + n);
+      svc[tt] = *(const uint64_t*)(sv + 2 * (int64_t)n); svh[tt] = *(const uint64_t*)(sv + 3 * (int64_t)n);
+      hpv[tt] = *(const uint64_t*)(p.hprev + hidx);
+      if (p.dhp_in) carry[tt] = *(const f32x4*)(p.dhp_in + hidx);
+    }
+    if (p.dhz_next != nullptr) {
+      const bf16_t* bp = p.dhz_next + (int64_t)(row_ok ? row : 0) * K + kq4 * Kq + q * 8;
+      const bf16x8_t zero = {};
+#pragma unroll 12
+      for (int k = 0; k < Kq; k += 32) {
+        const bf16x8_t a = *(const bf16x8_t*)(ap + k);
+        bf16x8_t b = *(const bf16x8_t*)(bp + k);
+        b = row_ok ? b : zero;
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[tt], 0, 0, 0);
+      }
+      if (kq4 > 0) red[((tt * 3 + (kq4 - 1)) * 4 + tile0) * 64 + lane] = acc[tt];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int tt = 0; tt < GRU_BWD_TILES; ++tt) {
+    const int tile = tile0 + 4 * tt;
+    if (tile * 16 >= mb) continue;
+    const int row = tile * 16 + bcol;
+    if (!(unit_lane && row < mb)) continue;
+    if (p.dhz_next != nullptr) {
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const f32x4 part = red[((tt * 3 + kk) * 4 + tile0) * 64 + lane];
+        acc[tt] += part;
+      }
+    }
+    float e4[4], r4[4], u4[4], c4[4], h4[4], hp4[4];
+    g_unpack4(ev[tt], e4); g_unpack4(svr[tt], r4); g_unpack4(svu[tt], u4); g_unpack4(svc[tt], c4); g_unpack4(svh[tt], h4);
+    g_unpack4(hpv[tt], hp4);
+    float dr[4], du[4], dc[4], dcr[4];
+    f32x4 dpo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = e4[j] + acc[tt][j] + carry[tt][j];
+      const float r = r4[j], u = u4[j], c = c4[j];
+      dc[j] = d * (1.f - u) * (1.f - c * c);
+      du[j] = d * (hp4[j] - c) * u * (1.f - u);
+      dr[j] = dc[j] * h4[j] * r * (1.f - r);
+      dcr[j] = dc[j] * r;
+      dpo[j] = d * u;
+    }
+    const int64_t hidx = (int64_t)row * n + uq;
+    *(f32x4*)(p.dhp_out + hidx) = dpo;
+    bf16_t* gx = p.dxz + (int64_t)row * K + uq;
+    bf16_t* gh = p.dhz + (int64_t)row * K + uq;
+    const uint64_t pr = g_pack4(dr[0], dr[1], dr[2], dr[3]), pu = g_pack4(du[0], du[1], du[2], du[3]);
+    *(uint64_t*)(gx) = pr; *(uint64_t*)(gx + n) = pu; *(uint64_t*)(gx + 2 * (int64_t)n) = g_pack4(dc[0], dc[1], dc[2], dc[3]);
+    *(uint64_t*)(gh) = pr; *(uint64_t*)(gh + n) = pu; *(uint64_t*)(gh + 2 * (int64_t)n) = g_pack4(dcr[0], dcr[1], dcr[2], dcr[3]);
+  }
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+DL4J_API int dl4j_gru_steps_supported(int mb, int n) { return (mb > 0 && mb <= 128 && n > 0 && n % 128 == 0 && n / 8 <= 4096) ? 1 : 0; }
+
+// xz [T, mb, 3n], wh_t [3n, ld], h0 [mb, n] -> H [T, mb, n], SV [T, mb, 4n] (null for inference). bf16.
+DL4J_API int dl4j_gru_steps_fwd(const void* xz, const void* wh_t, int64_t ld, const void* h0, void* H, void* SV, int T, int mb, int n,
+                                hipStream_t st) {
+  if (T <= 0) return 0;
+  if (!xz || !wh_t || !h0 || !H) return -3;
+  if (!dl4j_gru_steps_supported(mb, n) || ld < n || ld % 8 != 0 || !al16(xz) || !al16(wh_t) || !al16(h0) || !al16(H) || (SV && !al16(SV)))
+    return -2;
+  const size_t hn = (size_t)mb * n;
+  const bf16_t* hp = (const bf16_t*)h0;
+  for (int t = 0; t < T; ++t) {
+    GruFwdP p{(const bf16_t*)xz + 3 * t * hn, (const bf16_t*)wh_t, ld, hp, (bf16_t*)H + t * hn, SV ? (bf16_t*)SV + 4 * t * hn : nullptr, mb, n};
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(n / 8), dim3(GRU_THREADS), 0, st, p);
+    hp = (const bf16_t*)H + t * hn;
+  }
+  DL4J_RET_LAST();
+}
+
+// E [T, mb, n] (dL/dH), wh [n, ld] (ld >= 3n), SV [T, mb, 4n], H [T, mb, n], h0 [mb, n] -> dXZ, dHZ [T, mb, 3n]; carry [2, mb, n] fp32
+// scratch: on return carry[(T - 1) & 1 ... see below] holds u_0 * dh_0, the direct part of dL/dh0 (the caller adds dHZ_0 . Wh^T).
+// Returns the index (0 / 1) of the carry half that holds it, or a negative error code.
+DL4J_API int dl4j_gru_steps_bwd(const void* E, const void* wh, int64_t ld, const void* SV, const void* H, const void* h0, void* dXZ, void* dHZ,
+                                float* carry, int T, int mb, int n, hipStream_t st) {
+  if (T <= 0) return 0;
+  if (!E || !wh || !SV || !H || !h0 || !dXZ || !dHZ || !carry) return -3;
+  if (!dl4j_gru_steps_supported(mb, n) || ld < 3 * (int64_t)n || ld % 8 != 0 || !al16(E) || !al16(wh) || !al16(SV) || !al16(H) || !al16(h0) ||
+      !al16(dXZ) || !al16(dHZ) || !al16(carry))
+    return -2;
+  const size_t hn = (size_t)mb * n;
+  int last = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    const int half = (T - 1 - t) & 1;
+    GruBwdP p{(const bf16_t*)E + t * hn, (const bf16_t*)wh, ld, (const bf16_t*)SV + 4 * t * hn, t > 0 ? (const bf16_t*)H + (t - 1) * hn : (const bf16_t*)h0,
+              t == T - 1 ? nullptr : (const bf16_t*)dHZ + 3 * (t + 1) * hn, t == T - 1 ? nullptr : carry + (size_t)(half ^ 1) * hn,
+              (bf16_t*)dXZ + 3 * t * hn, (bf16_t*)dHZ + 3 * t * hn, carry + (size_t)half * hn, mb, n};
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(n / 8), dim3(GRU_THREADS), 0, st, p);
+    last = half;
+  }
+  const int rc = (int)hipGetLastError();
+  return rc ? -100 - rc : last;
+}

@@ -239,7 +239,7 @@ def _sdpa_v2_bp(ins, i, t, b, d):
     fw, g = list(ins[:n]), ins[n] if len(ins) > n else ins[-1]
     leaves = [x.detach().clone().requires_grad_(True) for x in fw]
     with torch.enable_grad():
-        y = _sdpa_v2(leaves + list(ins[n + 1:]), i, t, [b[0] if b else False, False], d)[0]
+        y = first(_sdpa_v2(leaves + list(ins[n + 1:]), i, t, [b[0] if b else False, False], d))      # (a bare tensor without the weights outputs)
     return torch.autograd.grad(y, leaves, g)
 
 
@@ -1160,9 +1160,9 @@ def _loss(name, per_fn):
         leaves = [pred.detach().clone().requires_grad_(True), w.detach().clone().float().requires_grad_(True),
                   lab.detach().clone().requires_grad_(True) if lab.is_floating_point() else lab]
         with torch.enable_grad():
-            y = f(leaves, i, t, b, d)
+            y = f(leaves, i, t, b, d).sum()          # (the reduction too: the op may be executed under no_grad by a gradient graph)
         req = [v for v in leaves if v.requires_grad]
-        gs = torch.autograd.grad(y.sum(), req, allow_unused=True)
+        gs = torch.autograd.grad(y, req, allow_unused=True)
         return tuple(gg if gg is not None else torch.zeros_like(v) for gg, v in zip(gs, req))
     op(name + "_grad")(g)
 

@@ -233,6 +233,50 @@ def gru_cell_backward(dh, sv, hz, hprev):
     return dxz, dhz, dhp
 
 
+def gru_fused_ok(xz, n):
+    """bf16 sequences whose shape the fused step kernels (native/csrc/gru_seq.hip) take: one launch per step in each direction."""
+    return (os.environ.get("DL4J_AMD_GRU_FUSED", "1") != "0" and L.use_hip(xz) and xz.dtype == torch.bfloat16 and xz.dim() == 3
+            and bool(L.hip().dl4j_gru_steps_supported(L.c_int(xz.shape[1]), L.c_int(n))))
+
+
+class _GruSeqFused(torch.autograd.Function):
+    """gru layer on the fused step kernels: per time step ONE launch does the three-gate recurrent GEMM (MFMA), the gate math and the
+    blend; backwards ONE launch does dHZ_{t+1} . Wh^T and the cell backward. Weight gradients are big GEMMs over all steps."""
+
+    @staticmethod
+    def forward(ctx, xz, h0, Wh):
+        T, mb, n3 = xz.shape
+        n = n3 // 3
+        train = any(ctx.needs_input_grad)          # (grad mode is off inside forward: is_grad_enabled() would always say no)
+        wh_t = Wh.t().contiguous()                               # [3n, n]: row = gate column, K contiguous
+        H = torch.empty(T, mb, n, device=xz.device, dtype=xz.dtype)
+        SV = torch.empty(T, mb, 4 * n, device=xz.device, dtype=xz.dtype) if train else None
+        h0c, xzc = h0.contiguous(), xz.contiguous()
+        L.check(L.hip().dl4j_gru_steps_fwd(L.ptr(xzc), L.ptr(wh_t), L.c_int64(n), L.ptr(h0c), L.ptr(H), L.ptr(SV), L.c_int(T), L.c_int(mb),
+                                           L.c_int(n), L.stream()), "gru_steps_fwd")
+        ctx.save_for_backward(H, SV, h0c, Wh)
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        H, SV, h0, Wh = ctx.saved_tensors
+        if SV is None:
+            raise RuntimeError("gru: backward called on a forward pass that saved no activations")
+        T, mb, n = H.shape
+        dXZ = torch.empty(T, mb, 3 * n, device=H.device, dtype=H.dtype)
+        dHZ = torch.empty_like(dXZ)
+        carry = torch.empty(2, mb, n, device=H.device, dtype=torch.float32)
+        whc = Wh.contiguous()                                    # [n, 3n]: row j = gate weights leaving unit j
+        rc = L.hip().dl4j_gru_steps_bwd(L.ptr(dH.contiguous()), L.ptr(whc), L.c_int64(3 * n), L.ptr(SV), L.ptr(H), L.ptr(h0), L.ptr(dXZ),
+                                        L.ptr(dHZ), L.ptr(carry), L.c_int(T), L.c_int(mb), L.c_int(n), L.stream())
+        if rc < 0:
+            raise RuntimeError("dl4j_gru_steps_bwd failed with status %d" % rc)
+        dh0 = (carry[rc] + (dHZ[0] @ whc.t()).float()).to(H.dtype)
+        Hprev = torch.cat([h0.unsqueeze(0), H[:-1]], 0)
+        dWh = Hprev.reshape(T * mb, n).t() @ dHZ.reshape(T * mb, 3 * n)
+        return dXZ, dh0, dWh
+
+
 class _GruSeq(torch.autograd.Function):
     """gru layer on the native loop: forward = C++ time loop (recurrent GEMM on the MFMA kernel + fused cell), backward = fused cell
     backward per step + one GEMM per step for dh, the weight gradients as big GEMMs over all steps."""
@@ -277,6 +321,8 @@ def gru_sequence(x, h0, Wx, Wh, b):
     xz = x @ Wx
     if b is not None:
         xz = xz + b
+    if gru_fused_ok(xz, Wh.shape[0]):
+        return _GruSeqFused.apply(xz, h0, Wh)
     return _GruSeq.apply(xz, h0, Wh)
 
 

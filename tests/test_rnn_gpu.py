@@ -90,6 +90,43 @@ def test_gru_op_native_loop_matches_reference_math(dtype):
         assert (a_.float() - r_).abs().max().item() < tol * max(1.0, r_.abs().max().item()) * (1 if dtype == torch.float32 else 4)
 
 
+@pytest.mark.parametrize("T,B,nIn,n", [(6, 64, 96, 128), (9, 100, 64, 256), (5, 128, 128, 512)])
+def test_gru_fused_step_kernels_match_torch_gru_forward_and_backward(T, B, nIn, n):
+    """gru_seq.hip (one launch per step per direction, bf16) against torch.nn.GRU in fp32 with the same weights: libnd4j's gate order
+    [r | u | c] is ATen's (r, z, n) and the candidate uses r * (h . Wh_c), so the two are the same function."""
+    from deeplearning4j_amd.nd4j.ops.custom import exec_op
+    from deeplearning4j_amd.ops import lstm as R
+    g = torch.Generator(device="cuda").manual_seed(11)
+    bf = torch.bfloat16
+    x = torch.randn(T, B, nIn, device="cuda", generator=g).to(bf)
+    h0 = (torch.randn(B, n, device="cuda", generator=g) * 0.5).to(bf)
+    Wx = (torch.randn(nIn, 3 * n, device="cuda", generator=g) / nIn ** 0.5).to(bf)
+    Wh = (torch.randn(n, 3 * n, device="cuda", generator=g) / n ** 0.5).to(bf)
+    b = (torch.randn(3 * n, device="cuda", generator=g) * 0.1).to(bf)
+    m = torch.nn.GRU(nIn, n).cuda().float()
+    with torch.no_grad():
+        m.weight_ih_l0.copy_(Wx.float().t()); m.weight_hh_l0.copy_(Wh.float().t()); m.bias_ih_l0.copy_(b.float()); m.bias_hh_l0.zero_()
+    xr, hr = x.float().requires_grad_(True), h0.float().requires_grad_(True)
+    ref = m(xr, hr.unsqueeze(0))[0]
+    dH = torch.randn(T, B, n, device="cuda", generator=g)
+    rgx, rgh, rgwi, rgwh, rgb = torch.autograd.grad(ref, [xr, hr, m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0], dH)
+    ins = [v.detach().clone().requires_grad_(True) for v in (x, h0, Wx, Wh, b)]
+    assert R.gru_fused_ok(torch.empty(T, B, 3 * n, device="cuda", dtype=bf), n)
+    out = exec_op("gru", ins)[0]
+    assert type(out.grad_fn).__name__.startswith("_GruSeqFused")
+    scale = float(ref.abs().max())
+    assert (out.float() - ref).abs().max().item() < 3e-2 * max(1.0, scale)
+    gg = torch.autograd.grad(out, ins, dH.to(bf))
+    for name, a_, r_ in zip(("dx", "dh0", "dWx", "dWh", "db"), gg, (rgx, rgh, rgwi.t(), rgwh.t(), rgb)):
+        err = (a_.float() - r_).abs().max().item()
+        cos = float((a_.float() * r_).sum() / (a_.float().norm() * r_.norm() + 1e-12))
+        assert cos > 0.995 and err < 6e-2 * max(1.0, r_.abs().max().item()), (name, err, cos)
+    # inference form: no saved activations
+    with torch.no_grad():
+        out2 = exec_op("gru", [x, h0, Wx, Wh, b])[0]
+    assert torch.equal(out2, out.detach())
+
+
 def _seq_case(T, mb, n, peep, masked, seed):
     g = torch.Generator().manual_seed(seed)
     xw = (torch.randn(T, mb, 4 * n, generator=g) * 0.5).bfloat16().cuda()
