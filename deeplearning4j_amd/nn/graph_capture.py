@@ -73,15 +73,25 @@ class CapturedTrainStep:
 
     def run(self, x, y):
         net = self.net
-        x = net._prep_features(x)
+        staged = False
+        if self._x is not None and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 \
+                and tuple(x.shape) == tuple(self._x.shape) and net.ctx.channels_last:
+            # image batch straight into the static input: NCHW fp32 -> NHWC compute type in one kernel, no staging copy
+            from ..ops import spatial as SP
+            staged = SP.nchw_f32_to_nhwc(x, self._x.dtype, out=self._x) is not None
+        if not staged:
+            x = net._prep_features(x)
         y = net._prep_labels(y)
-        sig = (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype)
+        if staged and (self._sig is None or self._sig[2:] != (tuple(y.shape), y.dtype)):
+            x, staged = net._prep_features(x), False          # the labels changed shape: buffers are rebuilt below from prepared inputs
+        sig = ((tuple(self._x.shape), self._x.dtype) if staged else (tuple(x.shape), x.dtype)) + (tuple(y.shape), y.dtype)
         if self._sig != sig:
             self.graph_a = self.graph_b = None
             self._seen, self._sig = 0, sig
             self._x = torch.empty_like(x)
             self._y = torch.empty_like(y)
-        self._x.copy_(x, non_blocking=True)
+        if not staged:
+            self._x.copy_(x, non_blocking=True)
         self._y.copy_(y, non_blocking=True)
         if self.graph_a is None:
             if self._seen < self.warmup:

@@ -498,6 +498,13 @@ class BaseNetwork:
 
     def _prep_features(self, x):
         x = self._to_dev(x)
+        if (x.dim() == 4 and self.ctx.channels_last and x.is_cuda and x.dtype == torch.float32 and x.shape[1] <= 4 and x.is_contiguous()
+                and self.ctx.cdtype in (torch.bfloat16, torch.float32) and not x.requires_grad):
+            # image batches (NCHW fp32 from the iterator) -> NHWC compute type in one pass instead of a cast and a permuting copy
+            from ..ops import spatial as SP
+            y = SP.nchw_f32_to_nhwc(x, self.ctx.cdtype)
+            if y is not None:
+                return y
         if x.is_floating_point() and x.dtype != self.ctx.cdtype:
             x = x.to(self.ctx.cdtype)
         if x.dim() == 4 and self.ctx.channels_last:

@@ -131,3 +131,25 @@ def lrn(x, n, k, alpha, beta):
     sq = F.pad(sq, (0, 0, 0, 0, pad, n - 1 - pad))
     s = F.avg_pool3d(sq, (n, 1, 1), stride=1).squeeze(1) * n
     return x / (k + alpha * s) ** beta
+
+
+def nchw_f32_to_nhwc(x, dtype, out=None):
+    """Contiguous NCHW fp32 image batch (C <= 4) -> the same logical [N, C, H, W] tensor in channels-last memory and ``dtype``
+    (fp32 / bf16) with one kernel (native/csrc/layout.hip). Returns None when the kernel does not take the arguments. ``out``: a
+    tensor of that shape / dtype / memory format to write into (the static input of a captured training step)."""
+    from ..native import lib as L
+    if not (L.use_hip(x) and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous() and 1 <= x.shape[1] <= 4
+            and dtype in (torch.float32, torch.bfloat16) and x.numel() > 0):
+        return None
+    n, c, h, w = x.shape
+    if out is not None:
+        if not (out.shape == x.shape and out.dtype == dtype and out.device == x.device and out.permute(0, 2, 3, 1).is_contiguous()):
+            return None
+        y = out
+    elif c == 1:                     # one channel: both formats are the same memory; strides of a size-1 dim are free
+        y = torch.empty((n, h, w, c), device=x.device, dtype=dtype).permute(0, 3, 1, 2)
+    else:
+        y = torch.empty((n, c, h, w), device=x.device, dtype=dtype, memory_format=torch.channels_last)
+    L.check(L.hip().dl4j_nchw_f32_to_nhwc(L.ptr(x), L.ptr(y), L.c_int64(n), L.c_int(c), L.c_int64(h * w), L.c_int(0 if dtype == torch.float32 else 1),
+                                          L.stream()), "nchw_f32_to_nhwc")
+    return y

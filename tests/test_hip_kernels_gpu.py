@@ -519,3 +519,15 @@ def test_softmax_rows_register_resident_forms(dtype, N):
     pf = p.float()
     refd = pf * (dy.float() - (dy.float() * pf).sum(-1, keepdim=True))
     assert (dz.float() - refd).abs().max().item() < tol * max(refd.abs().max().item(), 1e-3) + 1e-6
+
+
+def test_fused_input_staging_matches_cast_then_permute():
+    from deeplearning4j_amd.ops import spatial as SP
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for c, dt in ((3, torch.bfloat16), (3, torch.float32), (1, torch.bfloat16), (4, torch.bfloat16)):
+        x = torch.randn(5, c, 17, 13, device="cuda", generator=g)
+        y = SP.nchw_f32_to_nhwc(x, dt)
+        ref = x.to(dt).contiguous(memory_format=torch.channels_last)
+        assert y.shape == ref.shape and y.dtype == dt and torch.equal(y, ref)
+        assert y.is_contiguous(memory_format=torch.channels_last) or c == 1
+    assert SP.nchw_f32_to_nhwc(torch.randn(2, 8, 4, 4, device="cuda"), torch.bfloat16) is None
