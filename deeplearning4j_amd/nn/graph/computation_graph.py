@@ -26,10 +26,10 @@ import torch
 from ...nd4j.activations import ActivationReLU, ActivationIdentity
 from ..conf import graph as G
 from ..conf import layers as C
-from ..conf.base import BackpropType
+from ..conf.base import BackpropType, ConvolutionMode, PoolingType
 from ..conf.configuration import ComputationGraphConfiguration
 from ..layers import registry
-from ..layers.core import BatchNormalizationImpl, ConvolutionLayerImpl, ActivationLayerImpl
+from ..layers.core import BatchNormalizationImpl, ConvolutionLayerImpl, ActivationLayerImpl, SubsamplingLayerImpl
 from ..layers.recurrent import LSTMImpl, SimpleRnnImpl
 from ..network_base import BaseNetwork
 from ...ops.conv_igemm import MaskedGrad
@@ -103,6 +103,53 @@ class _FusedBNNode(_Node):
         if isinstance(dz, MaskedGrad):
             return [dxa, self.bn2.backward(dz.src, ext_mask_bits=dz.bits)]
         return [dxa, self.bn2.backward(dz)]
+
+
+class _FusedBNPoolNode(_Node):
+    """BN -> ReLU -> MaxPool (the stem of the ImageNet networks) as one forward pass and a backward that never writes the full-resolution
+    activation or its gradient (ops/bn_pool.py); layer by layer whenever the fused kernels do not take the call."""
+    __slots__ = ("bn", "pool", "_st")
+
+    def __init__(self, out, inputs, bn, pool, names):
+        super().__init__(out, inputs, bn, None, False, False, names)
+        self.bn, self.pool, self._st = bn, pool, None
+
+    def forward(self, xs, train, mode=None):
+        from ...ops import bn_pool as BP
+        bn, pc, x = self.bn, self.pool.conf, xs[0]
+        self._st = None
+        if x.dim() == 4 and x.is_cuda and x.dtype == torch.bfloat16:
+            x2, shp = bn._to2d(x)
+            geom = BP.geometry(shp, pc.kernelSize, pc.stride, pc.padding)
+            if x2.is_contiguous() and BP.usable(x2, geom):
+                scale, shift = bn.coefficients(x2, train)
+                y, idx = BP.forward(x2, scale, shift, geom, train)
+                if train:
+                    bn._x2, bn._shp = x2, shp
+                    bn._out2 = bn._z2 = bn._mask_coeffs = bn._mask_bits = None
+                    bn._want_dz = False
+                    self._st = (y, idx, geom)
+                return y.permute(0, 3, 1, 2)
+        return self.pool.forward(bn.forward(x, train, relu=True), train)
+
+    def backward(self, eps, mb):
+        if self._st is None:
+            return [self.bn.backward(self.pool.backward(eps))]
+        from ...ops import bn_pool as BP
+        bn = self.bn
+        y, idx, geom = self._st
+        dy = eps.permute(0, 2, 3, 1)
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        if dy.dtype != y.dtype:
+            dy = dy.to(y.dtype)
+        gamma = bn.params["gamma"].reshape(-1) if "gamma" in bn.params else None
+        beta = bn.params["beta"].reshape(-1) if "beta" in bn.params else None
+        dg = bn.grads["gamma"].reshape(-1) if "gamma" in bn.grads else None
+        db = bn.grads["beta"].reshape(-1) if "beta" in bn.grads else None
+        dx2 = BP.backward(bn._x2, dy, y, idx, gamma, beta, bn._mean, bn._invstd, dg, db, geom)
+        self._st = None
+        return [bn._from2d(dx2, bn._shp)]
 
 
 class _LstmStackNode(_Node):
@@ -231,6 +278,14 @@ class ComputationGraph(BaseNetwork):
             return (isinstance(l, ActivationLayerImpl) and isinstance(l.conf.activationFn, ActivationReLU)
                     and l.conf.idropout is None and conf.vertices[n].preProcessor is None)
 
+        def is_plain_max_pool(n):
+            l = impls.get(n)
+            if not isinstance(l, SubsamplingLayerImpl) or conf.vertices[n].preProcessor is not None or l.conf.idropout is not None:
+                return False
+            c = l.conf
+            return (c.poolingType == PoolingType.MAX and tuple(c.dilation) == (1, 1)
+                    and (c.convolutionMode or ConvolutionMode.Truncate) != ConvolutionMode.Same)
+
         def is_plain_bn(n):
             l = impls.get(n)
             return isinstance(l, BatchNormalizationImpl) and l.conf.idropout is None and conf.vertices[n].preProcessor is None
@@ -251,6 +306,14 @@ class ComputationGraph(BaseNetwork):
                 if is_relu_layer(c):
                     fused_away[n] = c
                     fused_away[c] = c
+                    pl = cons[c][0] if single(c) else None
+                    if pl is not None and is_plain_max_pool(pl):
+                        # BN -> ReLU -> MaxPool (the ImageNet stem): one forward pass, backward without the full-resolution gradient
+                        fused_away[c] = pl
+                        fused_away[n] = pl
+                        fused_away[pl] = pl
+                        nodes[pl] = _FusedBNPoolNode(pl, conf.vertexInputs[n], impls[n], impls[pl], [n, c, pl])
+                        continue
                     nodes[c] = _FusedBNNode(c, conf.vertexInputs[n], impls[n], None, False, [n, c])
                     continue
                 ci = impls.get(c)
