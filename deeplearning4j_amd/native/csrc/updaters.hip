@@ -290,12 +290,38 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
                                                          const int32_t* __restrict__ blk_seg,
                                                          const int32_t* __restrict__ blk_chunk) {
   const CastSeg s = segs[blk_seg[blockIdx.x]];
+  __shared__ __attribute__((aligned(16))) float lds[CAST_LDS_FLOATS];
+  if (s.mode == 1) {
+    // dest [i][k'][o] (k' = K-1-k) <- src [o][i][k], as 64 x 64 transpose tiles (the table holds one block per TILE for these
+    // entries): 256-byte source runs in, 64 consecutive o out, the flip of k resolved on the way out. Destination chunks of a
+    // fixed length (the first version) gathered 36-byte source runs for the 3x3 filters.
+    float* tile = lds;                                   // 64 x 65 floats of the staging array
+    const uint32_t O_ = (uint32_t)s.O, IK_ = (uint32_t)s.I * (uint32_t)s.K, K_ = (uint32_t)s.K;
+    const uint32_t tiles_q = (IK_ + 63) / 64;
+    const uint32_t t = (uint32_t)blk_chunk[blockIdx.x];
+    const uint32_t o0 = (t / tiles_q) * 64, q0 = (t % tiles_q) * 64;
+    const float* sp_ = src + s.src_off;
+    typename CV::T* dp_ = dst + s.dst_off;
+    for (uint32_t idx = threadIdx.x; idx < 4096; idx += 256) {
+      const uint32_t ol = idx >> 6, j = idx & 63;
+      if (o0 + ol < O_ && q0 + j < IK_) tile[ol * 65 + j] = sp_[(o0 + ol) * IK_ + q0 + j];
+    }
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < 4096; idx += 256) {
+      const uint32_t ql = idx >> 6, ol = idx & 63;
+      const uint32_t q = q0 + ql;
+      if (o0 + ol < O_ && q < IK_) {
+        const uint32_t i = q / K_, k = q - i * K_;
+        dp_[(i * K_ + (K_ - 1 - k)) * O_ + o0 + ol] = CV::cv(tile[ol * 65 + ql]);
+      }
+    }
+    return;
+  }
   const int64_t start = (int64_t)blk_chunk[blockIdx.x] * UPD_CHUNK;
   const int64_t end = (start + UPD_CHUNK < s.len) ? start + UPD_CHUNK : s.len;
   // one entry is one weight tensor (< 2^31 elements, checked on the host): 32-bit index math. The permuting modes stage
   // the source through LDS: a destination chunk is contiguous and its sources form a few contiguous runs, so both the
   // global reads and the global writes are coalesced (the first version gathered 4 bytes per 128-byte line).
-  __shared__ float lds[CAST_LDS_FLOATS];
   const uint32_t I = (uint32_t)s.I, K = (uint32_t)s.K, O = (uint32_t)s.O;
   const uint32_t IK = I * K, KO = K * O;
   const float* sp = src + s.src_off;
@@ -305,8 +331,25 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
     const uint32_t o0 = d0 / IK, o1 = (d1 - 1) / IK;
     const uint32_t base = o0 * IK, n_src = (o1 + 1 - o0) * IK;
     if (n_src <= CAST_LDS_FLOATS) {
-      for (uint32_t j = threadIdx.x; j < n_src; j += 256) lds[j] = sp[base + j];
+      if (((s.src_off + base) & 3) == 0 && (n_src & 3) == 0) {       // 16-byte source loads
+        const f32x4* sp4 = reinterpret_cast<const f32x4*>(sp + base);
+        for (uint32_t j = threadIdx.x; j < (n_src >> 2); j += 256) *reinterpret_cast<f32x4*>(lds + 4 * j) = sp4[j];
+      } else {
+        for (uint32_t j = threadIdx.x; j < n_src; j += 256) lds[j] = sp[base + j];
+      }
       __syncthreads();
+      if ((I & 3) == 0 && (d0 & 3) == 0 && ((d1 - d0) & 3) == 0 && ((s.dst_off + d0) & 3) == 0) {
+        // four consecutive destinations = four consecutive i of one (o, k): one 4-element store per thread
+        for (uint32_t d = d0 + 4 * threadIdx.x; d < d1; d += 1024) {
+          const uint32_t o = d / IK, rem = d - o * IK;
+          const uint32_t k = rem / I, i = rem - k * I;
+          const float* q = lds + (o * IK + i * K + k - base);
+          typename CV::T v4[4] = {CV::cv(q[0]), CV::cv(q[K]), CV::cv(q[2 * K]), CV::cv(q[3 * K])};
+          if (sizeof(typename CV::T) == 2) *reinterpret_cast<uint2*>(dp + d) = *reinterpret_cast<const uint2*>(v4);
+          else *reinterpret_cast<uint4*>(dp + d) = *reinterpret_cast<const uint4*>(v4);
+        }
+        return;
+      }
       for (uint32_t d = d0 + threadIdx.x; d < d1; d += 256) {
         const uint32_t o = d / IK, rem = d - o * IK;
         const uint32_t k = rem / I, i = rem - k * I;
@@ -324,6 +367,19 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
         lds[o * pitch + j] = sp[o * IK + q0 + j];
       }
       __syncthreads();
+      if ((O & 3) == 0 && (d0 & 3) == 0 && ((d1 - d0) & 3) == 0 && ((s.dst_off + d0) & 3) == 0) {
+        // four consecutive destinations = four consecutive o of one (i, k'): one 4-element store per thread (the odd LDS pitch
+        // keeps the four reads on different banks)
+        for (uint32_t d = d0 + 4 * threadIdx.x; d < d1; d += 1024) {
+          const uint32_t r = d / O, o = d - r * O;
+          const uint32_t i = r / K, kf = r - i * K;
+          const float* q = lds + (o * pitch + i * K + (K - 1 - kf) - q0);
+          typename CV::T v4[4] = {CV::cv(q[0]), CV::cv(q[pitch]), CV::cv(q[2 * pitch]), CV::cv(q[3 * pitch])};
+          if (sizeof(typename CV::T) == 2) *reinterpret_cast<uint2*>(dp + d) = *reinterpret_cast<const uint2*>(v4);
+          else *reinterpret_cast<uint4*>(dp + d) = *reinterpret_cast<const uint4*>(v4);
+        }
+        return;
+      }
       for (uint32_t d = d0 + threadIdx.x; d < d1; d += 256) {
         const uint32_t r = d / O, o = d - r * O;
         const uint32_t i = r / K, kf = r - i * K;
@@ -331,6 +387,19 @@ __global__ void __launch_bounds__(256) cast_table_kernel(const float* __restrict
       }
       return;
     }
+  }
+  if (s.mode == 0 && K == 1 && ((s.src_off + d0) & 3) == 0 && ((s.dst_off + d0) & 3) == 0) {
+    // straight cast (1x1 filters, dense weights, biases): 16-byte loads, 4-element stores, scalar tail
+    const uint32_t n4 = (d1 - d0) >> 2;
+    const f32x4* sp4 = reinterpret_cast<const f32x4*>(sp + d0);
+    for (uint32_t j = threadIdx.x; j < n4; j += 256) {
+      const f32x4 v = sp4[j];
+      typename CV::T v4[4] = {CV::cv(v[0]), CV::cv(v[1]), CV::cv(v[2]), CV::cv(v[3])};
+      if (sizeof(typename CV::T) == 2) *reinterpret_cast<uint2*>(dp + d0 + 4 * j) = *reinterpret_cast<const uint2*>(v4);
+      else *reinterpret_cast<uint4*>(dp + d0 + 4 * j) = *reinterpret_cast<const uint4*>(v4);
+    }
+    for (uint32_t d = d0 + 4 * n4 + threadIdx.x; d < d1; d += 256) dp[d] = CV::cv(sp[d]);
+    return;
   }
   for (uint32_t d = d0 + threadIdx.x; d < d1; d += 256) {        // straight copies and oversize fallbacks
     uint32_t si = d;

@@ -253,10 +253,17 @@ class CastTable:
         raw = b"".join(struct.pack("<qqqiiii", *e) for e in self.entries)
         self._seg = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device) if raw
                      else torch.zeros(0, dtype=torch.uint8, device=self.device))
-        bs, bc = _block_tables([e[2] for e in self.entries])
+        # mode-1 entries are processed as 64 x 64 transpose tiles: one block per tile (the chunk index of the table is the tile index)
+        bs, bc = _block_tables([e[2] if e[6] != 1 else self._tiles(e) * CHUNK for e in self.entries])
         self.num_blocks = int(bs.shape[0])
         self._blk_seg = torch.from_numpy(bs).to(self.device)
         self._blk_chunk = torch.from_numpy(bc).to(self.device)
+
+    @staticmethod
+    def _tiles(e):
+        _, _, n, I, K, O, _ = e
+        assert O > 0 and n == O * I * K, "mode-1 cast entries describe a whole [O, I, K] filter"
+        return ((O + 63) // 64) * ((I * K + 63) // 64)
 
     def run(self, src_f32, dst_bf16):
         if L.use_hip(src_f32) and src_f32.dtype == torch.float32 and dst_bf16.dtype in (torch.float32, torch.bfloat16, torch.float16):

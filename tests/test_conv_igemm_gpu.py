@@ -213,6 +213,32 @@ def test_cast_table_lds_staged_permutes_at_network_sizes(O, I, K):
     assert float(dst[:3].abs().sum()) == 0 and float(dst[3 + n:3 + n + 5].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("O,I,K,tail", [(64, 64, 9, 0), (512, 512, 9, 0), (256, 64, 1, 0), (1000, 2048, 1, 3), (64, 3, 49, 0), (130, 36, 9, 0), (31, 7, 1, 2)])
+def test_cast_table_vector_paths_with_aligned_offsets(O, I, K, tail):
+    """16-byte aligned entries (what the real arena holds for the convolution / dense weights): the vector load / 4-element store
+    paths of the straight cast and of the OIHW -> OHWI permute, including a scalar tail and shapes that fall back (I % 4 != 0)."""
+    from deeplearning4j_amd.ops import updater as U
+    n = O * I * K
+    torch.manual_seed(O + I + K)
+    src = torch.randn(8 + n + tail + 4, device="cuda")
+    n2 = n + tail if K == 1 else n
+    ct = U.CastTable([(8, 4, n2, I if K > 1 else n2, K, 0, 0)], "cuda")
+    dst = torch.zeros(4 + n2 + 8, dtype=torch.bfloat16, device="cuda")
+    ct.run(src, dst)
+    if K == 1:
+        assert torch.equal(dst[4:4 + n2], src[8:8 + n2].bfloat16())
+    else:
+        assert torch.equal(dst[4:4 + n].view(O, K, I), src[8:8 + n].view(O, I, K).permute(0, 2, 1).contiguous().bfloat16())
+    assert float(dst[:4].abs().sum()) == 0 and float(dst[4 + n2:].abs().sum()) == 0
+    # the flipped [I, K, O] image for the data-gradient kernels
+    ct2 = U.CastTable([(8, 4, n, I, K, O, 1)], "cuda")
+    dst2 = torch.zeros(4 + n + 8, dtype=torch.bfloat16, device="cuda")
+    ct2.run(src, dst2)
+    w = src[8:8 + n].view(O, I, K)
+    assert torch.equal(dst2[4:4 + n].view(I, K, O), torch.flip(w, dims=[2]).permute(1, 2, 0).contiguous().bfloat16())
+    assert float(dst2[:4].abs().sum()) == 0 and float(dst2[4 + n:].abs().sum()) == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 192, 320), (4096, 768, 768)])
 def test_hand_written_gemm_nt_matches_fp32(M, N, K):
     from deeplearning4j_amd.ops import gemm as G
