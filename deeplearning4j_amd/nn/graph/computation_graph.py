@@ -29,7 +29,7 @@ from ..conf import layers as C
 from ..conf.base import BackpropType, ConvolutionMode, PoolingType
 from ..conf.configuration import ComputationGraphConfiguration
 from ..layers import registry
-from ..layers.core import BatchNormalizationImpl, ConvolutionLayerImpl, ActivationLayerImpl, SubsamplingLayerImpl
+from ..layers.core import BatchNormalizationImpl, ConvolutionLayerImpl, ActivationLayerImpl, SubsamplingLayerImpl, ZeroPaddingLayerImpl
 from ..layers.recurrent import LSTMImpl, SimpleRnnImpl
 from ..network_base import BaseNetwork
 from ...ops.conv_igemm import MaskedGrad
@@ -298,7 +298,24 @@ class ComputationGraph(BaseNetwork):
             elif isinstance(impl, BatchNormalizationImpl):
                 impl.conv_bias = None
                 impl.producer = None
+            elif isinstance(impl, ZeroPaddingLayerImpl):
+                impl.passthrough = False
+            if isinstance(impl, ConvolutionLayerImpl):
+                impl.extra_pad = (0, 0)
         if self.fusion_enabled:
+            # ZeroPadding (symmetric) -> Convolution (truncate mode): the convolution pads inside its own kernels, the padded copy
+            # of the input (the 230x230 image batch of the ImageNet stems) is never made
+            for n in self.topologicalOrder:
+                z = impls[n]
+                if not (type(z) is ZeroPaddingLayerImpl and single(n) and conf.vertices[n].preProcessor is None and z.conf.idropout is None):
+                    continue
+                t_, b_, l_, r_ = z.conf.padding
+                cn = cons[n][0]
+                a = impls.get(cn)
+                if (t_ == b_ and l_ == r_ and type(a) is ConvolutionLayerImpl and conf.vertices[cn].preProcessor is None
+                        and a.conf.idropout is None and (a.conf.convolutionMode or ConvolutionMode.Truncate) != ConvolutionMode.Same):
+                    z.passthrough = True
+                    a.extra_pad = (int(t_), int(l_))
             for n in self.topologicalOrder:
                 if n in fused_away or not is_plain_bn(n) or not single(n):
                     continue

@@ -425,6 +425,7 @@ class ConvolutionLayerImpl(LayerImpl):
         self.fold_bias = False   # bias folded into a following BatchNorm (fusion planner)
         self.want_stats = False  # emit per-channel sum/sumsq for the following BatchNorm (conv epilogue fusion)
         self.out_sums = None
+        self.extra_pad = (0, 0)  # symmetric zero padding of a preceding ZeroPaddingLayer absorbed by the fusion planner
 
     def compute_replicas(self):
         r = [("W", "ohwi"), ("W", "dgrad")]
@@ -440,7 +441,7 @@ class ConvolutionLayerImpl(LayerImpl):
             if ph[0] == ph[1] and pw[0] == pw[1]:
                 return (ph[0], pw[0]), None
             return (0, 0), (pw[0], pw[1], ph[0], ph[1])
-        return tuple(c.padding), None
+        return (c.padding[0] + self.extra_pad[0], c.padding[1] + self.extra_pad[1]), None
 
     def forward(self, x, train=False):
         x = self._dropout_in(x, train)
@@ -553,7 +554,11 @@ class SubsamplingLayerImpl(LayerImpl):
 
 
 class ZeroPaddingLayerImpl(LayerImpl):
+    passthrough = False          # set by the graph fusion planner when the consuming convolution pads inside its own kernel
+
     def forward(self, x, train=False):
+        if self.passthrough:
+            return x
         t, b, l, r = self.conf.padding
         y = F.pad(x, (l, r, t, b))
         if self.ctx.channels_last and x.is_cuda:
@@ -561,6 +566,8 @@ class ZeroPaddingLayerImpl(LayerImpl):
         return y
 
     def backward(self, eps):
+        if self.passthrough:
+            return eps
         t, b, l, r = self.conf.padding
         return eps[:, :, t:eps.shape[2] - b, l:eps.shape[3] - r]
 
