@@ -145,9 +145,14 @@ __global__ void __launch_bounds__(256) bn_pool_bwd_coeffs_kernel(const float* __
 }
 
 // pass 2: one thread per full-resolution (n, h, w, 8 channels)
+// KS = kernel * 16 + stride when both windows are square and known at compile time (3x3 / 2: the ImageNet stem), 0 = runtime geometry:
+// the covering-window arithmetic then divides by constants
+template <int KS>
 __global__ void __launch_bounds__(256) bn_pool_bwd_dx_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                              const uint8_t* __restrict__ idx, const float* __restrict__ coef,
-                                                             bf16_t* __restrict__ dx, BnPoolP p) {
+                                                             bf16_t* __restrict__ dx, BnPoolP pr) {
+  BnPoolP p = pr;
+  if (KS != 0) { p.kH = p.kW = KS >> 4; p.sH = p.sW = KS & 15; }
   const unsigned cv = p.C / 8;
   const int64_t total = (int64_t)p.N * p.H * p.W * cv;
   const int spanH = p.kH - 1, spanW = p.kW - 1;
@@ -253,7 +258,11 @@ DL4J_API int dl4j_bn_pool_bwd(const void* x, const void* dy, const void* y, cons
   const float inv_m = 1.f / (float)((int64_t)p.N * p.H * p.W);
   hipLaunchKernelGGL(bn_pool_bwd_coeffs_kernel, dim3(1), dim3(256), 0, st, ws, gamma, mean, invstd, dbeta, dgamma, ws + 3 * C, C, inv_m);
   const int64_t total = (int64_t)p.N * p.H * p.W * (C / 8);
-  hipLaunchKernelGGL(bn_pool_bwd_dx_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, idx, ws + 3 * C,
-                     (bf16_t*)dx, p);
+  if (p.kH == 3 && p.kW == 3 && p.sH == 2 && p.sW == 2)
+    hipLaunchKernelGGL(bn_pool_bwd_dx_kernel<3 * 16 + 2>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, idx,
+                       ws + 3 * C, (bf16_t*)dx, p);
+  else
+    hipLaunchKernelGGL(bn_pool_bwd_dx_kernel<0>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, idx, ws + 3 * C,
+                       (bf16_t*)dx, p);
   DL4J_RET_LAST();
 }
