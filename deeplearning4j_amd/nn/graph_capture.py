@@ -187,6 +187,11 @@ class CapturedTrainStep:
         return segs
 
 
+import threading
+
+_CAPTURE_LOCK = threading.Lock()
+
+
 class CapturedInference:
     """HIP-graph replay of the inference forward pass, one graph per input signature (shapes + dtypes).
 
@@ -220,17 +225,19 @@ class CapturedInference:
                 if self._stream is None:
                     self._stream = torch.cuda.Stream()
                 static_in = [x.clone() for x in xs]
-                self._stream.wait_stream(torch.cuda.current_stream())
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self._stream, capture_error_mode="thread_local"):
-                    static_out = fwd(static_in)
+                with _CAPTURE_LOCK:           # several host threads (ParallelInference workers) capture one at a time
+                    self._stream.wait_stream(torch.cuda.current_stream())
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self._stream, capture_error_mode="thread_local"):
+                        static_out = fwd(static_in)
                 e.update(graph=g, static_in=static_in, static_out=static_out)
             except Exception as ex:           # an op that synchronises with the host: stay eager for this network
                 import warnings
                 warnings.warn("inference graph capture disabled: %s" % (ex,))
                 self.disabled = True
-                self.entries.clear()
-                torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()
+                self._retired = list(self.entries.values())     # graphs of other signatures are kept alive, not destroyed mid-flight
+                self.entries = {}
                 return None
         for s, x in zip(e["static_in"], xs):
             s.copy_(x)

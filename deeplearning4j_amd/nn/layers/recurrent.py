@@ -207,7 +207,8 @@ class _side_stream:
         self.side.wait_stream(self.cur)
         self.forked = True
         self.held = inputs
-        return torch.cuda.stream(self.side)
+        from ...ops.streams import side_region
+        return side_region(self.side, 'bidirectional side-stream')
 
     def join(self):
         if self.forked:

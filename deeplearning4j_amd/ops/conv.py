@@ -133,7 +133,7 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
             if (streams.active() and dw_out is not None and dw_out.dtype == torch.float32 and dw_out.is_contiguous()
                     and dz.is_contiguous(memory_format=torch.channels_last)):
                 # dW goes straight into the flat gradient view and is not read before the updater: side stream
-                with torch.cuda.stream(streams.fork(dz, x, dw_out)):
+                with streams.side_region(streams.fork(dz, x, dw_out), 'convolution weight-gradient'):
                     IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
             else:
                 dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
@@ -191,7 +191,7 @@ def _backward_mfma(dz, x, w, stride, padding, dilation, need_dx, need_dw, need_d
         if IG.wgrad_supported(x, w):
             from . import streams
             if (streams.active() and dw_out is not None and dw_out.dtype == torch.float32 and dw_out.is_contiguous()):
-                with torch.cuda.stream(streams.fork(dz, x, dw_out)):
+                with streams.side_region(streams.fork(dz, x, dw_out), 'convolution weight-gradient'):
                     IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
             else:
                 dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)

@@ -197,7 +197,7 @@ class FusedDenseFn(torch.autograd.Function):
         if side:
             # dW is off the critical path: issued first, on the side stream, so that it overlaps dx and what follows (ops/streams.py)
             lw.hits += 1
-            with torch.cuda.stream(STREAMS.fork(x2, d2)):
+            with STREAMS.side_region(STREAMS.fork(x2, d2), 'dense weight-gradient'):
                 DENSE.dw(x2, d2, lw.grad.view(K, N), True)
         if ctx.needs_input_grad[0]:
             wc = w if w.is_contiguous() else w.contiguous()

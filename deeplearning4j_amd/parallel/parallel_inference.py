@@ -81,6 +81,8 @@ class _Worker(threading.Thread):
         self._model_version = -1
         self.ready = threading.Event()
         self.init_error = None
+        self._lib_gemm = {}            # input signature -> vendor GEMMs inside the captured graph (None = not seen yet)
+        self.gemm_counts = {}
 
     def _refresh_model(self):
         v = self.pi._model_version
@@ -129,6 +131,37 @@ class _Worker(threading.Thread):
                 for o in batch:
                     o.fail(e)
 
+    def _guarded_forward(self, ins, masks):
+        """The replica's forward under the vendor-GEMM rule of ops/streams.py: workers of one device each own a stream, and two vendor
+        GEMMs running at the same time on two streams can dead-lock the device (the reference holds a per-device mutex around cuBLAS for
+        the same reason, MmulHelper.cu:261). 2-D GEMMs are routed to the in-tree kernel; any other vendor GEMM runs under the device
+        token; a forward whose HIP graph recorded vendor GEMMs is replayed under the token as a whole. Input signatures not seen yet
+        run under the token too (their first call captures, and replays, a graph whose contents are not known before)."""
+        if self.stream is None or not self.pi._shares_device:
+            return [_raw(y) for y in _forward(self.replica, ins, masks)]
+        from ..ops import streams as _st
+        sig = tuple((tuple(x.shape), x.dtype) for x in ins)
+        state = self._lib_gemm.get(sig)
+        guard = _st.library_gemm_guard("route", "ParallelInference worker")
+        if state is False:
+            with guard:
+                outs = [_raw(y) for y in _forward(self.replica, ins, masks)]
+        else:
+            with _st.library_gemm_token(self.device), guard:
+                outs = [_raw(y) for y in _forward(self.replica, ins, masks)]
+        for k, v in guard.counts.items():
+            self.gemm_counts[k] = self.gemm_counts.get(k, 0) + v
+        if guard.counts["captured"]:
+            self._lib_gemm[sig] = True
+        elif state is None:
+            # decided once the signature has been captured (the eager warm-up calls before it say nothing about the graph), or at once
+            # when this replica does not capture at all
+            cap = getattr(self.replica, "_infer_cap", None)
+            e = cap.entries.get(sig) if cap is not None and not cap.disabled else None
+            if cap is None or cap.disabled or (e is not None and e.get("graph") is not None):
+                self._lib_gemm[sig] = False
+        return outs
+
     @staticmethod
     def _compatible(a: _Observable, b: _Observable):
         if len(a.inputs) != len(b.inputs) or (a.masks is None) != (b.masks is None):
@@ -153,7 +186,7 @@ class _Worker(threading.Thread):
                 tgt = 1 << (n - 1).bit_length()
                 if tgt != n:
                     ins = [torch.cat([x, x[-1:].expand(tgt - n, *x.shape[1:])], 0) for x in ins]
-            outs = [_raw(y) for y in _forward(self.replica, ins, masks)]
+            outs = self._guarded_forward(ins, masks)
             if self.stream is not None:
                 self.stream.synchronize()
         self.counter += len(batch)
@@ -185,6 +218,7 @@ class ParallelInference:
             devices = [torch.device("cuda", i) for i in range(n)] if n else [model.ctx.device]
         devices = [torch.device(d) for d in devices]
         self.workers_n = int(workers) if workers else len(devices)
+        self._shares_device = self.workers_n > len(set(devices))      # several workers (= streams) on one device: ops/streams.py rule applies
         self._model_version = 0
         self._rr = 0
         self._lock = threading.Lock()
@@ -296,6 +330,15 @@ class ParallelInference:
 
     def getWorkerCounter(self, i):
         return self._workers[i].counter
+
+    def gemmStatistics(self):
+        """Vendor-GEMM accounting of the workers (ops/streams.py): routed to the in-tree kernel / serialised by the device token /
+        recorded into a HIP graph (such graphs replay under the token)."""
+        tot = {"routed": 0, "serialized": 0, "captured": 0}
+        for w in self._workers:
+            for k, v in w.gemm_counts.items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
 
     def shutdown(self):
         if self._shutdown:
