@@ -1,10 +1,12 @@
 """In-tree build of the native libraries (gfx950 only).
 
-Two shared objects are produced next to this file:
+Three shared objects are produced next to this file:
 
 * ``libdl4j_hip.so``   – every hand-written HIP kernel (``csrc/*.hip``), compiled with
   ``hipcc --offload-arch=gfx950`` and exposed through a flat C ABI (ctypes on the Python side,
   the same ABI a JavaCPP preset would bind — mirrors the role of libnd4j's NativeOps.h).
+* ``libnd4jrocm_dev.so`` – the memory / device / stream / event / launch-context / sort groups of the C ABI on the HIP runtime and
+  rocPRIM (``csrc/abi_runtime.hip``), under the reference's function names.
 * ``libnd4jrocm_rt.so`` – the host C++ runtime (``csrc/*.cpp``): shapeInfo/TAD math, workspaces,
   DataBuffer serde, threshold codecs (host), record readers + prefetch loader, op registry.
 
@@ -26,6 +28,8 @@ OBJ = HERE / "_obj"
 ARCH = "gfx950"
 HIP_LIB = HERE / "libdl4j_hip.so"
 RT_LIB = HERE / "libnd4jrocm_rt.so"
+DEV_LIB = HERE / "libnd4jrocm_dev.so"
+DEV_SRCS = ("abi_runtime.hip",)      # device-runtime ABI under the reference's unprefixed names: its own library, loaded RTLD_LOCAL
 
 
 def _hipcc() -> str:
@@ -74,10 +78,13 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
             for out in ex.map(_run, tasks):
                 if verbose and out.strip():
                     print(out)
-    hip_objs = [str(OBJ / (s.stem + ".hip.o")) for s in hip_srcs]
+    hip_objs = [str(OBJ / (s.stem + ".hip.o")) for s in hip_srcs if s.name not in DEV_SRCS]
+    dev_objs = [str(OBJ / (s.stem + ".hip.o")) for s in hip_srcs if s.name in DEV_SRCS]
     cpp_objs = [str(OBJ / (s.stem + ".cpp.o")) for s in cpp_srcs]
     if hip_objs and (force or tasks or not HIP_LIB.exists()):
         _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(HIP_LIB), *hip_objs])
+    if dev_objs and (force or tasks or not DEV_LIB.exists()):
+        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(DEV_LIB), *dev_objs])
     if cpp_objs and (force or tasks or not RT_LIB.exists()):
         _run(["g++", "-shared", "-fPIC", "-pthread", "-o", str(RT_LIB), *cpp_objs])
 

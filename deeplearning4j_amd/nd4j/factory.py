@@ -387,12 +387,33 @@ class Nd4j:
 
     @staticmethod
     def sort(arr, dim=-1, ascending=True):
-        return INDArray(torch.sort(_unwrap(arr), dim=dim, descending=not ascending).values, "c")
+        """Sorted copy along ``dim`` (Nd4j.sort -> NativeOps::sortTad; on the GPU the rocPRIM segmented radix sort of
+        native/csrc/abi_runtime.hip, on the host torch's sort)."""
+        t = _unwrap(arr)
+        if t.is_cuda and t.dim() >= 1:
+            from . import native_runtime as NR
+            if NR.supported(t):
+                return INDArray(NR.sort_along(t.clone(memory_format=torch.contiguous_format), dim, not ascending), "c")
+        return INDArray(torch.sort(t, dim=dim, descending=not ascending).values, "c")
 
     @staticmethod
     def sortWithIndices(arr, dim=-1, ascending=True):
-        v, i = torch.sort(_unwrap(arr), dim=dim, descending=not ascending)
+        """(indices, sorted values) along ``dim`` (Nd4j.sortWithIndices -> NativeOps::sortTadByKey with positions as the values)."""
+        t = _unwrap(arr)
+        if t.is_cuda and t.dim() >= 1:
+            from . import native_runtime as NR
+            if NR.supported(t):
+                v, i = NR.sort_with_indices(t, dim, not ascending)
+                return INDArray(i, "c"), INDArray(v, "c")
+        v, i = torch.sort(t, dim=dim, descending=not ascending, stable=True)
         return INDArray(i, "c"), INDArray(v, "c")
+
+    @staticmethod
+    def sortCooIndices(indices, values, shape):
+        """COO entries into row-major order of the full array, in place (NativeOps::sortCooIndices; BaseSparseNDArrayCOO)."""
+        from . import native_runtime as NR
+        NR.sort_coo(_unwrap(indices), _unwrap(values), shape)
+        return indices, values
 
     @staticmethod
     def argMax(arr, *dims):

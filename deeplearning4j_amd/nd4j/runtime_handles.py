@@ -52,6 +52,22 @@ class LaunchContext:
     def isInitialized(self) -> bool:
         return True
 
+    # -- the native launch context of the C ABI (NativeOps::defaultLaunchContext + lc* accessors): execution / copy streams and
+    #    the scalar / reduction / allocation scratch buffers a foreign binding launches the legacy kernels with
+    def nativeHandle(self) -> int:
+        from .native_runtime import lib, check
+        h = lib().defaultLaunchContext()
+        if not h:
+            check("defaultLaunchContext")
+        return int(h)
+
+    def nativePointers(self) -> dict:
+        from .native_runtime import lib
+        L, h = lib(), self.nativeHandle()
+        return {"executionStream": L.lcExecutionStream(h), "copyStream": L.lcCopyStream(h), "scalarPointer": L.lcScalarPointer(h),
+                "reductionPointer": L.lcReductionPointer(h), "allocationPointer": L.lcAllocationPointer(h),
+                "blasHandle": L.lcBlasHandle(h), "solverHandle": L.lcSolverHandle(h)}
+
 
 def _tt(x):
     return x.tensor() if isinstance(x, INDArray) else torch.as_tensor(x)
@@ -163,6 +179,12 @@ class NativeOpsHolder:
         return cls._inst
 
     def getDeviceNativeOps(self):
+        """The device-runtime ABI (memory / devices / streams / events / launch context / sort) under the reference's method names
+        (nativeblas/NativeOps.java), served by libnd4jrocm_dev.so."""
+        from .native_runtime import DeviceNativeOps
+        return DeviceNativeOps()
+
+    def getKernelLibrary(self):
         """ctypes handle of the HIP kernel library (libdl4j_hip.so); raises when it was not built."""
         from ..native import lib as L
         return L.hip()
