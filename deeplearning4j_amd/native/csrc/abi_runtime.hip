@@ -318,6 +318,7 @@ int sort_tads(void* hx, void* dx, const LongType* si, void* hy, void* dy, const 
   if (!ke || (pairs && !ve)) return fail(2, "sortTad: unsupported data type");
   const LongType n = g.num_tads * g.tad_len;
   int rc = 0;
+  if (n == 0) return 0;
   if (dk) {
     if (pairs && !dv) return fail(2, "sortTad: keys on the device but values on the host");
     DevTmp dense(st), vdense(st), perm(st);
@@ -395,6 +396,7 @@ int sort_flat(void* hx, void* dx, const LongType* si, void* hy, void* dy, const 
   const int ke = size_of(kt), ve = pairs ? size_of(type_of(vsi)) : 0;
   if (!ke || (pairs && !ve)) return fail(2, "sort: unsupported data type");
   int rc = 0;
+  if (n == 0) return 0;
   if (dk) {
     if (pairs && !dv) return fail(2, "sort: keys on the device but values on the host");
     DevTmp perm(st);

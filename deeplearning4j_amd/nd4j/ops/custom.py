@@ -374,7 +374,17 @@ class OpExecutioner:
         return _IMPL[name](ins, i, t, b, d)
 
     def exec(self, op_or_name, *args, **kw):
-        """exec(DynamicCustomOp) / exec(name, inputs, iArgs=..., tArgs=..., bArgs=..., dArgs=...) / exec(op, OpContext)."""
+        """exec(DynamicCustomOp) / exec(name, inputs, iArgs=..., tArgs=..., bArgs=..., dArgs=...) / exec(op, OpContext) /
+        exec(Aggregate) / exec(Batch) (OpExecutioner.java: exec(Aggregate), exec(Batch<T>) -> execAggregate / execAggregateBatch)."""
+        from . import aggregates as _agg
+        if isinstance(op_or_name, _agg.Batch):
+            return _agg.exec_batch(op_or_name)
+        if isinstance(op_or_name, _agg.Aggregate):
+            return _agg.exec_aggregate(op_or_name)
+        if isinstance(op_or_name, (list, tuple)) and op_or_name and all(isinstance(a, _agg.Aggregate) for a in op_or_name):
+            for bt in _agg.Batch.getBatches(list(op_or_name)):          # exec(List<Aggregate>)
+                _agg.exec_batch(bt)
+            return None
         if isinstance(op_or_name, str):
             o = DynamicCustomOp(op_or_name, args[0] if args else kw.get("inputs"), kw.get("outputs"), kw.get("iArgs"),
                                 kw.get("tArgs"), kw.get("bArgs"), kw.get("dArgs"))

@@ -78,7 +78,7 @@ def test_device_sort_every_type_both_directions(dt):
 def test_device_sort_special_values_and_tiny_inputs():
     x = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), 3.0, -3.0, 1e-30, -1e-30], device=dev())
     got = R.sort_tensor(x.clone())
-    assert got.tolist() == [-float("inf"), -3.0, -1e-30, -0.0, 0.0, 1e-30, 3.0, float("inf")]
+    assert torch.equal(got.cpu(), torch.tensor([-float("inf"), -3.0, -1e-30, -0.0, 0.0, 1e-30, 3.0, float("inf")]))
     assert torch.signbit(got[3]) and not torch.signbit(got[4])           # the bit-pattern order puts -0 before +0
     assert R.sort_tensor(torch.tensor([2.0], device=dev())).tolist() == [2.0]
     assert R.sort_tensor(torch.empty(0, device=dev())).numel() == 0
