@@ -14,6 +14,7 @@
 // boolean by definition). Arrays of VARIABLE / CONSTANT nodes are exposed zero-copy from the
 // registered buffer.
 #include "rt_common.h"
+#include "rt_exceptions.h"
 
 #include <algorithm>
 #include <chrono>
@@ -528,9 +529,8 @@ RT_API int graph_register(LongType id, const void* buf, LongType len) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_graphs[id] = g;
     return 0;
-  } catch (const std::exception& e) {
-    rt::set_error(1, std::string("graph_register: ") + e.what());
-    return 1;
+  } catch (...) {
+    return rt::report_current_exception("graph_register");       // category code (rt_exceptions.h), message in the error slot
   }
 }
 
@@ -542,7 +542,7 @@ RT_API int graph_unregister(LongType id) {
 RT_API int graph_registered(LongType id) { return get(id) ? 1 : 0; }
 RT_API int graph_count() { std::lock_guard<std::mutex> lk(g_mu); return (int)g_graphs.size(); }
 
-#define GET_OR(ret) auto g = get(id); if (!g) { rt::set_error(2, "unknown graph id"); return ret; }
+#define GET_OR(ret) auto g = get(id); if (!g) { rt::set_error(rt::CAT_UNKNOWN_GRAPH, rt::unknown_graph_exception(id).what()); return ret; }
 
 RT_API int graph_num_nodes(LongType id) { GET_OR(-1) return (int)g->nodes.size(); }
 RT_API int graph_num_vars(LongType id) { GET_OR(-1) return (int)g->vars.size(); }
@@ -722,8 +722,8 @@ RT_API int graph_execute(LongType id, const int* feed_vars, const LongType* feed
     }
   }
   if (!ok) {
-    rt::set_error(3, "graph_execute: " + ex.error);
-    return 3;
+    rt::set_error(rt::CAT_GRAPH_EXECUTION, std::string("graph_execute: ") + rt::graph_execution_exception(id, ex.error).what());
+    return rt::CAT_GRAPH_EXECUTION;
   }
   for (int k = 0; k < n_wanted; ++k) {
     auto it = ex.vals.find(Key{wanted[k], 0, 0});

@@ -13,6 +13,7 @@
 //     (registerCustomOpFallback); without one execCustomOp2 reports "not implemented natively" through the error channel.
 //   * Shape functions are native for every op in the table (calculateOutputShapes2 -> OpaqueShapeList).
 #include "rt_common.h"
+#include "rt_exceptions.h"
 
 #include <algorithm>
 #include <cmath>
@@ -662,8 +663,8 @@ RT_API int execCustomOp2(void** /*extraPointers*/, LongType hash, OpaqueContext*
     }
     if (g_fallback) return g_fallback(hash, ctx, g_fallback_user);
     return fail(12, "execCustomOp2: op is not implemented natively and no fallback is registered");
-  } catch (const std::exception& e) {
-    return fail(13, std::string("execCustomOp2: ") + e.what());
+  } catch (...) {
+    return rt::report_current_exception("execCustomOp2");
   }
 }
 
@@ -686,8 +687,8 @@ RT_API OpaqueShapeList* calculateOutputShapes2(void** /*extraPointers*/, LongTyp
     auto* out = new OpaqueShapeList();
     if (it->second.shape(in, args, *out) != 0) { delete out; return nullptr; }
     return out;
-  } catch (const std::exception& e) {
-    fail(13, std::string("calculateOutputShapes2: ") + e.what());
+  } catch (...) {
+    rt::report_current_exception("calculateOutputShapes2");
     return nullptr;
   }
 }

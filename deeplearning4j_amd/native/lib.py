@@ -65,6 +65,9 @@ def _declare_rt(lib):
     sig = {
         # error channel
         "nd4j_last_error_code": (i32, []), "nd4j_last_error_message": (cp, []), "nd4j_clear_error": (None, []),
+        "nd4j_backtrace_toggle": (None, [i32]), "nd4j_backtrace_enabled": (i32, []), "nd4j_last_error_backtrace": (cp, []),
+        "nd4j_error_category": (cp, [i32]), "nd4j_current_backtrace": (i64, [cp, i64]), "nd4j_raise_for_test": (i32, [i32, i64]),
+        "nd4j_install_crash_handler": (None, []),
         # shape / TAD
         "nd4j_shape_info_length": (i32, [i32]),
         "nd4j_shape_buffer": (i32, [i32, P64, C.c_char, i64, P64]),
@@ -138,9 +141,10 @@ def _declare_rt(lib):
 
 
 def rt_check(code, what="native runtime"):
+    """Non-zero status of a runtime entry point -> the matching exception class of nd4j/exceptions.py (all are RuntimeErrors)."""
     if code != 0:
-        lib = rt()
-        raise RuntimeError("%s failed: %s (code %d)" % (what, (lib.nd4j_last_error_message() or b"").decode(), code))
+        from ..nd4j.exceptions import raise_native
+        raise_native(code, what)
 
 
 def gpu_available() -> bool:
