@@ -46,7 +46,7 @@ struct EpiP {
   const float* stat_shift;   // [N] per-column shift subtracted before summing (running mean; null = 0): keeps E[x^2]-E[x]^2 stable
   float alpha;
   int act;
-  int accum;                 // out += result
+  int accum;                 // 1: out += result (read-modify-write), 2: fp32 atomic add (split-K partials)
 };
 
 // RowOff: int64 element offset of tile row r's first column (n0) in `out`, or -1 when the row is out of range.
@@ -119,6 +119,17 @@ __device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C:
     if (ro < 0 || n >= N) continue;
     const int64_t o = ro + ch * EPC;
     const char* sp = sC + row * PITCH + ch * 16;
+    if constexpr (OT == OT_F32) {
+      if (e.accum == 2) {                       // split-K partial: fp32 atomics into a pre-zeroed (or beta-scaled) output
+        const float* se = reinterpret_cast<const float*>(sp);
+        for (int j = 0; j < EPC && n + j < N; ++j) {
+          float f = se[j];
+          if (res != nullptr) f += res[o + j];
+          atomicAdd(out + o + j, f);
+        }
+        continue;
+      }
+    }
     if ((full_cols || n + EPC <= N) && ((reinterpret_cast<uintptr_t>(out + o) & 15) == 0)) {
       f32x4 v = *reinterpret_cast<const f32x4*>(sp);
       if (res != nullptr || e.accum) {

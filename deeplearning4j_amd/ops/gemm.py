@@ -108,3 +108,88 @@ def bgemm_nt(a, b, alpha=1.0, out_dtype=None):
     _launch(a, b, y, None, None, alpha, None, M, N, K, a.stride(1), b.stride(1), N, a.stride(0), b.stride(0), M * N, B, t,
             out_dtype == torch.float32 and a.dtype != torch.float32)
     return y
+
+
+# ------------------------------------------------------------------------------------------------------------------ all operand layouts
+def _layout(t):
+    """(kmajor, ld) of a 2-D / batched operand view whose LAST TWO dims are (rows, k): K-contiguous -> (False, row stride);
+    row-contiguous (a transposed view) -> (True, k stride); None when neither dim is dense."""
+    if t.stride(-1) == 1:
+        return False, t.stride(-2)
+    if t.stride(-2) == 1:
+        return True, t.stride(-1)
+    return None
+
+
+def supported_ex(a, b):
+    """a: [.., M, K] view, b: [.., N, K] view (i.e. C = a . b^T), each either K-contiguous or its transpose; same dtype; 16-byte chunks."""
+    if not (a.is_cuda and b.is_cuda and a.dtype == b.dtype and a.dtype in _DT and a.dim() == b.dim() and a.dim() in (2, 3)):
+        return False
+    if a.shape[-1] != b.shape[-1] or a.numel() == 0 or b.numel() == 0 or (a.dim() == 3 and a.shape[0] != b.shape[0]):
+        return False
+    la, lb = _layout(a), _layout(b)
+    if la is None or lb is None:
+        return False
+    ch = chunk(a.dtype)
+    M, K, N = a.shape[-2], a.shape[-1], b.shape[-2]
+    if la[1] % ch or lb[1] % ch or a.data_ptr() % 16 or b.data_ptr() % 16:
+        return False
+    if (not la[0] or not lb[0]) and K % ch:
+        return False
+    if (la[0] and M % ch) or (lb[0] and N % ch):
+        return False
+    if a.dim() == 3 and (a.stride(0) % ch or b.stride(0) % ch):
+        return False
+    return True
+
+
+def pick_splits(M, N, K, tile, dtype):
+    """Split-K factor for skinny outputs (dense weight gradients: K = tokens): enough workgroups for ~2 per CU, K ranges of >= 4 tiles."""
+    bm, bn = TILES[tile]
+    blocks = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+    bk = 32 if dtype == torch.float32 else 64
+    ktiles = (K + bk - 1) // bk
+    if blocks >= 384 or ktiles < 8:
+        return 1
+    return max(1, min(ktiles // 4, (512 + blocks - 1) // blocks))
+
+
+def gemm(a, b, bias=None, act=None, residual=None, alpha=1.0, out=None, out_dtype=None, tile=None, splits=None, accum=False):
+    """C = act(alpha * a . b^T + bias) (+ residual) for operand VIEWS in any of the four layouts: pass ``w`` ([N, K]) for the NT form,
+    ``w.t()`` of a [K, N] matrix for NN, ``x.t()`` of a [K, M] matrix for TN - no transpose copy is made (native/csrc/gemm_trans.h).
+    3-D operands are a strided batch. ``splits`` > 1 (or None = heuristic) cuts K over workgroups (fp32 output, atomics)."""
+    assert supported_ex(a, b), "gemm: same-dtype 2-D / 3-D views, each K-contiguous or transposed, with 16-byte aligned chunks"
+    batched = a.dim() == 3
+    M, K, N = a.shape[-2], a.shape[-1], b.shape[-2]
+    B = a.shape[0] if batched else 1
+    (ta, lda), (tb, ldb) = _layout(a), _layout(b)
+    out_dtype = out_dtype or (out.dtype if out is not None else a.dtype)
+    assert out_dtype in (a.dtype, torch.float32)
+    f32out = out_dtype == torch.float32
+    t = (pick_tile(M, N, K, a.dtype) if tile is None else tile)
+    t = 0 if t == 4 else t
+    if splits is None:
+        splits = pick_splits(M, N, K, t, a.dtype) if (f32out and act in (None, "identity") and not batched) else 1
+    if splits > 1:
+        assert f32out and act in (None, "identity"), "split-K needs an fp32 output and a linear epilogue"
+    if out is None:
+        y = (torch.zeros if splits > 1 else torch.empty)((B, M, N) if batched else (M, N), device=a.device, dtype=out_dtype)
+    else:
+        y = out
+        assert y.is_contiguous() and y.dtype == out_dtype and y.numel() == B * M * N
+        if splits > 1 and not accum:
+            y.zero_()
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        bias = bias.float().contiguous()
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == out_dtype and residual.is_contiguous()
+    d = (ctypes.c_int64 * 18)(M, N, K, lda, ldb, N, a.stride(0) if batched else 0, b.stride(0) if batched else 0, M * N, B, t, _DT[a.dtype],
+                              1 if (f32out and a.dtype != torch.float32) else 0, ACTS[act], 1 if ta else 0, 1 if tb else 0, int(splits),
+                              1 if (accum and splits <= 1) else 0)
+    L.check(L.hip().dl4j_gemm_ex2(L.ptr(a), L.ptr(b), L.ptr(y), L.ptr(bias), L.ptr(residual), ctypes.c_float(alpha), d, L.stream()), "gemm_ex2")
+    return y
+
+
+def matmul(x, w, **kw):
+    """Row-major x [.., M, K] @ w [.., K, N] without copies: w enters as the K-major operand."""
+    return gemm(x, w.transpose(-1, -2), **kw)

@@ -1,0 +1,75 @@
+"""Every operand layout of the in-tree MFMA GEMM (native/csrc/gemm_trans.h: NN / TN / TT next to the native NT form, strided batches,
+split-K) against fp32 torch matmuls. Reference coverage: libnd4j/include/helpers/cuda_off/MmulHelper.cu:255-341 (all transposes to
+cuBLAS), helpers/cuda/batched_gemm.cu:145-193."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def _operands(M, N, K, ta, tb, dt, batch=None, pad=0):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    lead = () if batch is None else (batch,)
+
+    def make(rows, cols, transposed):
+        if transposed:                      # stored [cols, rows + pad], viewed as [rows, cols]
+            t = torch.randn(*lead, cols, rows + pad, generator=g).to(dev()).to(dt)
+            return t[..., :rows].transpose(-1, -2)
+        t = torch.randn(*lead, rows, cols + pad, generator=g).to(dev()).to(dt)
+        return t[..., :cols]
+    return make(M, K, ta), make(N, K, tb)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 2e-2), (torch.float16, 4e-3), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_all_four_layouts_match_torch(dt, tol, ta, tb):
+    from deeplearning4j_amd.ops import gemm as G
+    ch = 4 if dt == torch.float32 else 8
+    for (M, N, K), tile in (((256, 256, 256), 0), ((136, 72, 200), 1), ((64, 64, 64), 2), ((40, 264, 1024), 3), ((1000, 520, 96), None),
+                            ((8, 8, 32), 2)):
+        for pad in (0, ch):
+            a, b = _operands(M, N, K, ta, tb, dt, pad=pad)
+            assert G.supported_ex(a, b), (M, N, K, ta, tb, pad)
+            got = G.gemm(a, b, tile=tile, splits=1)
+            ref = a.float() @ b.float().transpose(-1, -2)
+            scale = float(ref.abs().max())
+            assert got.dtype == dt and got.shape == ref.shape
+            err = float((got.float() - ref).abs().max())
+            assert err <= tol * scale + 1e-5, (M, N, K, ta, tb, pad, tile, err, scale)
+
+
+def test_epilogue_batch_and_split_k_on_transposed_operands():
+    from deeplearning4j_amd.ops import gemm as G
+    # bias + activation + residual on the NN form (row-major x @ w)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(300, 192, generator=g).to(dev()).bfloat16()
+    w = torch.randn(192, 136, generator=g).to(dev()).bfloat16()
+    bias = torch.randn(136, generator=g).to(dev())
+    res = torch.randn(300, 136, generator=g).to(dev()).bfloat16()
+    got = G.matmul(x, w, bias=bias, act="relu", residual=res)
+    ref = torch.relu(x.float() @ w.float() + bias) + res.float()
+    assert float((got.float() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+    # strided batch, TN per batch item: scores^T-like products
+    a, b = _operands(72, 88, 160, True, True, torch.bfloat16, batch=5)
+    got = G.gemm(a, b, out_dtype=torch.float32)
+    ref = a.float() @ b.float().transpose(-1, -2)
+    assert got.shape == (5, 72, 88) and float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # dense weight gradient shape: dW[nOut, nIn] = dz^T . x, K = tokens, both operands K-major, split over K with fp32 atomics
+    for dt, tol in ((torch.bfloat16, 2e-2), (torch.float32, 3e-4)):
+        dz = torch.randn(4096, 264, generator=g).to(dev()).to(dt)
+        xx = torch.randn(4096, 520, generator=g).to(dev()).to(dt)
+        ref = dz.float().t() @ xx.float()
+        for splits in (None, 1, 7):
+            got = G.gemm(dz.t(), xx.t(), out_dtype=torch.float32, splits=splits)
+            assert float((got - ref).abs().max()) <= tol * float(ref.abs().max()), (dt, splits)
+        acc = torch.ones(264, 520, device=dev())
+        G.gemm(dz.t(), xx.t(), out=acc, splits=4, accum=True)                    # += into the gradient buffer
+        assert float((acc - 1 - ref).abs().max()) <= tol * float(ref.abs().max())
+    # host-side refusals
+    assert not G.supported_ex(x[:, ::2], w.t())                                   # neither dim dense
+    assert not G.supported_ex(x, torch.randn(136, 100, device=dev()).bfloat16())  # K mismatch
+    assert not G.supported_ex(torch.randn(60, 33, device=dev()).bfloat16().t(), torch.randn(64, 60, device=dev()).bfloat16())  # M % 8 with K-major A
