@@ -42,9 +42,16 @@ def _reverse(ins, i, t, b, d):
 
 
 def _matmul(ins, i, t, b, d):
-    tb = len(i) > 1 and bool(i[1])
-    if len(ins) >= 2 and ins[0].dim() == 2 and ins[1].dim() == 2 and not tb:
-        return "NN form (right operand [K, N]): the MFMA kernel is NT and has to transpose it first; hipBLASLt measured 2.2x faster at 4096x1024x4096 bf16"
+    """Plain GEMMs (no fused epilogue): the vendor library is ahead on most shapes in every operand layout
+    (profiles/r3_gemm_layouts.md: in-tree NT / NN / TN / TT at 0.55-1.08x hipBLASLt; >= 0.92x only around 4096 x 768 x 768), so an
+    untracked 2-D matmul goes to it unless the product is small enough that the two are level."""
+    if len(ins) >= 2 and ins[0].dim() == 2 and ins[1].dim() == 2:
+        m, k = ins[0].shape[-2], ins[0].shape[-1]
+        if i and int(i[0]):
+            m, k = k, m
+        n = ins[1].shape[-2] if (i and len(i) > 1 and int(i[1])) else ins[1].shape[-1]
+        if 2.0 * m * n * k > 6e9 or min(m, n, k) < 256:
+            return "plain 2-D GEMM %dx%dx%d: hipBLASLt measured 1.2-1.8x faster than the in-tree kernel at this size (in-tree wins / ties only near 4096x768x768)" % (m, n, k)
     return None
 
 

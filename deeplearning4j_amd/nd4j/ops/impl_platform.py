@@ -724,6 +724,81 @@ def _xw_plus_b_hip(ins, i, t, b, d):
     return LIN.linear(ins[0], ins[1], ins[2] if len(ins) > 2 else None)
 
 
+def _mm_views(ins, i):
+    """(a [.., M, K] view, b [.., N, K] view) of matmul's operands under its transposeX / transposeY flags - no copies."""
+    ta = bool(i and int(i[0]))
+    tb = bool(i and len(i) > 1 and int(i[1]))
+    a, bb = ins[0], ins[1]
+    a = a.transpose(-1, -2) if ta else a
+    bb = bb if tb else bb.transpose(-1, -2)
+    return a, bb
+
+
+def _mm_any_ok(ins, i, t, b, d):
+    """matmul in ANY transpose combination, 2-D or equal-rank 3-D (strided batch), alpha free, beta 0, result not transposed, no autograd:
+    the operand views go straight to the layout-aware MFMA GEMM (native/csrc/gemm_trans.h)."""
+    from ...ops import gemm as G
+    if len(ins) != 2 or not (_fx(ins[0]) and _fx(ins[1])) or ins[0].dim() != ins[1].dim() or ins[0].dim() not in (2, 3):
+        return False
+    if (i and len(i) > 2 and int(i[2])) or (t and len(t) > 1 and float(t[1]) != 0.0):
+        return False
+    if torch.is_grad_enabled() and (ins[0].requires_grad or ins[1].requires_grad):
+        return False
+    a, bb = _mm_views(ins, i)
+    return G.supported_ex(a, bb)
+
+
+@platform("matmul", _mm_any_ok)
+def _matmul_any_hip(ins, i, t, b, d):
+    from ...ops import gemm as G
+    a, bb = _mm_views(ins, i)
+    return G.gemm(a, bb, alpha=float(t[0]) if t else 1.0, splits=1)
+
+
+def _bg_ok(ins, i, t, b, d):
+    """batched_gemm (alpha, beta, A_0.., B_0..): every pair through the layout-aware MFMA GEMM; beta must be 0 (no C operands in this
+    form of the op), operands 2-D of one shape per side."""
+    from ...ops import gemm as G
+    n = int(i[8]) if i and len(i) > 8 else (len(ins) - 2) // 2
+    if n < 1 or len(ins) < 2 + 2 * n or not all(_fx(x) and x.dim() == 2 for x in ins[2:2 + 2 * n]):
+        return False
+    if ins[1].numel() and float(ins[1].reshape(-1)[0]) != 0.0:
+        return False
+    if torch.is_grad_enabled() and any(x.requires_grad for x in ins[2:2 + 2 * n]):
+        return False
+    ta, tb = bool(i and i[0] in (1, 112)), bool(i and len(i) > 1 and i[1] in (1, 112))
+    return all(G.supported_ex(ins[2 + k].t() if ta else ins[2 + k], ins[2 + n + k] if tb else ins[2 + n + k].t()) for k in range(n))
+
+
+@platform("batched_gemm", _bg_ok)
+def _batched_gemm_hip(ins, i, t, b, d):
+    from ...ops import gemm as G
+    n = int(i[8]) if i and len(i) > 8 else (len(ins) - 2) // 2
+    ta, tb = bool(i and i[0] in (1, 112)), bool(i and len(i) > 1 and i[1] in (1, 112))
+    al = ins[0].reshape(-1)
+    same = len({(x.shape, x.stride()) for x in ins[2:2 + n]}) == 1 and len({(x.shape, x.stride()) for x in ins[2 + n:2 + 2 * n]}) == 1
+    A, B = ins[2:2 + n], ins[2 + n:2 + 2 * n]
+    if same and al.numel() == 1 and n > 1:
+        # equally spaced operands (views of one buffer): ONE strided-batch launch
+        da, db = A[1].data_ptr() - A[0].data_ptr(), B[1].data_ptr() - B[0].data_ptr()
+        es = A[0].element_size()
+        if da > 0 and db > 0 and da % es == 0 and db % es == 0 and \
+                all(A[k].data_ptr() - A[0].data_ptr() == k * da and B[k].data_ptr() - B[0].data_ptr() == k * db for k in range(n)):
+            sa = torch.as_strided(A[0], (n,) + tuple(A[0].shape), (da // es,) + tuple(A[0].stride()))
+            sb = torch.as_strided(B[0], (n,) + tuple(B[0].shape), (db // es,) + tuple(B[0].stride()))
+            sa = sa.transpose(-1, -2) if ta else sa
+            sb = sb if tb else sb.transpose(-1, -2)
+            if G.supported_ex(sa, sb):
+                C = G.gemm(sa, sb, alpha=float(al[0]), splits=1)
+                return tuple(C[k] for k in range(n))
+    outs = []
+    for k in range(n):
+        a = A[k].t() if ta else A[k]
+        bb = B[k] if tb else B[k].t()
+        outs.append(G.gemm(a, bb, alpha=float(al[0] if al.numel() == 1 else al[k]), splits=1))
+    return tuple(outs)
+
+
 def _mm_ok(ins, i, t, b, d):
     """matmul(x [.., M, K], w [K, N]) with a plain 2-D right operand, no transposes / alpha / beta: the dense-layer shape."""
     from ...ops import linear as LIN
@@ -736,25 +811,6 @@ def _mm_ok(ins, i, t, b, d):
 def _matmul_hip(ins, i, t, b, d):
     from ...ops import linear as LIN
     return LIN.linear(ins[0], ins[1], None)
-
-
-def _bgemm_ok(ins, i, t, b, d):
-    """matmul of two rank-3 operands with transB (attention scores q . k^T): strided-batched NT GEMM, inference only."""
-    from ...ops import gemm as G
-    if len(ins) != 2 or not i or len(i) < 2 or int(i[0]) or not int(i[1]) or (len(i) > 2 and int(i[2])):
-        return False
-    a, bb = ins
-    if not (_fx(a) and _fx(bb) and a.dim() == 3 and bb.dim() == 3 and a.dtype == bb.dtype and a.shape[0] == bb.shape[0]):
-        return False
-    ch = G.chunk(a.dtype)
-    return a.shape[2] == bb.shape[2] and a.shape[2] % ch == 0 and a.is_contiguous() and bb.is_contiguous() and \
-        (not t or (float(t[0]) != 0.0 and (len(t) < 2 or float(t[1]) == 0.0)))
-
-
-@platform("matmul", _bgemm_ok)
-def _matmul_batched_hip(ins, i, t, b, d):
-    from ...ops import gemm as G
-    return G.bgemm_nt(ins[0], ins[1], alpha=float(t[0]) if t else 1.0)
 
 
 # ----------------------------------------------------------------------------- fused_dense (MI355X graph-fusion target, not a reference op)

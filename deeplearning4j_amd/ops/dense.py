@@ -2,7 +2,8 @@
 
     z  = x . Wt^T + b            ops/gemm.py gemm_nt (bias in the epilogue)            Wt = [nOut, nIn], DL4J's 'f'-ordered W in memory
     dx = dz . W_dgrad^T          gemm_nt on the [nIn, nOut] image of W kept by the cast table ("dgrad" replica)
-    dW = dz^T . x                the split-K weight-gradient kernel (a dense layer is a 1x1 convolution over M "pixels")
+    dW = dz^T . x                the TN form of the LDS-DMA GEMM core when the output fills the chip, else the split-K weight-gradient
+                                 kernel (a dense layer is a 1x1 convolution over M "pixels")
 
 Reference: nn/layers/BaseLayer.java:92-111 (backpropGradient: gemm(input, delta, true, false), W.mmul(delta^T)^T) and :322-331
 (preOutput), which go to cuBLAS through MmulHelper; here no rocBLAS/hipBLASLt kernel (``Cijk_*``) is launched for these shapes.
@@ -40,8 +41,19 @@ def dw_ok(dz2, x2, dw_t):
     return x2.dtype in (torch.bfloat16, torch.float16, torch.float32) and x2.shape[1] % ch == 0 and dz2.shape[1] % ch == 0
 
 
+def _tn_core_wins(nOut, nIn, dtype):
+    """Measured (profiles/r3_gemm_layouts.md): the TN kernel on the LDS-DMA core beats the round-1 wgrad kernel when the output alone
+    fills the chip (>= 128 tiles of 128 x 128, no split-K: 768 x 3072 51.9 vs 71.2 us, 4096 x 4096 383 vs 527 us); below that the
+    round-1 kernel's LDS-reduced split-K atomics are ahead (768 x 768 25 vs 43 us)."""
+    return dtype in (torch.bfloat16, torch.float16) and ((nOut + 127) // 128) * ((nIn + 127) // 128) >= 128
+
+
 def dw(dz2, x2, dw_t, prezeroed):
     M, nIn = x2.shape
     nOut = dz2.shape[1]
+    if _tn_core_wins(nOut, nIn, x2.dtype) and G.supported_ex(dz2.t(), x2.t()):
+        # dW[nOut, nIn] = dz^T . x with both operands read K-major (no transposes); accumulates like the atomics of the other path
+        G.gemm(dz2.t(), x2.t(), out=dw_t, splits=1, accum=bool(prezeroed))
+        return
     IG.wgrad(dz2.view(M, nOut, 1, 1), x2.view(M, nIn, 1, 1), (nOut, nIn, 1, 1), (1, 1), (0, 0), (1, 1), dw_out=dw_t.view(nOut, nIn, 1, 1),
              prezeroed=prezeroed)

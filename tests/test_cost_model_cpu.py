@@ -13,8 +13,11 @@ def test_rules_decline_the_measured_slow_shapes_only():
     assert CM.prefer_generic("pad", [wide, torch.tensor([[0, 0], [1, 1]])], [0], [0.0], [], []) is None
     assert CM.prefer_generic("reverse", [img], [3], [], [], []) is not None and CM.prefer_generic("reverse", [wide], [1], [], [], []) is None
     a, b = torch.empty(128, 64), torch.empty(64, 256)
-    assert "NN form" in CM.prefer_generic("matmul", [a, b], [], [], [], [])
-    assert CM.prefer_generic("matmul", [a, torch.empty(256, 64)], [0, 1], [], [], []) is None
+    assert "plain 2-D GEMM 128x256x64" in CM.prefer_generic("matmul", [a, b], [], [], [], [])
+    assert "8192x4096x4096" in CM.prefer_generic("matmul", [torch.empty(8192, 4096, device="meta"), torch.empty(4096, 4096, device="meta")], [0, 1], [], [], [])
+    level = [torch.empty(4096, 768, device="meta"), torch.empty(768, 768, device="meta")]
+    assert CM.prefer_generic("matmul", level, [], [], [], []) is None and CM.prefer_generic("matmul", level, [0, 1], [], [], []) is None
+    assert CM.prefer_generic("matmul", [torch.empty(6, 40, 64), torch.empty(6, 24, 64)], [0, 1], [], [], []) is None      # batched: in-tree
     assert CM.prefer_generic("xw_plus_b", [a, b, torch.empty(256)], [], [], [], []) is not None
     assert CM.prefer_generic("biasadd", [img, torch.empty(64)], [], [], [True], []) is not None
     assert CM.prefer_generic("biasadd", [wide, torch.empty(4096)], [], [], [], []) is None

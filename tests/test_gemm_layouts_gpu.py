@@ -73,3 +73,45 @@ def test_epilogue_batch_and_split_k_on_transposed_operands():
     assert not G.supported_ex(x[:, ::2], w.t())                                   # neither dim dense
     assert not G.supported_ex(x, torch.randn(136, 100, device=dev()).bfloat16())  # K mismatch
     assert not G.supported_ex(torch.randn(60, 33, device=dev()).bfloat16().t(), torch.randn(64, 60, device=dev()).bfloat16())  # M % 8 with K-major A
+
+
+def test_matmul_and_batched_gemm_ops_take_every_layout_without_copies(monkeypatch):
+    """The custom ops reach the layout-aware kernel: no transpose / contiguous copy and no library GEMM inside the route."""
+    from deeplearning4j_amd.nd4j.ops import cost_model
+    from deeplearning4j_amd.nd4j.ops.custom import exec_op, OpExecutioner
+    monkeypatch.setattr(cost_model, "ENABLED", False)
+    g = torch.Generator().manual_seed(9)
+    A = torch.randn(264, 520, generator=g).to(dev()).bfloat16()          # used as [M, K] or as [K, M]
+    for ta in (0, 1):
+        for tb in (0, 1):
+            M, K = (520, 264) if ta else (264, 520)
+            B = torch.randn(*((136, K) if tb else (K, 136)), generator=g).to(dev()).bfloat16()
+            ref = (A.float().t() if ta else A.float()) @ (B.float().t() if tb else B.float())
+            OpExecutioner.resetHelperStatistics()
+            real = torch.matmul
+            monkeypatch.setattr(torch, "matmul", lambda *a, **k: (_ for _ in ()).throw(AssertionError("library GEMM")))
+            monkeypatch.setattr(torch.Tensor, "contiguous", lambda self, *a, **k: (_ for _ in ()).throw(AssertionError("copy")))
+            try:
+                got = exec_op("matmul", [A, B], iArgs=[ta, tb, 0], tArgs=[0.5, 0.0])[0]
+            finally:
+                monkeypatch.undo()
+                monkeypatch.setattr(cost_model, "ENABLED", False)
+            assert real is torch.matmul
+            assert OpExecutioner.helperStatistics()["hit"].get("matmul") == 1
+            assert got.shape == (M, 136) and float((got.float() - 0.5 * ref).abs().max()) <= 2e-2 * float(ref.abs().max()), (ta, tb)
+    # batched_gemm: equally spaced operands -> one strided-batch launch; separate arrays -> one launch per pair
+    bufA = torch.randn(5, 72, 160, generator=g).to(dev()).bfloat16()
+    bufB = torch.randn(5, 160, 88, generator=g).to(dev()).bfloat16()
+    alpha, beta = torch.tensor(2.0, device=dev()), torch.tensor(0.0, device=dev())
+    OpExecutioner.resetHelperStatistics()
+    outs = exec_op("batched_gemm", [alpha, beta] + [bufA[k] for k in range(5)] + [bufB[k] for k in range(5)], iArgs=[0, 0, 72, 88, 160, 72, 160, 72, 5])
+    assert OpExecutioner.helperStatistics()["hit"].get("batched_gemm") == 1 and len(outs) == 5
+    for k in range(5):
+        ref = 2.0 * bufA[k].float() @ bufB[k].float()
+        assert float((outs[k].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    loose = [torch.randn(160, 72, generator=g).to(dev()).bfloat16() for _ in range(3)]          # transA form, separately allocated
+    looseB = [torch.randn(88, 160, generator=g).to(dev()).bfloat16() for _ in range(3)]         # transB form
+    outs = exec_op("batched_gemm", [alpha, beta] + loose + looseB, iArgs=[1, 1, 72, 88, 160, 160, 88, 72, 3])
+    for k in range(3):
+        ref = 2.0 * loose[k].float().t() @ looseB[k].float().t()
+        assert float((outs[k].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
