@@ -104,20 +104,50 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const typename V8<DT>::T* 
   }
 }
 
-// grid (ceil(N / 512), row blocks); 256 threads = 64 column chunks x 4 row lanes
+// grid (ceil(N / 256), row blocks); 256 threads = 32 column chunks x 8 row lanes. The pass is short (a [4096, 768] bf16 operand is 6 MB),
+// so what matters is memory-level parallelism, not the instruction count: a thread issues the loads of FOUR rows before it touches any of
+// them (the one-row-per-trip loop of round 2 paid one memory latency per row: 12.8 us for 16 rows per thread at 4096 x 768, against
+// ~3 us of traffic), and the grid is sized from N in 256-column slices so narrow operands do not leave half a block idle.
 template <int DT>
 __global__ void __launch_bounds__(256) act_bwd_colsum_kernel(const typename V8<DT>::T* __restrict__ z,
                                                              const typename V8<DT>::T* __restrict__ dy,
                                                              typename V8<DT>::T* __restrict__ dz, float* __restrict__ db, int64_t M, int N,
                                                              int64_t rows_per_block, int act) {
-  __shared__ float red[4][512];
-  const int cc = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 512 + cc * 8;
+  __shared__ float red[8][256];
+  const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 256 + cc * 8;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (col < N) {
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
+    int64_t r = r0 + rl;
+    for (; r + 24 < r1; r += 32) {
+      float g0[8], g1[8], g2[8], g3[8];
+      V8<DT>::ld(dy + r * N + col, g0);
+      V8<DT>::ld(dy + (r + 8) * N + col, g1);
+      V8<DT>::ld(dy + (r + 16) * N + col, g2);
+      V8<DT>::ld(dy + (r + 24) * N + col, g3);
+      if (z != nullptr) {
+        float v0[8], v1[8], v2[8], v3[8];
+        V8<DT>::ld(z + r * N + col, v0);
+        V8<DT>::ld(z + (r + 8) * N + col, v1);
+        V8<DT>::ld(z + (r + 16) * N + col, v2);
+        V8<DT>::ld(z + (r + 24) * N + col, v3);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          g0[k] *= act_d(v0[k], act); g1[k] *= act_d(v1[k], act); g2[k] *= act_d(v2[k], act); g3[k] *= act_d(v3[k], act);
+        }
+      }
+      if (dz != nullptr) {
+        V8<DT>::st(dz + r * N + col, g0);
+        V8<DT>::st(dz + (r + 8) * N + col, g1);
+        V8<DT>::st(dz + (r + 16) * N + col, g2);
+        V8<DT>::st(dz + (r + 24) * N + col, g3);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += (g0[k] + g1[k]) + (g2[k] + g3[k]);
+    }
+    for (; r < r1; r += 8) {
       float g[8];
       V8<DT>::ld(dy + r * N + col, g);
       if (z != nullptr) {
@@ -135,9 +165,12 @@ __global__ void __launch_bounds__(256) act_bwd_colsum_kernel(const typename V8<D
 #pragma unroll
   for (int k = 0; k < 8; ++k) red[rl][cc * 8 + k] = s[k];
   __syncthreads();
-  for (int c = threadIdx.x; c < 512; c += 256) {
-    const int n = blockIdx.x * 512 + c;
-    if (n < N) atomicAdd(db + n, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][threadIdx.x];
+    atomicAdd(db + n, t);
   }
 }
 
@@ -165,11 +198,14 @@ DL4J_API int dl4j_act_bwd_colsum(const void* z, const void* dy, void* dz, float*
                                  hipStream_t st) {
   if (M <= 0 || N <= 0) return 0;
   if (N % 8) return -3;
-  const int gx = (N + 511) / 512;
-  int64_t gy = (M + 63) / 64;
+  const int gx = (N + 255) / 256;
+  // 32 rows per block (4 per thread, all in flight at once) until that makes more than ~8 blocks per CU; then longer row ranges
+  int64_t gy = (M + 31) / 32;
+  const int64_t want = (2048 + gx - 1) / gx;
+  if (gy > want) gy = want;
   const int64_t cap = (DL4J_MAX_GRID + gx - 1) / gx;
   if (gy > cap) gy = cap;
-  const int64_t rpb = (((M + gy - 1) / gy) + 3) / 4 * 4;
+  const int64_t rpb = (((M + gy - 1) / gy) + 31) / 32 * 32;
   gy = (M + rpb - 1) / rpb;
   DISPATCH_DT(typedef typename V8<DT>::T T;
               hipLaunchKernelGGL(act_bwd_colsum_kernel<DT>, dim3(gx, (unsigned)gy), dim3(256), 0, st, (const T*)z, (const T*)dy, (T*)dz,

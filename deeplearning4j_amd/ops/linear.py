@@ -231,10 +231,12 @@ def fused_dense(x, w, bias=None, residual=None, act=None):
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     r2 = None if residual is None else residual.reshape(-1, N).contiguous()
+    wt = w.t()                                   # [N, K] view of the [K, N] weight: read K-major by the layout-aware kernel, no copy
+    mm = (lambda **kw: G.gemm(x2, wt, splits=1, **kw)) if G.supported_ex(x2, wt) else (lambda **kw: G.gemm_nt(x2, wt.contiguous(), **kw))
     if a in _EPI_ACT:
-        y = G.gemm_nt(x2, w.t().contiguous(), bias=f32_operand(bias), act=_EPI_ACT[a], residual=r2)
+        y = mm(bias=f32_operand(bias), act=_EPI_ACT[a], residual=r2)
     else:
-        y = act_fwd(G.gemm_nt(x2, w.t().contiguous(), bias=f32_operand(bias)), a)
+        y = act_fwd(mm(bias=f32_operand(bias)), a)
         if r2 is not None:
             y = y + r2
     return y.view(*x.shape[:-1], N)
