@@ -16,7 +16,7 @@ import torch
 
 from ..native import lib as L
 
-TILES = ((128, 128), (128, 64), (64, 64), (64, 128), (256, 256))
+TILES = ((128, 128), (128, 64), (64, 64), (64, 128), (256, 256), (128, 128), (128, 64), (64, 64), (64, 128), (64, 64))   # 5..9: deeper pipelines of 0..3 / 2
 _DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 ACTS = {None: 0, "identity": 0, "relu": 1, "gelu": 2, "gelu_tanh": 2, "gelu_erf": 3, "tanh": 4, "sigmoid": 5}
 
@@ -37,17 +37,15 @@ def supported(x, w):
 
 
 def pick_tile(M, N, K, dtype):
-    """Measured on MI355X with tools/gemm_lab (profiles/r2_gemm_lab_v2.txt, r2_gemm_lab_v4_pingpong.txt)."""
+    """Measured on MI355X (tools/gemm_tile_sweep.py -> profiles/r3_gemm_tile_sweep.md): the 64-row tiles win everywhere below the
+    ping-pong regime because three of their workgroups fit a CU's LDS (48 KB each with two stages) and hide each other's barriers; the
+    128 x 128 tile (two per CU) and the three / four stage variants (5..9) lose on every shape of the sweep."""
     def blocks(t):
         bm, bn = TILES[t]
         return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     if dtype == torch.bfloat16 and blocks(4) >= 448 and K >= 2048:
         return 4                                  # 256x256 ping-pong: only when it fills the chip ~2x with a deep K loop
-    if blocks(0) >= 1536 and K >= 1024:
-        return 0
-    if blocks(1) >= 640:
-        return 1
-    if N >= 128 and M < 128:
+    if N >= 128 and blocks(3) >= 512:
         return 3
     return 2
 
