@@ -89,6 +89,216 @@ __global__ void layer_norm_bwd_dx_kernel(const T* __restrict__ x, const T* __res
   }
 }
 
+// ---- register-resident forms (rows of whole 16-byte chunks, up to MAXC chunks per lane): ONE wave owns a row, reads it once with
+// 16-byte loads, keeps it in registers for the mean, the (two-pass) variance and the output, and reduces with 64-lane shuffles - no
+// LDS, no workgroup barrier. The block-per-row kernels above re-read the row three times with 2-byte loads and two barriers: 17.9 us
+// forward / 13.9 + 7.0 us backward at [4096, 768] bf16 (profiles/r3_bert_kernels.md), i.e. ~0.7 TB/s. The backward form also folds the
+// dgamma / dbeta column partials in (registers -> LDS atomics -> one partial row per block), so x and g are read once instead of twice.
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16_t> {
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&f)[8]) {
+    const s16x8 v = *reinterpret_cast<const s16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = bf2f((bf16_t)v[i]);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&f)[8]) {
+    s16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (short)f2bf(f[i]);
+    *reinterpret_cast<s16x8*>(p) = v;
+  }
+};
+template <> struct Vec16<float> {
+  static constexpr int V = 4;
+  static __device__ __forceinline__ void ld(const float* p, float (&f)[4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&f)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]}; }
+};
+// parameter vectors are views of a flat parameter vector: 16-byte alignment is usual but not guaranteed (wave-uniform branch)
+template <int V> __device__ __forceinline__ void ld_f32(const float* p, float (&f)[V]) {
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < V; i += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+      f[i] = v[0]; f[i + 1] = v[1]; f[i + 2] = v[2]; f[i + 3] = v[3];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) f[i] = p[i];
+  }
+}
+
+template <typename T, int MAXC>
+__global__ void __launch_bounds__(256) layer_norm_fwd_wave_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
+                                                                  float* __restrict__ rstd, int64_t rows, int cols, float eps) {
+  constexpr int V = Vec16<T>::V;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  const int nch = cols / V;
+  const T* xr = x + r * cols;
+  float v[MAXC][V];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      Vec16<T>::ld(xr + c * V, v[i]);
+#pragma unroll
+      for (int k = 0; k < V; ++k) s += v[i][k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) v[i][k] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < nch) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) { const float d = v[i][k] - mu; q += d * d; }
+    }
+  const float rs = rsqrtf(wave_sum(q) / cols + eps);
+  if (lane == 0) { if (mean) mean[r] = mu; if (rstd) rstd[r] = rs; }
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float o[V], gm[V], bt[V];
+      if (gamma) ld_f32<V>(gamma + c * V, gm);
+      if (beta) ld_f32<V>(beta + c * V, bt);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        o[k] = (v[i][k] - mu) * rs;
+        if (gamma) o[k] *= gm[k];
+        if (beta) o[k] += bt[k];
+      }
+      Vec16<T>::st(y + r * cols + c * V, o);
+    }
+  }
+}
+
+// block = 8 waves, rows [blockIdx.x * rpb, + rpb) dealt to the waves round-robin; partial (optional) [gridDim.x][2][cols]
+template <typename T, int MAXC>
+__global__ void __launch_bounds__(512) layer_norm_bwd_wave_kernel(const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  T* __restrict__ dx, float* __restrict__ partial, int64_t rows, int cols,
+                                                                  int64_t rpb) {
+  constexpr int V = Vec16<T>::V;
+  constexpr int MAXCOLS = MAXC * 64 * V;
+  __shared__ float acc[2 * MAXCOLS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = cols / V;
+  if (partial) {
+    for (int c = threadIdx.x; c < 2 * MAXCOLS; c += 512) acc[c] = 0.f;
+    __syncthreads();
+  }
+  float gm[MAXC][V], dg[MAXC][V], db[MAXC][V];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+#pragma unroll
+    for (int k = 0; k < V; ++k) { gm[i][k] = 1.f; dg[i][k] = 0.f; db[i][k] = 0.f; }
+    if (gamma && c < nch) ld_f32<V>(gamma + c * V, gm[i]);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = r0 + rpb < rows ? r0 + rpb : rows;
+  for (int64_t r = r0 + wave; r < r1; r += 8) {
+    float xv[MAXC][V], gv[MAXC][V];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        Vec16<T>::ld(x + r * cols + c * V, xv[i]);
+        Vec16<T>::ld(g + r * cols + c * V, gv[i]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) { xv[i][k] = 0.f; gv[i][k] = 0.f; }
+      }
+    }
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const float xh = (xv[i][k] - mu) * rs, gg = gv[i][k] * gm[i][k];
+          xv[i][k] = xh;
+          s1 += gg; s2 += gg * xh;
+          dg[i][k] += gv[i][k] * xh;
+          db[i][k] += gv[i][k];
+        }
+      }
+    s1 = wave_sum(s1) / cols;
+    s2 = wave_sum(s2) / cols;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float o[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = rs * (gv[i][k] * gm[i][k] - s1 - xv[i][k] * s2);
+        Vec16<T>::st(dx + r * cols + c * V, o);
+      }
+    }
+  }
+  if (!partial) return;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        atomicAdd(&acc[c * V + k], dg[i][k]);
+        atomicAdd(&acc[MAXCOLS + c * V + k], db[i][k]);
+      }
+    }
+  }
+  __syncthreads();
+  float* out = partial + (int64_t)blockIdx.x * 2 * cols;
+  for (int c = threadIdx.x; c < cols; c += 512) {
+    out[c] = acc[c];
+    out[cols + c] = acc[MAXCOLS + c];
+  }
+}
+
+template <typename T> int ln_maxc(int cols) {
+  constexpr int V = Vec16<T>::V;
+  if (cols % V) return 0;
+  const int nch = cols / V;
+  return nch <= 64 ? 1 : nch <= 128 ? 2 : nch <= 256 ? 4 : 0;
+}
+template <typename T>
+bool ln_fwd_wave(const T* x, const float* gamma, const float* beta, T* y, float* mean, float* rstd, int64_t rows, int cols, float eps,
+                 hipStream_t st) {
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  switch (ln_maxc<T>(cols)) {
+    case 1: hipLaunchKernelGGL((layer_norm_fwd_wave_kernel<T, 1>), grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, cols, eps); return true;
+    case 2: hipLaunchKernelGGL((layer_norm_fwd_wave_kernel<T, 2>), grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, cols, eps); return true;
+    case 4: hipLaunchKernelGGL((layer_norm_fwd_wave_kernel<T, 4>), grid, dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, cols, eps); return true;
+    default: return false;
+  }
+}
+template <typename T>
+bool ln_bwd_wave(const T* x, const T* g, const float* gamma, const float* mean, const float* rstd, T* dx, float* partial, int64_t rows,
+                 int cols, int64_t rpb, int gy, hipStream_t st) {
+  switch (ln_maxc<T>(cols)) {
+    case 1: hipLaunchKernelGGL((layer_norm_bwd_wave_kernel<T, 1>), dim3(gy), dim3(512), 0, st, x, g, gamma, mean, rstd, dx, partial, rows, cols, rpb); return true;
+    case 2: hipLaunchKernelGGL((layer_norm_bwd_wave_kernel<T, 2>), dim3(gy), dim3(512), 0, st, x, g, gamma, mean, rstd, dx, partial, rows, cols, rpb); return true;
+    case 4: hipLaunchKernelGGL((layer_norm_bwd_wave_kernel<T, 4>), dim3(gy), dim3(512), 0, st, x, g, gamma, mean, rstd, dx, partial, rows, cols, rpb); return true;
+    default: return false;
+  }
+}
+bool ln_aligned(const void* a, const void* b, const void* c) {
+  return !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15);
+}
+
 // partial[gy][2][cols]: row 0 = sum g*xhat (dgamma), row 1 = sum g (dbeta); finished by dl4j_bn_sum_partials
 template <typename T>
 __global__ void layer_norm_bwd_param_kernel(const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ mean,
@@ -262,13 +472,20 @@ DL4J_API int dl4j_softmax_bwd_x(const void* x, const void* g, void* dx, int64_t 
 DL4J_API int dl4j_layer_norm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
                                  int cols, float eps, int dtype, hipStream_t st) {
   if (rows <= 0 || cols <= 0) return 0;
+  if (ln_aligned(x, y, nullptr)) {
+    bool done = false;
+    DISPATCH_T(done = ln_fwd_wave<T>((const T*)x, gamma, beta, (T*)y, mean, rstd, rows, cols, eps, st);)
+    if (done) DL4J_RET_LAST();
+  }
   DISPATCH_T(hipLaunchKernelGGL(layer_norm_fwd_kernel<T>, dim3((unsigned)rows), dim3(row_threads(cols)), 0, st, (const T*)x, gamma, beta,
                                 (T*)y, mean, rstd, rows, cols, eps);)
   DL4J_RET_LAST();
 }
 
+// rows of the partial buffer: one per workgroup of the backward pass (16 rows each, at most 512 of them)
 DL4J_API int dl4j_layer_norm_bwd_rows(int64_t rows) {
-  int64_t gy = rows < 256 ? rows : 256;
+  int64_t gy = (rows + 15) / 16;
+  if (gy > 512) gy = 512;
   return (int)(gy < 1 ? 1 : gy);
 }
 
@@ -278,6 +495,11 @@ DL4J_API int dl4j_layer_norm_bwd(const void* x, const void* g, const float* gamm
   if (rows <= 0 || cols <= 0) return 0;
   const int gy = dl4j_layer_norm_bwd_rows(rows);
   const int64_t rpb = (rows + gy - 1) / gy;
+  if (ln_aligned(x, g, dx)) {
+    bool done = false;
+    DISPATCH_T(done = ln_bwd_wave<T>((const T*)x, (const T*)g, gamma, mean, rstd, (T*)dx, partial, rows, cols, rpb, gy, st);)
+    if (done) DL4J_RET_LAST();
+  }
   const dim3 pg((cols + 255) / 256, gy);
   DISPATCH_T(
       hipLaunchKernelGGL(layer_norm_bwd_dx_kernel<T>, dim3((unsigned)rows), dim3(row_threads(cols)), 0, st, (const T*)x, (const T*)g,

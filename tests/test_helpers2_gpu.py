@@ -320,3 +320,31 @@ def test_upsampling2d_factor2_vector_path(dtype, W, fH):
         y = exec_op("upsampling2d", [x], iArgs=[fH, 2, 1])[0]
         y = y.tensor() if hasattr(y, "tensor") and callable(y.tensor) else y
     assert torch.equal(y, x.repeat_interleave(fH, 2).repeat_interleave(2, 3))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(4096, 768), (33, 8), (7, 512), (100, 1024), (5, 3, 2048), (64, 264)])
+def test_layer_norm_register_resident_kernels_match_fp32_math(dtype, shape):
+    """The one-wave-per-row layer norm (16-byte loads, row in registers, backward with folded dgamma / dbeta partials), including
+    parameter vectors that are NOT 16-byte aligned (views of a flat vector) and row counts that do not fill the last workgroup."""
+    from deeplearning4j_amd.ops import helpers as H
+    cols = shape[-1]
+    if dtype == torch.float32 and cols > 1024:
+        pytest.skip("fp32 rows beyond 1024 columns use the block-per-row kernels (covered by test_layer_norm_fwd_bwd)")
+    g_ = torch.Generator().manual_seed(3)
+    x = (torch.randn(*shape, generator=g_) * 2 + 0.5).to(dtype).cuda()
+    gr = torch.randn(*shape, generator=g_).to(dtype).cuda()
+    flat = torch.randn(2 * cols + 3, generator=g_).cuda()
+    gamma, beta = flat[1:1 + cols], flat[2 + cols:2 + 2 * cols]          # odd offsets: 4-byte aligned only
+    y, mean, rstd = H.layer_norm(x, gamma, beta, 1e-5, want_stats=True)
+    xf = x.float().requires_grad_(True)
+    gf, bf = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xf, (cols,), gf, bf, 1e-5)
+    tol = 3e-5 if dtype == torch.float32 else 4e-2
+    assert float((y.float() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    assert torch.allclose(mean, xf.detach().reshape(-1, cols).mean(1), atol=1e-4)
+    dx, dg, db = H.layer_norm_bwd(x, gr, gamma, mean, rstd)
+    ref.backward(gr.float())
+    assert float((dx.float() - xf.grad).abs().max()) <= tol * 4 * max(1.0, float(xf.grad.abs().max()))
+    assert float((dg - gf.grad).abs().max()) <= tol * 4 * max(1.0, float(gf.grad.abs().max()))
+    assert float((db - bf.grad).abs().max()) <= tol * 4 * max(1.0, float(bf.grad.abs().max()))
