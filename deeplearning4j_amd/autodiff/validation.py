@@ -233,10 +233,10 @@ def sweep(device="cpu", names=None, check_grad=True):
     """Walk the op registry through the case table (op_cases.py). Per op: status in
     {'reference', 'property', 'executed', 'failed', 'uncovered'} + details; for ops with a registered ``_bp`` and a differentiable
     case, the numeric gradient verdict. Mirrors OpValidation.java's coverage accounting (logCoverageInformation)."""
-    from ..nd4j.ops.custom import OpExecutioner, DynamicCustomOp, exec_op
+    from ..nd4j.ops.custom import OpExecutioner, DynamicCustomOp, exec_op, USER_DEFINED_OPS
     from .op_cases import cases
     table = cases()
-    all_ops = sorted(OpExecutioner.getInstance().getCustomOperations())
+    all_ops = sorted(n for n in OpExecutioner.getInstance().getCustomOperations() if n not in USER_DEFINED_OPS)
     if names is not None:
         all_ops = [n for n in all_ops if n in set(names)]
     report = {}

@@ -209,7 +209,10 @@ static int dispatch_gemm(GemmP& p, int tile, int batch, hipStream_t st) {
     case 2: return launch_gemm<Cfg<64, 64, 2, 2, 2, 16, DT>, OT>(p, batch, st);
     case 3: return launch_gemm<Cfg<64, 128, 2, 2, 2, 16, DT>, OT>(p, batch, st);
     case 4:
-      if constexpr (DT == DT_BF16 && OT == OT_BF16) return launch_gemm<Cfg<256, 256, 2, 4, 2, 16, DT>, OT, true>(p, batch, st);
+      if constexpr (DT == DT_BF16 && OT == OT_BF16) return launch_gemm<Cfg<256, 256, 2, 4, 2, 16, DT>, OT, 1>(p, batch, st);
+      else return -2;
+    case 10:  // 256x256 ping-pong, half-tile staging with counted waits (1.5 k-tiles of LDS-DMA in flight)
+      if constexpr (DT == DT_BF16 && OT == OT_BF16) return launch_gemm<Cfg<256, 256, 2, 4, 2, 16, DT>, OT, 2>(p, batch, st);
       else return -2;
     // deeper pipelines (counted vmcnt waits keep 1 - 2 k-tiles in flight across the barrier): 5..8 = tiles 0..3 with 3 stages, 9 = 64x64 with 4
     case 5: return launch_gemm<Cfg<128, 128, 2, 2, 3, 16, DT>, OT>(p, batch, st);

@@ -78,6 +78,9 @@ struct Cfg {
   static __device__ __forceinline__ int acc_row(int e, int lane) {
     return MF == 32 ? (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) : (lane >> 4) * 4 + e;
   }
+  // the same split into a lane part and a compile-time part (epilogue: one base address per lane + immediate offsets)
+  static __device__ __forceinline__ int acc_row_lane(int lane) { return MF == 32 ? 4 * (lane >> 5) : (lane >> 4) * 4; }
+  static constexpr int acc_row_const(int e) { return MF == 32 ? (e & 3) + 8 * (e >> 2) : e; }
   static __device__ __forceinline__ int acc_col(int lane) { return MF == 32 ? (lane & 31) : (lane & 15); }
   static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "wave tile is a multiple of the 32x32 MFMA block");
 };
@@ -296,6 +299,151 @@ __device__ __forceinline__ void mainloop_pingpong(char* smem, const Src& src, in
     PP_BAR();
   }
   if (grp == 0) PP_BAR();                 // re-align the two groups: every LDS read of the main loop is complete behind this
+#undef PP_BAR
+#undef PP_LOAD_END
+}
+
+// Deep-prefetch form of the ping-pong loop: same tile, wave groups, phases and fragment reads, but the K-tile is staged as four
+// HALF-TILES that are re-staged as soon as their last fragment read is behind a barrier, so every LDS-DMA has ~1.5 K-tiles (five to
+// six phases) to land and the loop never drains vmcnt to 0 (the drain in phase 3 of mainloop_pingpong exposed the L2 / HBM round trip
+// once per K-tile: ~600 cycles per phase against 256 of MFMA work):
+//   A-lo = rows g*128 + 0..63 (read in phase 0), A-hi = rows g*128 + 64..127 (phase 2), B-lo = cols wn*64 + 0..31 (phase 0),
+//   B-hi = cols wn*64 + 32..63 (phase 1); every wave stages two 1-KiB pieces of each half-tile.
+//   issue order (the order the counted waits assume):  phase 0: A-hi(t+1)   1: A-lo(t+2)   2: B-lo(t+2)   3: B-hi(t+2)
+//   waits (after the phase's issue, before its first barrier; the data is read one phase later):
+//     phase 0: vmcnt(10) -> B-hi(t) landed     phase 1: vmcnt(10) -> A-hi(t)     phase 3: vmcnt(10) -> A-lo(t+1), B-lo(t+1)
+//   (five half-tiles x 2 instructions stay in flight behind each wait).
+// WAR: a slot is re-staged at least one barrier after the lgkmcnt(0) + barrier that closes its last read by BOTH groups (group 1 runs
+// one barrier behind): A-lo/B-lo(t) are read in phase 0 (closed by barrier 8t+1) and re-staged in phases 1 / 2 (intervals >= 8t+2).
+// Tiles past the end are staged from the zero page, so the counts hold in the tail without branches.
+// Src: a_half(h, s, ktile) / b_half(h, s, ktile) -> this lane's source address for piece s (0..1) of half h of k-tile `ktile`.
+template <class C>
+__device__ __forceinline__ int pp_piece_a(int wid, int h, int s) { const int idx = wid * 2 + s; return (idx >> 3) * 16 + h * 8 + (idx & 7); }
+template <class C>
+__device__ __forceinline__ int pp_piece_b(int wid, int h, int s) { const int idx = wid * 2 + s; return (idx >> 2) * 8 + h * 4 + (idx & 3); }
+
+template <class C, class Src>
+__device__ __forceinline__ void mainloop_pingpong_deep(char* smem, const Src& src, int KT, typename C::acc_t (&acc)[C::TM][C::TN]) {
+  static_assert(C::BM == 256 && C::BN == 256 && C::WM == 2 && C::WN == 4 && C::MF == 16 && C::STAGES == 2, "ping-pong geometry");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wn = wid & 3;
+#pragma unroll
+  for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  // LDS byte offsets (inside a stage buffer) of this wave's two pieces of every half-tile
+  int oa[2][2], ob[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      oa[h][s] = pp_piece_a<C>(wid, h, s) * 1024;
+      ob[h][s] = C::A_BYTES + pp_piece_b<C>(wid, h, s) * 1024;
+    }
+  auto stage_ah = [&](int h, int t) {
+    char* sb = smem + (t & 1) * C::STAGE_BYTES;
+    glds16(src.a_half(h, 0, t), sb + oa[h][0]);
+    glds16(src.a_half(h, 1, t), sb + oa[h][1]);
+  };
+  auto stage_bh = [&](int h, int t) {
+    char* sb = smem + (t & 1) * C::STAGE_BYTES;
+    glds16(src.b_half(h, 0, t), sb + ob[h][0]);
+    glds16(src.b_half(h, 1, t), sb + ob[h][1]);
+  };
+  const int lr = lane & 15, lq = lane >> 4, sw = (lr >> 1) & 7;
+  int foff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) foff[ks] = lr * 128 + (((ks * 4 + lq) ^ sw) << 4);
+  const int a_wave = grp * 128 * 128;
+  const int b_wave = C::A_BYTES + wn * 64 * 128;
+  constexpr int BLK = 16 * 128;
+
+#define PP_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_LOAD_END() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_BAR(); } while (0)
+  stage_ah(0, 0); stage_bh(0, 0); stage_bh(1, 0); stage_ah(1, 0);
+  stage_ah(0, 1); stage_bh(0, 1); stage_bh(1, 1);
+  wait_vmcnt<6>();                        // k-tile 0 landed
+  PP_BAR();
+  if (grp == 1) PP_BAR();                 // stagger: group 1 runs one barrier behind group 0
+
+  bf16x8_t af[4][2], b0[2][2], b1[2][2];
+  for (int t = 0; t < KT; ++t) {
+    const char* cs = smem + (t & 1) * C::STAGE_BYTES;
+    // ---- phase 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(cs + a_wave + i * BLK + foff[ks]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b0[j][ks] = *reinterpret_cast<const bf16x8_t*>(cs + b_wave + j * BLK + foff[ks]);
+    stage_ah(1, t + 1);
+    wait_vmcnt<10>();
+    PP_LOAD_END();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], b0[j][ks], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PP_BAR();
+    // ---- phase 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) b1[j][ks] = *reinterpret_cast<const bf16x8_t*>(cs + b_wave + (2 + j) * BLK + foff[ks]);
+    stage_ah(0, t + 2);
+    wait_vmcnt<10>();
+    PP_LOAD_END();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], b1[j][ks], acc[i][2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PP_BAR();
+    // ---- phase 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const bf16x8_t*>(cs + a_wave + (4 + i) * BLK + foff[ks]);
+    stage_bh(0, t + 2);
+    PP_LOAD_END();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], b1[j][ks], acc[4 + i][2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PP_BAR();
+    // ---- phase 3
+    stage_bh(1, t + 2);
+    wait_vmcnt<10>();
+    PP_LOAD_END();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], b0[j][ks], acc[4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PP_BAR();
+  }
+  wait_vmcnt<0>();                        // the zero-page stages of the tiles past the end: the epilogue reuses the staging memory
+  if (grp == 0) PP_BAR();                 // re-align the two groups: every LDS read of the main loop is complete behind this
+  PP_BAR();
 #undef PP_BAR
 #undef PP_LOAD_END
 }

@@ -51,9 +51,9 @@ struct EpiP {
 
 // RowOff: int64 element offset of tile row r's first column (n0) in `out`, or -1 when the row is out of range.
 // vrows: number of valid rows of this tile (rows >= vrows are padding: excluded from the statistics, never stored).
-template <class C, int OT, class RowOff>
-__device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C::TM][C::TN], int mt, int n0, int N, int vrows,
-                                         const EpiP& e, RowOff rowoff) {
+template <class C, int OT, bool FAST, int STATS, class RowOff>      // STATS: 0 never, 1 always, 2 decided at run time (e.stats)
+__device__ __forceinline__ void epilogue_impl(char* smem, typename C::acc_t (&acc)[C::TM][C::TN], int mt, int n0, int N, int vrows,
+                                              const EpiP& e, RowOff rowoff) {
   typedef Out<OT> O;
   typedef typename O::T OTy;
   constexpr int PITCH = C::pitch_c(O::SZ);
@@ -65,7 +65,13 @@ __device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C:
   float* sS = reinterpret_cast<float*>(smem + C::BM * PITCH + C::BM * 8);
   // statistics straight from the accumulator registers: a lane owns one column of every block, so the column sums are a sum over
   // its registers and row blocks, then over the lanes that share the column (xor 16 / 32), then over the wave rows through LDS
-  const bool want_stats = e.stats != nullptr;
+  const bool want_stats = STATS == 2 ? e.stats != nullptr : STATS == 1;
+  const int row0 = wm * (C::BM / C::WM) + C::acc_row_lane(lane);
+  char* wbase = sC + row0 * PITCH + (wn * (C::BN / C::WN) + lc) * O::SZ;
+  // FAST (no activation or ReLU): branch-free, v = max(alpha * acc + bias, lo) with lo = 0 or -inf. Inlined per element (128
+  // accumulators per lane on the 256 x 256 tile) the six-way activation switch makes the epilogue ~30k instructions / ~2000
+  // branches, far beyond the instruction cache (+10 us per output tile, measured): only the transcendental activations pay that.
+  const float lo = e.act == ACT_RELU ? 0.f : -__builtin_inff();
 #pragma unroll
   for (int j = 0; j < C::TN; ++j) {
     const int col = wn * (C::BN / C::WN) + j * C::MF + lc;
@@ -77,9 +83,11 @@ __device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C:
     for (int i = 0; i < C::TM; ++i)
 #pragma unroll
       for (int q = 0; q < C::ACC; ++q) {
-        const int row = wm * (C::BM / C::WM) + i * C::MF + C::acc_row(q, lane);
-        const OTy o = O::cv(apply_act(acc[i][j][q] * e.alpha + bv, e.act));
-        *reinterpret_cast<OTy*>(sC + row * PITCH + col * O::SZ) = o;
+        const int row = row0 + i * C::MF + C::acc_row_const(q);
+        float f = acc[i][j][q] * e.alpha + bv;
+        if constexpr (FAST) f = fmaxf(f, lo); else f = apply_act(f, e.act);
+        const OTy o = O::cv(f);
+        *reinterpret_cast<OTy*>(wbase + (i * C::MF + C::acc_row_const(q)) * PITCH + j * C::MF * O::SZ) = o;
         if (want_stats) {
           const float v = row < vrows ? O::fl(o) - sh : 0.f;
           s1 += v; s2 += v * v;
@@ -157,6 +165,18 @@ __device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C:
         out[o + j] = O::cv(f);
       }
     }
+  }
+}
+
+// two complete bodies (nothing is joined behind the branch: both end the kernel), chosen by a workgroup-uniform test
+template <class C, int OT, class RowOff>
+__device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C::TM][C::TN], int mt, int n0, int N, int vrows,
+                                         const EpiP& e, RowOff rowoff) {
+  if (e.act == ACT_NONE || e.act == ACT_RELU) {
+    if (e.stats == nullptr) epilogue_impl<C, OT, true, 0>(smem, acc, mt, n0, N, vrows, e, rowoff);
+    else epilogue_impl<C, OT, true, 1>(smem, acc, mt, n0, N, vrows, e, rowoff);
+  } else {
+    epilogue_impl<C, OT, false, 2>(smem, acc, mt, n0, N, vrows, e, rowoff);
   }
 }
 

@@ -31,7 +31,24 @@ template <class C> struct PlainSrc {
   }
 };
 
-template <class C, int OT, bool PP = false>
+// operand rows of the deep ping-pong loop (mainloop_pingpong_deep): index h*2+s = half h, piece s of this wave
+template <class C> struct PlainSrcPP {
+  const char* ap[4];
+  const char* bp[4];
+  int kch[2];      // first k of this lane's 16-byte chunk inside a k-tile, per piece parity s
+  int K;
+  __device__ __forceinline__ const void* a_half(int h, int s, int t) const {
+    const int k = t * C::BK + kch[s];
+    return k < K ? (const void*)(ap[h * 2 + s] + (int64_t)k * C::ESZ) : (const void*)g_zero_page;
+  }
+  __device__ __forceinline__ const void* b_half(int h, int s, int t) const {
+    const int k = t * C::BK + kch[s];
+    return k < K ? (const void*)(bp[h * 2 + s] + (int64_t)k * C::ESZ) : (const void*)g_zero_page;
+  }
+};
+
+// PP: 0 = barrier-synchronous loop, 1 = ping-pong wave groups, 2 = ping-pong with half-tile staging and counted waits
+template <class C, int OT, int PP = 0>
 __global__ void __launch_bounds__(C::NT) gemm_nt_kernel(const GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -41,6 +58,27 @@ __global__ void __launch_bounds__(C::NT) gemm_nt_kernel(const GemmP p) {
   const char* A = (const char*)p.A + (int64_t)blockIdx.y * p.sA * C::ESZ;
   const char* B = (const char*)p.B + (int64_t)blockIdx.y * p.sB * C::ESZ;
 
+  typename C::acc_t acc[C::TM][C::TN];
+  const int KT = (p.K + C::BK - 1) / C::BK;
+  if constexpr (PP == 2) {
+    PlainSrcPP<C> src;
+    src.K = p.K;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) src.kch[s] = ((lane & 7) ^ (s * 4 + (lane >> 4))) * C::CH;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        int m = m0 + pp_piece_a<C>(wid, h, s) * 8 + (lane >> 3);
+        if (m > p.M - 1) m = p.M - 1;
+        src.ap[h * 2 + s] = A + (int64_t)m * p.lda * C::ESZ;
+        int n = n0 + pp_piece_b<C>(wid, h, s) * 8 + (lane >> 3);
+        if (n > p.N - 1) n = p.N - 1;
+        src.bp[h * 2 + s] = B + (int64_t)n * p.ldb * C::ESZ;
+      }
+    mainloop_pingpong_deep<C>(smem, src, KT, acc);
+  } else {
   PlainSrc<C> src;
   src.K = p.K;
   src.kchunk = stage_chunk(stage_row<C>(0)) * C::CH;
@@ -56,10 +94,9 @@ __global__ void __launch_bounds__(C::NT) gemm_nt_kernel(const GemmP p) {
     if (n > p.N - 1) n = p.N - 1;
     src.bp[i] = B + (int64_t)n * p.ldb * C::ESZ;
   }
-  typename C::acc_t acc[C::TM][C::TN];
-  const int KT = (p.K + C::BK - 1) / C::BK;
-  if constexpr (PP) mainloop_pingpong<C>(smem, src, KT, acc);
+  if constexpr (PP == 1) mainloop_pingpong<C>(smem, src, KT, acc);
   else mainloop<C>(smem, src, KT, acc);
+  }
 
   EpiP e = p.epi;
   const int64_t boff = (int64_t)blockIdx.y * p.sC;
@@ -73,7 +110,7 @@ __global__ void __launch_bounds__(C::NT) gemm_nt_kernel(const GemmP p) {
   });
 }
 
-template <class C, int OT, bool PP = false>
+template <class C, int OT, int PP = 0>
 static int launch_gemm(GemmP& p, int batch, hipStream_t st) {
   p.mtiles = (p.M + C::BM - 1) / C::BM;
   p.ntiles = (p.N + C::BN - 1) / C::BN;

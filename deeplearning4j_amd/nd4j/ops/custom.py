@@ -272,6 +272,9 @@ class DynamicCustomOp:
         return OpExecutioner.getInstance().exec(self)
 
 
+USER_DEFINED_OPS = set()        # names registered at run time by UserDefinedCustomOp (not part of the built-in op set)
+
+
 class UserDefinedCustomOp(DynamicCustomOp):
     """UDF ops (ADR 0023): subclass, implement ``doExec(ins, i, t, b, d)``; registered at first use."""
 
@@ -281,6 +284,7 @@ class UserDefinedCustomOp(DynamicCustomOp):
     def exec(self):
         if self.opName not in _IMPL:
             L.rt().ops_register(self.opName.encode(), -1, -1, 0, -1, -1)
+            USER_DEFINED_OPS.add(self.opName)
             _IMPL[self.opName] = lambda ins, i, t, b, d, _s=self: _s.doExec(ins, i, t, b, d)
         return super().exec()
 

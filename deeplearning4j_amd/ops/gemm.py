@@ -16,7 +16,7 @@ import torch
 
 from ..native import lib as L
 
-TILES = ((128, 128), (128, 64), (64, 64), (64, 128), (256, 256), (128, 128), (128, 64), (64, 64), (64, 128), (64, 64))   # 5..9: deeper pipelines of 0..3 / 2
+TILES = ((128, 128), (128, 64), (64, 64), (64, 128), (256, 256), (128, 128), (128, 64), (64, 64), (64, 128), (64, 64), (256, 256))   # 5..9: deeper pipelines of 0..3 / 2; 10: ping-pong with half-tile staging
 _DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 ACTS = {None: 0, "identity": 0, "relu": 1, "gelu": 2, "gelu_tanh": 2, "gelu_erf": 3, "tanh": 4, "sigmoid": 5}
 
@@ -36,6 +36,9 @@ def supported(x, w):
             and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
+PP_MIN_BLOCKS = 176
+
+
 def pick_tile(M, N, K, dtype):
     """Measured on MI355X (tools/gemm_tile_sweep.py -> profiles/r3_gemm_tile_sweep.md): the 64-row tiles win everywhere below the
     ping-pong regime because three of their workgroups fit a CU's LDS (48 KB each with two stages) and hide each other's barriers; the
@@ -43,8 +46,8 @@ def pick_tile(M, N, K, dtype):
     def blocks(t):
         bm, bn = TILES[t]
         return ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-    if dtype == torch.bfloat16 and blocks(4) >= 448 and K >= 2048:
-        return 4                                  # 256x256 ping-pong: only when it fills the chip ~2x with a deep K loop
+    if dtype == torch.bfloat16 and blocks(10) >= PP_MIN_BLOCKS and K >= 256:
+        return 10                                 # 256x256 ping-pong with half-tile staging once it covers ~2/3 of the CUs
     if N >= 128 and blocks(3) >= 512:
         return 3
     return 2
@@ -83,7 +86,7 @@ def gemm_nt(x, w, bias=None, act=None, residual=None, alpha=1.0, out_dtype=None,
     if residual is not None:
         assert residual.shape == y.shape and residual.dtype == out_dtype and residual.is_contiguous()
     t = pick_tile(M, N, K, x.dtype) if tile is None else tile
-    if t == 4 and (x.dtype != torch.bfloat16 or out_dtype != torch.bfloat16):
+    if t in (4, 10) and (x.dtype != torch.bfloat16 or out_dtype != torch.bfloat16):
         t = 0
     _launch(x, w, y, bias, residual, alpha, act, M, N, K, x.stride(0), w.stride(0), N, 0, 0, 0, 1, t, out_dtype == torch.float32
             and x.dtype != torch.float32)
@@ -101,7 +104,7 @@ def bgemm_nt(a, b, alpha=1.0, out_dtype=None):
     out_dtype = out_dtype or a.dtype
     y = torch.empty(B, M, N, device=a.device, dtype=out_dtype)
     t = pick_tile(M, N, K, a.dtype)
-    if t == 4:
+    if t in (4, 10):
         t = 0
     _launch(a, b, y, None, None, alpha, None, M, N, K, a.stride(1), b.stride(1), N, a.stride(0), b.stride(0), M * N, B, t,
             out_dtype == torch.float32 and a.dtype != torch.float32)
@@ -165,7 +168,10 @@ def gemm(a, b, bias=None, act=None, residual=None, alpha=1.0, out=None, out_dtyp
     assert out_dtype in (a.dtype, torch.float32)
     f32out = out_dtype == torch.float32
     t = (pick_tile(M, N, K, a.dtype) if tile is None else tile)
-    t = 0 if t == 4 else t
+    if (t in (4, 10) and not ta and not tb and not batched and not accum and out is None and splits in (None, 1)
+            and out_dtype == torch.bfloat16 and a.dtype == torch.bfloat16):
+        return gemm_nt(a, b, bias=bias, act=act, residual=residual, alpha=alpha, tile=t)      # plain NT product: the ping-pong kernel
+    t = 0 if t in (4, 10) else t
     if splits is None:
         splits = pick_splits(M, N, K, t, a.dtype) if (f32out and act in (None, "identity") and not batched) else 1
     if splits > 1:
