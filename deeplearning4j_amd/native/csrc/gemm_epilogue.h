@@ -51,7 +51,7 @@ struct EpiP {
 
 // RowOff: int64 element offset of tile row r's first column (n0) in `out`, or -1 when the row is out of range.
 // vrows: number of valid rows of this tile (rows >= vrows are padding: excluded from the statistics, never stored).
-template <class C, int OT, bool FAST, int STATS, class RowOff>      // STATS: 0 never, 1 always, 2 decided at run time (e.stats)
+template <class C, int OT, int ACTK, int STATS, class RowOff>   // ACTK: ACT_NONE = linear / ReLU, else that activation; STATS: 0 never, 1 always, 2 run time (e.stats)
 __device__ __forceinline__ void epilogue_impl(char* smem, typename C::acc_t (&acc)[C::TM][C::TN], int mt, int n0, int N, int vrows,
                                               const EpiP& e, RowOff rowoff) {
   typedef Out<OT> O;
@@ -68,7 +68,7 @@ __device__ __forceinline__ void epilogue_impl(char* smem, typename C::acc_t (&ac
   const bool want_stats = STATS == 2 ? e.stats != nullptr : STATS == 1;
   const int row0 = wm * (C::BM / C::WM) + C::acc_row_lane(lane);
   char* wbase = sC + row0 * PITCH + (wn * (C::BN / C::WN) + lc) * O::SZ;
-  // FAST (no activation or ReLU): branch-free, v = max(alpha * acc + bias, lo) with lo = 0 or -inf. Inlined per element (128
+  // ACTK == ACT_NONE (no activation or ReLU): branch-free, v = max(alpha * acc + bias, lo) with lo = 0 or -inf. Inlined per element (128
   // accumulators per lane on the 256 x 256 tile) the six-way activation switch makes the epilogue ~30k instructions / ~2000
   // branches, far beyond the instruction cache (+10 us per output tile, measured): only the transcendental activations pay that.
   const float lo = e.act == ACT_RELU ? 0.f : -__builtin_inff();
@@ -85,7 +85,7 @@ __device__ __forceinline__ void epilogue_impl(char* smem, typename C::acc_t (&ac
       for (int q = 0; q < C::ACC; ++q) {
         const int row = row0 + i * C::MF + C::acc_row_const(q);
         float f = acc[i][j][q] * e.alpha + bv;
-        if constexpr (FAST) f = fmaxf(f, lo); else f = apply_act(f, e.act);
+        if constexpr (ACTK == ACT_NONE) f = fmaxf(f, lo); else f = apply_act(f, ACTK);
         const OTy o = O::cv(f);
         *reinterpret_cast<OTy*>(wbase + (i * C::MF + C::acc_row_const(q)) * PITCH + j * C::MF * O::SZ) = o;
         if (want_stats) {
@@ -168,16 +168,19 @@ __device__ __forceinline__ void epilogue_impl(char* smem, typename C::acc_t (&ac
   }
 }
 
-// two complete bodies (nothing is joined behind the branch: both end the kernel), chosen by a workgroup-uniform test
+// one complete straight-line body per activation kind (nothing is joined behind the branches: each ends the kernel), chosen by
+// workgroup-uniform tests
 template <class C, int OT, class RowOff>
 __device__ __forceinline__ void epilogue(char* smem, typename C::acc_t (&acc)[C::TM][C::TN], int mt, int n0, int N, int vrows,
                                          const EpiP& e, RowOff rowoff) {
   if (e.act == ACT_NONE || e.act == ACT_RELU) {
-    if (e.stats == nullptr) epilogue_impl<C, OT, true, 0>(smem, acc, mt, n0, N, vrows, e, rowoff);
-    else epilogue_impl<C, OT, true, 1>(smem, acc, mt, n0, N, vrows, e, rowoff);
-  } else {
-    epilogue_impl<C, OT, false, 2>(smem, acc, mt, n0, N, vrows, e, rowoff);
+    if (e.stats == nullptr) epilogue_impl<C, OT, ACT_NONE, 0>(smem, acc, mt, n0, N, vrows, e, rowoff);
+    else epilogue_impl<C, OT, ACT_NONE, 1>(smem, acc, mt, n0, N, vrows, e, rowoff);
   }
+  else if (e.act == ACT_GELU_TANH) epilogue_impl<C, OT, ACT_GELU_TANH, 2>(smem, acc, mt, n0, N, vrows, e, rowoff);
+  else if (e.act == ACT_GELU_ERF) epilogue_impl<C, OT, ACT_GELU_ERF, 2>(smem, acc, mt, n0, N, vrows, e, rowoff);
+  else if (e.act == ACT_TANH) epilogue_impl<C, OT, ACT_TANH, 2>(smem, acc, mt, n0, N, vrows, e, rowoff);
+  else epilogue_impl<C, OT, ACT_SIGMOID, 2>(smem, acc, mt, n0, N, vrows, e, rowoff);
 }
 
 }  // namespace gemmcore

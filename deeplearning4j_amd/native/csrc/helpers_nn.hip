@@ -183,7 +183,25 @@ __global__ void __launch_bounds__(256) layer_norm_fwd_wave_kernel(const T* __res
   }
 }
 
-// block = 8 waves, rows [blockIdx.x * rpb, + rpb) dealt to the waves round-robin; partial (optional) [gridDim.x][2][cols]
+// block = 8 waves, rows [blockIdx.x * rpb, + rpb) dealt to the waves round-robin; partial (optional) [gridDim.x][2][cols].
+// The row loop is software-pipelined (the 16-byte loads of the wave's next row are in flight while the two wave reductions of the
+// current row run: with two rows per wave the loop was a chain of exposed load latencies, 24 us at [4096, 768] = 0.75 TB/s), and the
+// column partials leave the registers through one LDS read-modify-write turn per wave (16-byte accesses, a barrier between turns)
+// instead of 32 LDS atomics per lane.
+template <typename T> struct Raw16;
+template <> struct Raw16<bf16_t> {
+  static __device__ __forceinline__ void cv(const uint4& v, float (&f)[8]) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+  }
+};
+template <> struct Raw16<float> {
+  static __device__ __forceinline__ void cv(const uint4& v, float (&f)[4]) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+  }
+};
+
 template <typename T, int MAXC>
 __global__ void __launch_bounds__(512) layer_norm_bwd_wave_kernel(const T* __restrict__ x, const T* __restrict__ g, const float* __restrict__ gamma,
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -191,13 +209,9 @@ __global__ void __launch_bounds__(512) layer_norm_bwd_wave_kernel(const T* __res
                                                                   int64_t rpb) {
   constexpr int V = Vec16<T>::V;
   constexpr int MAXCOLS = MAXC * 64 * V;
-  __shared__ float acc[2 * MAXCOLS];
+  __shared__ __attribute__((aligned(16))) float acc[2 * MAXCOLS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = cols / V;
-  if (partial) {
-    for (int c = threadIdx.x; c < 2 * MAXCOLS; c += 512) acc[c] = 0.f;
-    __syncthreads();
-  }
   float gm[MAXC][V], dg[MAXC][V], db[MAXC][V];
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
@@ -208,23 +222,33 @@ __global__ void __launch_bounds__(512) layer_norm_bwd_wave_kernel(const T* __res
   }
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   const int64_t r1 = r0 + rpb < rows ? r0 + rpb : rows;
-  for (int64_t r = r0 + wave; r < r1; r += 8) {
-    float xv[MAXC][V], gv[MAXC][V];
+  uint4 xr[MAXC], gr[MAXC], xn[MAXC], gn[MAXC];
+  float mu_n = 0.f, rs_n = 0.f;
+  auto issue = [&](int64_t r) {
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
+      xn[i] = make_uint4(0, 0, 0, 0); gn[i] = xn[i];
       if (c < nch) {
-        Vec16<T>::ld(x + r * cols + c * V, xv[i]);
-        Vec16<T>::ld(g + r * cols + c * V, gv[i]);
-      } else {
-#pragma unroll
-        for (int k = 0; k < V; ++k) { xv[i][k] = 0.f; gv[i][k] = 0.f; }
+        xn[i] = *reinterpret_cast<const uint4*>(x + r * cols + c * V);
+        gn[i] = *reinterpret_cast<const uint4*>(g + r * cols + c * V);
       }
     }
-    const float mu = mean[r], rs = rstd[r];
+    mu_n = mean[r]; rs_n = rstd[r];
+  };
+  int64_t r = r0 + wave;
+  if (r < r1) issue(r);
+  for (; r < r1; r += 8) {
+    const float mu = mu_n, rs = rs_n;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) { xr[i] = xn[i]; gr[i] = gn[i]; }
+    if (r + 8 < r1) issue(r + 8);
+    float xv[MAXC][V], gv[MAXC][V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
+    for (int i = 0; i < MAXC; ++i) {
+      Raw16<T>::cv(xr[i], xv[i]);
+      Raw16<T>::cv(gr[i], gv[i]);
       if (lane + 64 * i < nch) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -235,6 +259,7 @@ __global__ void __launch_bounds__(512) layer_norm_bwd_wave_kernel(const T* __res
           db[i][k] += gv[i][k];
         }
       }
+    }
     s1 = wave_sum(s1) / cols;
     s2 = wave_sum(s2) / cols;
 #pragma unroll
@@ -249,18 +274,27 @@ __global__ void __launch_bounds__(512) layer_norm_bwd_wave_kernel(const T* __res
     }
   }
   if (!partial) return;
+  // wave w adds its registers into the LDS rows in turn w (wave 0 stores): plain 16-byte LDS accesses, 8 short turns
+  for (int w = 0; w < 8; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nch) {
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
 #pragma unroll
-      for (int k = 0; k < V; ++k) {
-        atomicAdd(&acc[c * V + k], dg[i][k]);
-        atomicAdd(&acc[MAXCOLS + c * V + k], db[i][k]);
+          for (int k = 0; k < V; k += 4) {
+            f32x4* pg = reinterpret_cast<f32x4*>(&acc[c * V + k]);
+            f32x4* pb = reinterpret_cast<f32x4*>(&acc[MAXCOLS + c * V + k]);
+            f32x4 vg = {dg[i][k], dg[i][k + 1], dg[i][k + 2], dg[i][k + 3]};
+            f32x4 vb = {db[i][k], db[i][k + 1], db[i][k + 2], db[i][k + 3]};
+            if (w != 0) { vg += *pg; vb += *pb; }
+            *pg = vg; *pb = vb;
+          }
+        }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* out = partial + (int64_t)blockIdx.x * 2 * cols;
   for (int c = threadIdx.x; c < cols; c += 512) {
     out[c] = acc[c];
