@@ -241,6 +241,43 @@ __global__ void __launch_bounds__(256) bn_pool_prep_kernel(const float* __restri
 }
 }  // namespace
 
+// passes 1 + coefficients only (dgamma / dbeta and ws[3C, 6C) = gs / k1 / k0): pass 2 is then either dl4j_bn_pool_bwd_dx or runs inside
+// the consumer of dx (dl4j_conv_c3_wgrad_bnpool recomputes dx in its loader and the 411 MB tensor is never written)
+DL4J_API int dl4j_bn_pool_bwd_reduce(const void* dy, const void* y, const uint8_t* idx, const float* gamma, const float* beta,
+                                     const float* mean, const float* invstd, float* ws, float* dbeta, float* dgamma, const int* geom,
+                                     hipStream_t st) {
+  const BnPoolP p = mk(geom);
+  if (!geom_ok(p) || !dy || !y || !idx || !mean || !invstd || !ws) return -2;
+  if (!a16(dy) || !a16(y) || !a16(ws) || ((uintptr_t)idx & 7)) return -2;
+  const int C = p.C;
+  hipLaunchKernelGGL(bn_pool_prep_kernel, dim3(1), dim3(256), 0, st, gamma, beta, ws, C);
+  const int64_t rows = (int64_t)p.N * p.OH * p.OW;
+  int rpb = (int)((rows + 1023) / 1024);
+  if (rpb < 64) rpb = 64;
+  const int nblk = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, idx, ws + 6 * C, ws + 2 * C, ws, rows, C,
+                     rpb);
+  const float inv_m = 1.f / (float)((int64_t)p.N * p.H * p.W);
+  hipLaunchKernelGGL(bn_pool_bwd_coeffs_kernel, dim3(1), dim3(256), 0, st, ws, gamma, mean, invstd, dbeta, dgamma, ws + 3 * C, C, inv_m);
+  DL4J_RET_LAST();
+}
+
+// pass 2 on its own (ws as left by dl4j_bn_pool_bwd_reduce)
+DL4J_API int dl4j_bn_pool_bwd_dx(const void* x, const void* dy, const uint8_t* idx, const float* ws, void* dx, const int* geom, hipStream_t st) {
+  const BnPoolP p = mk(geom);
+  if (!geom_ok(p) || !x || !dy || !idx || !ws || !dx) return -2;
+  if (!a16(x) || !a16(dy) || !a16(dx) || !a16(ws) || ((uintptr_t)idx & 7)) return -2;
+  const int C = p.C;
+  const int64_t total = (int64_t)p.N * p.H * p.W * (C / 8);
+  if (p.kH == 3 && p.kW == 3 && p.sH == 2 && p.sW == 2)
+    hipLaunchKernelGGL(bn_pool_bwd_dx_kernel<3 * 16 + 2>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, idx,
+                       ws + 3 * C, (bf16_t*)dx, p);
+  else
+    hipLaunchKernelGGL(bn_pool_bwd_dx_kernel<0>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, idx, ws + 3 * C,
+                       (bf16_t*)dx, p);
+  DL4J_RET_LAST();
+}
+
 DL4J_API int dl4j_bn_pool_bwd(const void* x, const void* dy, const void* y, const uint8_t* idx, const float* gamma, const float* beta,
                               const float* mean, const float* invstd, float* ws, float* dbeta, float* dgamma, void* dx, const int* geom,
                               hipStream_t st) {

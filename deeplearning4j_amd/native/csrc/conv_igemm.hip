@@ -25,6 +25,26 @@
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
+// Division by a launch-invariant divisor (Granlund-Montgomery): q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(n, mul); exact for every
+// 32-bit n. The pixel -> (image, row, column) decompositions of the loaders and epilogues are 2 divisions per tile row: as runtime
+// divisions they were ~25 VALU instructions each, a large part of the instruction count of the short-reduction layers.
+struct FastDiv {
+  uint32_t mul, s1, s2;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mul = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l < 1 ? 0 : l - 1;
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+  const uint32_t un = (uint32_t)n, t = __umulhi(un, f.mul);
+  return (int)((t + ((un - t) >> f.s1)) >> f.s2);
+}
+
 struct IGemmP {
   const bf16_t* x;
   const bf16_t* w;
@@ -56,6 +76,7 @@ struct IGemmP {
   // statistics pivot: the partial sums are of (y - pivot) with pivot[c] = piv_mean[c] - piv_bias[c] (the consuming BatchNorm's
   // running mean, minus the folded conv bias): E[(y-p)^2] - E[y-p]^2 does not cancel when |mean| >> std. Null = no shift.
   const float* piv_mean; const float* piv_bias;
+  FastDiv d_ohw, d_ow;      // divisions by OH*OW and OW (set in launch_fwd)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -89,8 +110,8 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + lrow + 32 * i;
     if (m < p.M) {
-      const int n = m / OHW, rem = m - n * OHW;
-      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      const int n = fdiv(m, p.d_ohw), rem = m - n * OHW;
+      const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
       a_ih0[i] = oh * p.sh - p.ph;
       a_iw0[i] = ow * p.sw - p.pw;
       a_base[i] = (((aoff_t)n * p.H + a_ih0[i]) * p.W + a_iw0[i]) * p.C;
@@ -197,8 +218,8 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
       e_y[i] = s16x8{0, 0, 0, 0, 0, 0, 0, 0}; e_prev[i] = e_y[i];
       e_mb[i] = 0xFFu; e_ab[i] = 0xFFu;
       if (m < p.M) {
-        const int n = m / OHW, rem = m - n * OHW;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int n = fdiv(m, p.d_ohw), rem = m - n * OHW;
+        const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
         const int64_t o = (((int64_t)n * p.OHs + oh * p.oys) * p.OWs + ow * p.oxs) * p.K + n0 + ch * 8;
         e_o[i] = o;
         if (p.acc_src != nullptr) {
@@ -219,26 +240,38 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   char* sC = smem;
   float* sS = reinterpret_cast<float*>(smem + ((BM * PITCH_C + 255) & ~255));
   float csum[TN], csq[TN];
+  // two copies of the accumulator pass, chosen by a workgroup-uniform branch: launches without a statistics consumer (data gradients,
+  // convolutions not followed by a BatchNorm) skip the 5 VALU instructions per element of the column sums
+  auto acc_pass = [&](auto with_stats) {
+    constexpr bool WS = decltype(with_stats)::value;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = wn * (BN / 2) + j * 32 + l31;
-    const float bv = p.bias ? p.bias[n0 + col] : 0.f;
-    const float pv = pvq[j];
-    float s = 0.f, q2 = 0.f;
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * (BN / 2) + j * 32 + l31;
+      const float bv = p.bias ? p.bias[n0 + col] : 0.f;
+      const float pv = pvq[j];
+      float s = 0.f, q2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const bf16_t b = f2bf(acc[i][j][e] + bv);
-        *reinterpret_cast<bf16_t*>(sC + row * PITCH_C + col * 2) = b;
-        const float v = (m0 + row < p.M) ? bf2f(b) - pv : 0.f;
-        s += v; q2 += v * v;
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const bf16_t b = f2bf(acc[i][j][e] + bv);
+          *reinterpret_cast<bf16_t*>(sC + row * PITCH_C + col * 2) = b;
+          if constexpr (WS) {
+            const float v = (m0 + row < p.M) ? bf2f(b) - pv : 0.f;
+            s += v; q2 += v * v;
+          }
+        }
+      }
+      if constexpr (WS) {
+        csum[j] = s + __shfl_xor(s, 32, 64);
+        csq[j] = q2 + __shfl_xor(q2, 32, 64);
+      } else {
+        csum[j] = 0.f; csq[j] = 0.f;
       }
     }
-    csum[j] = s + __shfl_xor(s, 32, 64);
-    csq[j] = q2 + __shfl_xor(q2, 32, 64);
-  }
+  };
+  if (EPI == 0 && p.stats != nullptr) acc_pass(std::true_type{}); else acc_pass(std::false_type{});
   if (p.stats != nullptr && lane < 32) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -342,8 +375,8 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
     const int row = idx / CPR, ch = idx - row * CPR;
     const int m = m0 + row;
     if (m < p.M) {
-      const int n = m / OHW, rem = m - n * OHW;
-      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      const int n = fdiv(m, p.d_ohw), rem = m - n * OHW;
+      const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
       const int64_t o = (((int64_t)n * p.OHs + oh * p.oys) * p.OWs + ow * p.oxs) * p.K + n0 + ch * 8;
       s16x8 v = *reinterpret_cast<const s16x8*>(sC + row * PITCH_C + ch * 16);
       if (p.accum) {
@@ -374,6 +407,8 @@ template <int BM, int BN>
 static int launch_fwd(IGemmP& p, hipStream_t st) {
   p.mtiles = (p.M + BM - 1) / BM;
   p.ntiles = p.K / BN;
+  p.d_ohw = make_fastdiv((uint32_t)(p.OH * p.OW));
+  p.d_ow = make_fastdiv((uint32_t)p.OW);
   const int KT = p.R * p.S * (p.C >> 6);
   p.nbuf = KT == 1 ? 1 : 2;
   constexpr int PITCH_C = BN * 2 + 16;
@@ -515,6 +550,7 @@ struct WGradP {
   int P;              // N*OH*OW
   int ktiles, ctiles, splits, pps;   // pps: pixels per split (multiple of 64)
   int use_atomic;
+  FastDiv d_ohw, d_ow;
 };
 
 template <int PITCH>
@@ -601,8 +637,8 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
       const int pp = pb + prB + i * RPB;
       s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (pp < pend && c0 + chB * 8 < p.C) {
-        const int n = pp / OHW, rem = pp - n * OHW;
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int n = fdiv(pp, p.d_ohw), rem = pp - n * OHW;
+        const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
         const int ih = oh * p.sh - p.ph + r * p.dh, iw = ow * p.sw - p.pw + s * p.dw_;
         if (((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W))
           v = *reinterpret_cast<const s16x8*>(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.C + c0 + chB * 8);
@@ -704,6 +740,8 @@ template <int BK_, int BC_, int F16>
 static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t st) {
   p.ktiles = (p.K + BK_ - 1) / BK_;
   p.ctiles = (p.C + BC_ - 1) / BC_;
+  p.d_ohw = make_fastdiv((uint32_t)(p.OH * p.OW));
+  p.d_ow = make_fastdiv((uint32_t)p.OW);
   const int tiles = p.ktiles * p.ctiles * p.R * p.S;
   int splits;
   if (target_blocks > 0) {

@@ -33,6 +33,14 @@ struct StemP {
   const bf16_t* dy;     // [N][OH][OW][64] (wgrad)
   float* dwp;           // [64][KH][32] fp32 scratch (wgrad, atomics)
   int N, H, W, OH, OW, pad, rpb, nrb;
+  // FUSED weight gradient: dy is never materialised - it is the input gradient of the BatchNorm -> ReLU -> MaxPool(3x3 / 2) node
+  // behind this convolution (bn_pool_fused.hip pass 2), recomputed per output row from the pooled gradient:
+  //   dy[n,h,w,c] = gs[c] * dz + y[n,h,w,c] * k1[c] + k0[c],  dz = sum of pooled_dy over the covering windows whose argmax is (h, w)
+  const bf16_t* bp_y;        // [N][OH][OW][64] the convolution's own (raw) output = BatchNorm input
+  const bf16_t* bp_dy;       // [N][PH][PW][64] gradient of the pooled output
+  const uint8_t* bp_idx;     // [N][PH][PW][64] window-local argmax tap (kh * 3 + kw), 255 = none
+  const float* bp_coef;      // [3][64]: gs, k1, k0
+  int PH, PW, ppad;
 };
 
 __device__ __forceinline__ int swz128(int pixel) { return ((pixel >> 1) & 1) << 2; }
@@ -229,7 +237,7 @@ __global__ void __launch_bounds__(256) conv_c3_fwd_kernel(const StemP p) {
   }
 }
 
-template <int KH, int KW, int STR>
+template <int KH, int KW, int STR, bool FUSED = false>
 __global__ void __launch_bounds__(256) conv_c3_wgrad_kernel(const StemP p) {
   constexpr int PITCH = Ring<STR>::PITCH;
   __shared__ __attribute__((aligned(16))) char ring[8 * PITCH];
@@ -257,19 +265,91 @@ __global__ void __launch_bounds__(256) conv_c3_wgrad_kernel(const StemP p) {
 
   RowRegs<STR> nxt[STR];
   s16x8 dyr[4];
+  // FUSED: raw operands of the recomputation, requested a row ahead like dy itself (the arithmetic runs after the MFMA loop)
+  constexpr int FI = FUSED ? 4 : 1;
+  s16x8 fy[FI], fd[FI][4];
+  uint2 fi[FI][4];
+  f32x4 cg0, cg1, ck10, ck11, ck00, ck01;
+  if constexpr (FUSED) {
+    const float* cf = p.bp_coef + (tid & 7) * 8;
+    cg0 = *reinterpret_cast<const f32x4*>(cf); cg1 = *reinterpret_cast<const f32x4*>(cf + 4);
+    ck10 = *reinterpret_cast<const f32x4*>(cf + 64); ck11 = *reinterpret_cast<const f32x4*>(cf + 68);
+    ck00 = *reinterpret_cast<const f32x4*>(cf + 128); ck01 = *reinterpret_cast<const f32x4*>(cf + 132);
+  }
+  // window (a, b) of position (h, w): pooled row (h + ppad) / 2 - a, column (w + ppad) / 2 - b; covers the position iff the tap
+  // kh = h + ppad - 2 * prow is in [0, 3) and the row exists (3x3 / 2: at most 2 x 2 windows)
   auto load_dy = [&](int oh) {
+    if constexpr (FUSED) {
+      const int hp = oh + p.ppad;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pxl = (tid >> 3) + i * 32;
-      s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (pxl < p.OW) v = *reinterpret_cast<const s16x8*>(p.dy + (((int64_t)n * p.OH + oh) * p.OW + pxl) * 64 + (tid & 7) * 8);
-      dyr[i] = v;
+      for (int i = 0; i < 4; ++i) {
+        const int pxl = (tid >> 3) + i * 32;
+        const int wp = pxl + p.ppad;
+        fy[i] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (pxl < p.OW) fy[i] = *reinterpret_cast<const s16x8*>(p.bp_y + (((int64_t)n * p.OH + oh) * p.OW + pxl) * 64 + (tid & 7) * 8);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            int pr = (hp >> 1) - a, pc = (wp >> 1) - b;
+            pr = pr < 0 ? 0 : (pr > p.PH - 1 ? p.PH - 1 : pr);       // clamped: the tap test in finish_dy rejects what does not cover
+            pc = pc < 0 ? 0 : (pc > p.PW - 1 ? p.PW - 1 : pc);
+            const int64_t o = (((int64_t)n * p.PH + pr) * p.PW + pc) * 64 + (tid & 7) * 8;
+            fd[i][a * 2 + b] = *reinterpret_cast<const s16x8*>(p.bp_dy + o);
+            fi[i][a * 2 + b] = *reinterpret_cast<const uint2*>(p.bp_idx + o);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pxl = (tid >> 3) + i * 32;
+        s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (pxl < p.OW) v = *reinterpret_cast<const s16x8*>(p.dy + (((int64_t)n * p.OH + oh) * p.OW + pxl) * 64 + (tid & 7) * 8);
+        dyr[i] = v;
+      }
+    }
+  };
+  auto finish_dy = [&](int oh) {
+    if constexpr (FUSED) {
+      const int hp = oh + p.ppad;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pxl = (tid >> 3) + i * 32;
+        const int wp = pxl + p.ppad;
+        float dz[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dz[j] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int pr = (hp >> 1) - a, pc = (wp >> 1) - b;
+            const int kh = hp - 2 * pr, kw = wp - 2 * pc;
+            const bool cover = pr >= 0 && pr < p.PH && pc >= 0 && pc < p.PW && kh < 3 && kw < 3;
+            const unsigned code = cover ? (unsigned)(kh * 3 + kw) : 0xFEu;      // 0xFE never occurs in idx (taps 0..8, 255 = none)
+            const s16x8 d = fd[i][a * 2 + b];
+            const uint2 am = fi[i][a * 2 + b];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              dz[j] += ((am.x >> (8 * j)) & 0xFFu) == code ? bf2f((bf16_t)d[j]) : 0.f;
+              dz[4 + j] += ((am.y >> (8 * j)) & 0xFFu) == code ? bf2f((bf16_t)d[4 + j]) : 0.f;
+            }
+          }
+        s16x8 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = (short)f2bf(cg0[j] * dz[j] + bf2f((bf16_t)fy[i][j]) * ck10[j] + ck00[j]);
+          v[4 + j] = (short)f2bf(cg1[j] * dz[4 + j] + bf2f((bf16_t)fy[i][4 + j]) * ck11[j] + ck01[j]);
+        }
+        dyr[i] = pxl < p.OW ? v : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
     }
   };
   load_dy(oh_a);
   for (int oh = oh_a; oh < oh_b; ++oh) {
     const int ih0 = oh * STR - p.pad;
     const bool more = oh + 1 < oh_b;
+    finish_dy(oh);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pxl = (tid >> 3) + i * 32, pl = pxl & 63;
@@ -341,6 +421,27 @@ DL4J_API int dl4j_conv_c3_fwd(const void* x, const void* wpad, const float* bias
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)wpad; p.bias = bias; p.y = (bf16_t*)y; p.stats = stats; p.dy = nullptr; p.dwp = nullptr;
   p.N = N; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.pad = pad; p.rpb = rpb; p.nrb = (OH + rpb - 1) / rpb;
   hipLaunchKernelGGL((conv_c3_fwd_kernel<7, 7, 2>), dim3((unsigned)(N * p.nrb)), dim3(256), 0, st, p);
+  DL4J_RET_LAST();
+}
+
+// Weight gradient with the gradient tensor recomputed in the loader (StemP::bp_*): the stem convolution followed by the fused
+// BatchNorm -> ReLU -> MaxPool(3x3, stride 2, pad ppad) node. y = the convolution's output [N,OH,OW,64]; pooled_dy / idx [N,PH,PW,64];
+// coef fp32 [3][64] (16-byte aligned) as written by dl4j_bn_pool_bwd_reduce.
+DL4J_API int dl4j_conv_c3_wgrad_bnpool(const void* y, const void* pooled_dy, const uint8_t* idx, const float* coef, int PH, int PW, int ppad,
+                                       const void* x, float* scratch, float* dw_out, int N, int H, int W, int OH, int OW, int KH, int KW,
+                                       int stride, int pad, int rpb, int accumulate, hipStream_t st) {
+  const int rc = stem_check(N, H, W, OH, OW, KH, KW, stride, pad, rpb);
+  if (rc) return rc;
+  if (!y || !pooled_dy || !idx || !coef || PH <= 0 || PW <= 0 || ppad < 0 || ppad > 2) return -3;
+  if (PH != (OH + 2 * ppad - 3) / 2 + 1 || PW != (OW + 2 * ppad - 3) / 2 + 1) return -4;
+  if ((((uintptr_t)y | (uintptr_t)pooled_dy | (uintptr_t)coef) & 15) || ((uintptr_t)idx & 7)) return -2;
+  StemP p;
+  p.x = (const bf16_t*)x; p.w = nullptr; p.bias = nullptr; p.y = nullptr; p.stats = nullptr; p.dy = nullptr; p.dwp = scratch;
+  p.N = N; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.pad = pad; p.rpb = rpb; p.nrb = (OH + rpb - 1) / rpb;
+  p.bp_y = (const bf16_t*)y; p.bp_dy = (const bf16_t*)pooled_dy; p.bp_idx = idx; p.bp_coef = coef; p.PH = PH; p.PW = PW; p.ppad = ppad;
+  hipLaunchKernelGGL((conv_c3_wgrad_kernel<7, 7, 2, true>), dim3((unsigned)(N * p.nrb)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(conv_c3_wgrad_finalize_kernel, dim3((64 * KH * 32 + 255) / 256), dim3(256), 0, st, scratch, dw_out, KH, KW,
+                     accumulate);
   DL4J_RET_LAST();
 }
 

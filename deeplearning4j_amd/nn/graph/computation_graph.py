@@ -33,6 +33,7 @@ from ..layers.core import BatchNormalizationImpl, ConvolutionLayerImpl, Activati
 from ..layers.recurrent import LSTMImpl, SimpleRnnImpl
 from ..network_base import BaseNetwork
 from ...ops.conv_igemm import MaskedGrad
+from ...ops.bn_pool import PoolBnGrad
 from .vertices import create_vertex, VertexImpl, ElementWiseVertexImpl, LastTimeStepVertexImpl, \
     DuplicateToTimeSeriesVertexImpl, ReverseTimeSeriesVertexImpl
 
@@ -147,6 +148,10 @@ class _FusedBNPoolNode(_Node):
         beta = bn.params["beta"].reshape(-1) if "beta" in bn.params else None
         dg = bn.grads["gamma"].reshape(-1) if "gamma" in bn.grads else None
         db = bn.grads["beta"].reshape(-1) if "beta" in bn.grads else None
+        if BP.LAZY_DX:
+            lazy = BP.backward_lazy(bn._x2, dy, y, idx, gamma, beta, bn._mean, bn._invstd, dg, db, geom, bn._shp, bn._from2d)
+            self._st = None
+            return [lazy]
         dx2 = BP.backward(bn._x2, dy, y, idx, gamma, beta, bn._mean, bn._invstd, dg, db, geom)
         self._st = None
         return [bn._from2d(dx2, bn._shp)]
@@ -648,6 +653,9 @@ class ComputationGraph(BaseNetwork):
                     continue
                 if isinstance(e, MaskedGrad):
                     e = e.materialize()
+                elif isinstance(e, PoolBnGrad) and not (type(nd) is _Node and nd.is_layer and nd.pre is None
+                                                        and type(nd.impl) is ConvolutionLayerImpl):
+                    e = e.materialize()                   # only a plain convolution layer knows how to consume it unevaluated
                 # fan-out accumulation fused into the conv dgrad epilogue: the gradient already collected for this node's
                 # input is updated in place instead of materialising dx and running a separate add
                 acc_in = sink = sink_bn = None

@@ -479,7 +479,16 @@ class ConvolutionLayerImpl(LayerImpl):
         """``accum``: gradient already collected for this layer's input — a tensor (added in place by the dgrad epilogue) or a
         MaskedGrad (added from its source through the mask bits). ``bn_sink``: see ops/conv_igemm.BnBackwardSink."""
         from ...ops.conv_igemm import MaskedGrad
+        from ...ops.bn_pool import PoolBnGrad
         c = self.conf
+        if isinstance(eps, PoolBnGrad):
+            # the gradient of a fused BatchNorm -> ReLU -> MaxPool node, not evaluated yet: the stem weight-gradient kernel recomputes it
+            # in its loader when nothing else needs it (first layer: no input gradient, identity activation, no bias gradient)
+            if (self.z is None and accum is None and not getattr(self, "needs_input_grad", True)
+                    and not ("b" in self.params and not self.fold_bias) and eps.fusable_3x3s2()
+                    and CONV.stem_wgrad_bnpool(eps, self.input, self.w("W"), c.stride, self._pad, c.dilation, self.grads["W"])):
+                return None
+            eps = eps.materialize()
         dz = eps if self.z is None else c.activationFn.backprop(self.z, eps)
         if dz.dtype != self.input.dtype:
             dz = dz.to(self.input.dtype)

@@ -101,6 +101,19 @@ def dgrad_epilogue_ok(dz, x, w, stride, padding, dilation, w_dgrad):
     return IG.dgrad_supported(w, stride, padding, dz)
 
 
+def stem_wgrad_bnpool(lazy, x, w, stride, padding, dilation, dw_out):
+    """Weight gradient of the 3-channel stem from an unevaluated bn_pool.PoolBnGrad; False when this call is not the stem kernels'."""
+    if not (_stem_eligible(x, w, stride, padding, dilation) and x.shape[1] < 8 and lazy.dtype == torch.bfloat16
+            and dw_out is not None and dw_out.dtype == torch.float32 and dw_out.is_contiguous()):
+        return False
+    from . import conv_stem
+    oh, ow = conv_stem._out_hw(x, padding)
+    if (lazy.geom[0], lazy.geom[1], lazy.geom[2]) != (x.shape[0], oh, ow) or not lazy.x2.is_contiguous() or not lazy.dy.is_contiguous():
+        return False
+    conv_stem.wgrad_bnpool(lazy, x, stride, padding, dilation, dw_out=dw_out)
+    return True
+
+
 def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=True, need_db=False, w_dgrad=None,
                     dw_out=None, dx_accum=None, dw_prezeroed=False, dx_acc_masked=None, bn_sink=None):
     """Returns (dx, dW, db); dW has logical shape [nOut, nIn, kH, kW] — or None when it was written

@@ -76,3 +76,25 @@ def wgrad(dz, x, stride, padding, dilation, dw_out=None):
                                        L.c_int(OW), L.c_int(7), L.c_int(7), L.c_int(2), L.c_int(int(padding[0])),
                                        L.c_int(_rows_per_block(WGRAD_ROWS_PER_BLOCK, N, OH)), L.c_int(0), L.stream()), "conv_c3_wgrad")
     return None if dw_out is not None else tgt
+
+
+def wgrad_bnpool(lazy, x, stride, padding, dilation, dw_out=None):
+    """dW of the stem conv when its output gradient is a bn_pool.PoolBnGrad: the gradient rows are recomputed inside the kernel's loader
+    from the pooled gradient, the argmax bytes and the convolution's own output (never written to memory)."""
+    N, _, H, W = x.shape
+    OH, OW = _out_hw(x, padding)
+    g = lazy.geom
+    assert lazy.fusable_3x3s2() and (g[0], g[1], g[2]) == (N, OH, OW) and lazy.x2.dtype == torch.bfloat16
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    scratch = _SCRATCH.get(key)
+    if scratch is None:
+        scratch = _SCRATCH[key] = torch.zeros(64 * 7 * 32, device=x.device, dtype=torch.float32)
+    tgt = dw_out if dw_out is not None else torch.empty(64, 3, 7, 7, device=x.device, dtype=torch.float32)
+    assert tgt.dtype == torch.float32 and tgt.is_contiguous() and tgt.numel() == 64 * 147
+    coef = lazy.ws[3 * 64:6 * 64]
+    L.check(L.hip().dl4j_conv_c3_wgrad_bnpool(L.ptr(lazy.x2), L.ptr(lazy.dy), L.ptr(lazy.idx), L.ptr(coef), L.c_int(g[4]), L.c_int(g[5]),
+                                              L.c_int(g[10]), L.ptr(x), L.ptr(scratch), L.ptr(tgt), L.c_int(N), L.c_int(H), L.c_int(W),
+                                              L.c_int(OH), L.c_int(OW), L.c_int(7), L.c_int(7), L.c_int(2), L.c_int(int(padding[0])),
+                                              L.c_int(_rows_per_block(WGRAD_ROWS_PER_BLOCK, N, OH)), L.c_int(0), L.stream()),
+            "conv_c3_wgrad_bnpool")
+    return None if dw_out is not None else tgt

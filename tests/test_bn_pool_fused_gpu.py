@@ -102,3 +102,48 @@ def test_graph_node_matches_layer_by_layer(monkeypatch):
     monkeypatch.setattr(BP, "ENABLED", False)
     ob = b.outputSingle(x)
     assert (oa.float() - ob.float()).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("N,HW,pool_pad,conv_pad", [(3, 38, 1, 3), (2, 45, 0, 3), (2, 32, 1, 0)])
+def test_stem_wgrad_recomputes_the_pool_bn_gradient_in_its_loader(N, HW, pool_pad, conv_pad):
+    """dl4j_conv_c3_wgrad_bnpool (the gradient rows of the fused BN -> ReLU -> MaxPool node recomputed inside the stem weight-gradient
+    kernel, never written) against (a) the materialised gradient fed to the plain stem weight-gradient kernel and (b) fp32 PyTorch."""
+    from deeplearning4j_amd.ops import bn_pool as BP
+    from deeplearning4j_amd.ops import conv_stem as CS
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(N, 3, HW, HW, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, device="cuda", generator=g) * 0.1).bfloat16()
+    st, pd, dl = (2, 2), (conv_pad, conv_pad), (1, 1)
+    assert CS.supported(x, w, st, pd, dl)
+    z, _ = CS.forward(x, w, None, st, pd, dl)                                   # [N, 64, OH, OW] channels-last bf16
+    OH, OW = z.shape[2], z.shape[3]
+    gamma = torch.rand(64, device="cuda", generator=g) + 0.5
+    beta = torch.randn(64, device="cuda", generator=g) * 0.3
+    zf = z.float()
+    mean, var = zf.mean((0, 2, 3)), zf.var((0, 2, 3), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    z2 = z.permute(0, 2, 3, 1).reshape(-1, 64)
+    assert z2.is_contiguous()
+    geom = BP.geometry((N, OH, OW, 64), (3, 3), (2, 2), (pool_pad, pool_pad))
+    assert BP.usable(z2, geom)
+    y, idx = BP.forward(z2, scale, shift, geom, True)
+    dy = torch.randn(N, geom[4], geom[5], 64, device="cuda", generator=g).bfloat16()
+    dg, db = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    from2d = lambda t, shp: t.view(N, OH, OW, 64).permute(0, 3, 1, 2)
+    lazy = BP.backward_lazy(z2, dy, y, idx, gamma, beta, mean, invstd, dg, db, geom, (N, OH, OW, 64), from2d)
+    assert lazy.fusable_3x3s2() and tuple(lazy.shape) == (N, 64, OH, OW)
+    dw_fused = CS.wgrad_bnpool(lazy, x, st, pd, dl)
+    dz = lazy.materialize()
+    dw_plain = CS.wgrad(dz, x, st, pd, dl)
+    sc = dw_plain.abs().max().item()
+    assert (dw_fused - dw_plain).abs().max().item() < 2e-3 * sc, (dw_fused - dw_plain).abs().max().item() / sc   # same bf16 rows, fp32 sums
+    # (b) fp32 reference of conv -> BN -> ReLU -> pool
+    xr, wr = x.float(), w.float().requires_grad_(True)
+    zr = F.conv2d(xr, wr, None, st, pd)
+    m2, v2 = zr.mean((0, 2, 3)), zr.var((0, 2, 3), unbiased=False)
+    yr = F.max_pool2d(F.relu((zr - m2.view(1, -1, 1, 1)) * torch.rsqrt(v2.view(1, -1, 1, 1) + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)),
+                      3, 2, pool_pad)
+    gw, = torch.autograd.grad(yr, [wr], dy.float().permute(0, 3, 1, 2))
+    cos = float((dw_fused * gw).sum() / (dw_fused.norm() * gw.norm() + 1e-20))
+    assert cos > 0.995, cos
