@@ -209,30 +209,39 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   s16x8 e_y[E_NIT], e_prev[E_NIT];
   unsigned e_mb[E_NIT], e_ab[E_NIT];
   if constexpr (EPI == 1) {
+    // Straight-line code: every load is UNCONDITIONAL (absent operands are redirected to memory that is valid to read and their
+    // values discarded by selects on workgroup-uniform flags; rows past M read row M-1). With a branch per optional operand the
+    // compiler wrapped each load in its own block and waited vmcnt(0) inside it, i.e. the rows' round trips ran one after another.
     const int ch = tid % E_CPR, r0 = tid / E_CPR;
     const bool want = p.bnb_partial != nullptr;
+    const bool has_prev = p.acc_src != nullptr || p.accum;
+    const bf16_t* prev_ptr = p.acc_src != nullptr ? p.acc_src : p.y;                 // same layout as y; y itself when accumulating in place
+    const bool has_ab = p.acc_src != nullptr && p.acc_bits != nullptr;
+    const uint8_t* ab_ptr = has_ab ? p.acc_bits : reinterpret_cast<const uint8_t*>(prev_ptr);
+    const bf16_t* y_ptr = want ? p.bnb_y : prev_ptr;
+    const bool has_mb = want && p.bnb_mode == 1;
+    const uint8_t* mb_ptr = has_mb ? p.bnb_bits : reinterpret_cast<const uint8_t*>(y_ptr);
+    const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < E_NIT; ++i) {
       const int m = m0 + r0 + i * E_RPP;
-      e_o[i] = -1;
-      e_y[i] = s16x8{0, 0, 0, 0, 0, 0, 0, 0}; e_prev[i] = e_y[i];
-      e_mb[i] = 0xFFu; e_ab[i] = 0xFFu;
-      if (m < p.M) {
-        const int n = fdiv(m, p.d_ohw), rem = m - n * OHW;
-        const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
-        const int64_t o = (((int64_t)n * p.OHs + oh * p.oys) * p.OWs + ow * p.oxs) * p.K + n0 + ch * 8;
-        e_o[i] = o;
-        if (p.acc_src != nullptr) {
-          e_prev[i] = *reinterpret_cast<const s16x8*>(p.acc_src + o);
-          if (p.acc_bits != nullptr) e_ab[i] = p.acc_bits[o >> 3];
-        } else if (p.accum) {
-          e_prev[i] = *reinterpret_cast<const s16x8*>(p.y + o);
-        }
-        if (want) {
-          e_y[i] = *reinterpret_cast<const s16x8*>(p.bnb_y + o);
-          if (p.bnb_mode == 1) e_mb[i] = p.bnb_bits[o >> 3];
-        }
+      const int mc = m < p.M ? m : p.M - 1;
+      const int n = fdiv(mc, p.d_ohw), rem = mc - n * OHW;
+      const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
+      const int64_t o = (((int64_t)n * p.OHs + oh * p.oys) * p.OWs + ow * p.oxs) * p.K + n0 + ch * 8;
+      e_o[i] = m < p.M ? o : (int64_t)-1;
+      s16x8 pv = zero8;
+      unsigned ab = 0xFFu;
+      if (has_prev) {                                  // uniform for the whole grid and around BOTH loads of the row
+        pv = *reinterpret_cast<const s16x8*>(prev_ptr + o);
+        ab = ab_ptr[o >> 3];
       }
+      const s16x8 yv = *reinterpret_cast<const s16x8*>(y_ptr + o);
+      const unsigned mb = mb_ptr[o >> 3];
+      e_prev[i] = pv;
+      e_ab[i] = has_ab ? ab : 0xFFu;
+      e_y[i] = yv;
+      e_mb[i] = has_mb ? mb : 0xFFu;
     }
   }
 
