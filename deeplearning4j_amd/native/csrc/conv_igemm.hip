@@ -79,6 +79,13 @@ struct IGemmP {
   FastDiv d_ohw, d_ow;      // divisions by OH*OW and OW (set in launch_fwd)
 };
 
+// 256 bytes of zeros: out-of-range operand pieces (padding taps, rows past M, channel tails) are LOADED from here. The loaders are
+// straight-line code - per-lane source select, unconditional 16-byte load. Written as "v = 0; if (ok) v = load" every load sat in its
+// own EXEC-masked block behind a zero initialisation of its destination registers, and the compiler guarded those writes with
+// s_waitcnt vmcnt(1): the first loads of a k-tile had to RETURN before the remaining ones were issued (two exposed round trips per
+// k-tile instead of one).
+static __device__ __attribute__((aligned(256))) unsigned char g_conv_zero_page[256];
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
@@ -132,9 +139,8 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
     for (int i = 0; i < AI; ++i) {
       const int ih = a_ih0[i] + r * p.dh, iw = a_iw0[i] + s * p.dw;
       const bool ok = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-      s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok) v = *reinterpret_cast<const s16x8*>(p.x + ((int64_t)a_base[i] + doff));
-      ra[i] = v;
+      const bf16_t* src = ok ? p.x + ((int64_t)a_base[i] + doff) : reinterpret_cast<const bf16_t*>(g_conv_zero_page);
+      ra[i] = *reinterpret_cast<const s16x8*>(src);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i)
@@ -637,22 +643,22 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int pp = pb + prA + i * RPA;
-      s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (pp < pend && k0 + chA * 8 < p.K) v = *reinterpret_cast<const s16x8*>(p.dy + (int64_t)pp * p.K + k0 + chA * 8);
-      ra[i] = v;
+      const bf16_t* src = (pp < pend && k0 + chA * 8 < p.K) ? p.dy + (int64_t)pp * p.K + k0 + chA * 8
+                                                            : reinterpret_cast<const bf16_t*>(g_conv_zero_page);
+      ra[i] = *reinterpret_cast<const s16x8*>(src);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int pp = pb + prB + i * RPB;
-      s16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (pp < pend && c0 + chB * 8 < p.C) {
-        const int n = fdiv(pp, p.d_ohw), rem = pp - n * OHW;
-        const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
-        const int ih = oh * p.sh - p.ph + r * p.dh, iw = ow * p.sw - p.pw + s * p.dw_;
-        if (((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W))
-          v = *reinterpret_cast<const s16x8*>(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.C + c0 + chB * 8);
-      }
-      rb[i] = v;
+      const int ppc = pp < pend ? pp : pend - 1;                     // pend > pstart >= 0 is not guaranteed: clamp at 0 as well
+      const int ppv = ppc < 0 ? 0 : ppc;
+      const int n = fdiv(ppv, p.d_ohw), rem = ppv - n * OHW;
+      const int oh = fdiv(rem, p.d_ow), ow = rem - oh * p.OW;
+      const int ih = oh * p.sh - p.ph + r * p.dh, iw = ow * p.sw - p.pw + s * p.dw_;
+      const bool ok = pp < pend && c0 + chB * 8 < p.C && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+      const bf16_t* src = ok ? p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.C + c0 + chB * 8
+                             : reinterpret_cast<const bf16_t*>(g_conv_zero_page);
+      rb[i] = *reinterpret_cast<const s16x8*>(src);
     }
   };
   auto swrite = [&](int buf) {
