@@ -86,6 +86,11 @@ struct IGemmP {
 // k-tile instead of one).
 static __device__ __attribute__((aligned(256))) unsigned char g_conv_zero_page[256];
 
+// 16-byte global load the compiler does not track (no automatic s_waitcnt: see `retire` in igemm_fwd_kernel)
+__device__ __forceinline__ void async_load16(s16x8& dst, const void* src) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src));
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
@@ -130,8 +135,12 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
   const int KT = p.R * p.S * CT;
   const int64_t wrow = (int64_t)p.R * p.S * p.C;
 
-  s16x8 ra[AI], rb[BI];
-  auto gload = [&](int t) {
+  // Two register stages: the loads of k-tile t+2 are issued at the top of iteration t and written to LDS at the end of iteration
+  // t+1, so every load has two iterations to land. The deep-reduction layers (3x3 taps, C >= 512: 18-72 k-tiles of only 4-16 MFMAs
+  // per wave) run at one exposed round trip per k-tile with a single stage. Even tiles travel through set 0, odd tiles through set 1
+  // (static register names: the loop is unrolled by two).
+  s16x8 ra0[AI], rb0[BI], ra1[AI], rb1[BI];
+  auto gload = [&](int t, s16x8 (&ra)[AI], s16x8 (&rb)[BI]) {
     const int rs = t / CT, c0 = (t - rs * CT) << 6;
     const int r = rs / p.S, s = rs - r * p.S;
     const int doff = ((r * p.dh) * p.W + s * p.dw) * p.C + c0 + chunk * 8;
@@ -140,13 +149,24 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
       const int ih = a_ih0[i] + r * p.dh, iw = a_iw0[i] + s * p.dw;
       const bool ok = ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
       const bf16_t* src = ok ? p.x + ((int64_t)a_base[i] + doff) : reinterpret_cast<const bf16_t*>(g_conv_zero_page);
-      ra[i] = *reinterpret_cast<const s16x8*>(src);
+      async_load16(ra[i], src);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i)
-      rb[i] = *reinterpret_cast<const s16x8*>(p.w + (int64_t)(n0 + lrow + 32 * i) * wrow + rs * p.C + c0 + chunk * 8);
+      async_load16(rb[i], p.w + (int64_t)(n0 + lrow + 32 * i) * wrow + rs * p.C + c0 + chunk * 8);
   };
-  auto swrite = [&](int buf) {
+  // the loads above are invisible to the compiler's wait-count bookkeeping (which drained the queue at the loop header once two
+  // register sets were in flight): retire a set by hand, leaving `newer` younger loads in flight; the set's registers are tied to the
+  // wait so that nothing consuming them can be scheduled ahead of it
+  auto retire = [&](s16x8 (&ra)[AI], s16x8 (&rb)[BI], bool newer) {
+    if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < AI; ++i) asm volatile("" : "+v"(ra[i]));
+#pragma unroll
+    for (int i = 0; i < BI; ++i) asm volatile("" : "+v"(rb[i]));
+  };
+  auto swrite = [&](int buf, const s16x8 (&ra)[AI], const s16x8 (&rb)[BI]) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int row = lrow + 32 * i;
@@ -167,8 +187,10 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  gload(0);
-  swrite(0);
+  gload(0, ra0, rb0);
+  if (KT > 1) gload(1, ra1, rb1);
+  retire(ra0, rb0, KT > 1);
+  swrite(0, ra0, rb0);
   __syncthreads();
   const int l31 = lane & 31, lh = lane >> 5;
   // statistics pivot of this lane's output columns, requested before the K loop so the epilogue does not wait for it
@@ -178,9 +200,7 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
     const int col = n0 + wn * (BN / 2) + j * 32 + l31;
     pvq[j] = p.piv_mean ? p.piv_mean[col] - (p.piv_bias ? p.piv_bias[col] : 0.f) : 0.f;
   }
-  for (int t = 0; t < KT; ++t) {
-    const int cur = t & (p.nbuf - 1);
-    if (t + 1 < KT) gload(t + 1);
+  auto compute = [&](int cur) {
     const char* cA = sA + cur * (BM * 128);
     const char* cB = sB + cur * (BN * 128);
 #pragma unroll
@@ -203,9 +223,21 @@ __global__ void __launch_bounds__(256) igemm_fwd_kernel(const IGemmP p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < KT) swrite(cur ^ 1);
+  };
+  const int bmask = p.nbuf - 1;
+  for (int t = 0; t < KT; t += 2) {
+    if (t + 2 < KT) gload(t + 2, ra0, rb0);          // set 0 is free: tile t went to LDS in the previous iteration (or the prologue)
+    compute(t & bmask);
+    if (t + 1 < KT) { retire(ra1, rb1, t + 2 < KT); swrite((t + 1) & bmask, ra1, rb1); }
     __syncthreads();
+    if (t + 1 < KT) {                                // workgroup-uniform: every wave takes the same barriers
+      if (t + 3 < KT) gload(t + 3, ra1, rb1);
+      compute((t + 1) & bmask);
+      if (t + 2 < KT) { retire(ra0, rb0, t + 3 < KT); swrite((t + 2) & bmask, ra0, rb0); }
+      __syncthreads();
+    }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // EPI == 1: everything the fused epilogue reads from global memory is requested HERE, for all of this thread's rows at once,
   // so the latencies overlap each other and the accumulator staging below (issued row by row inside the store loop they were
