@@ -670,14 +670,15 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
   const int chB = tid % CPB, prB = tid / CPB;
   const int OHW = p.OH * p.OW;
 
-  s16x8 ra[NA], rb[NB];
-  auto gload = [&](int pb) {
+  // two register stages of untracked loads, as in igemm_fwd_kernel: even steps travel through set 0, odd steps through set 1
+  s16x8 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+  auto gload = [&](int pb, s16x8 (&ra)[NA], s16x8 (&rb)[NB]) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int pp = pb + prA + i * RPA;
       const bf16_t* src = (pp < pend && k0 + chA * 8 < p.K) ? p.dy + (int64_t)pp * p.K + k0 + chA * 8
                                                             : reinterpret_cast<const bf16_t*>(g_conv_zero_page);
-      ra[i] = *reinterpret_cast<const s16x8*>(src);
+      async_load16(ra[i], src);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -690,10 +691,18 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
       const bool ok = pp < pend && c0 + chB * 8 < p.C && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
       const bf16_t* src = ok ? p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.C + c0 + chB * 8
                              : reinterpret_cast<const bf16_t*>(g_conv_zero_page);
-      rb[i] = *reinterpret_cast<const s16x8*>(src);
+      async_load16(rb[i], src);
     }
   };
-  auto swrite = [&](int buf) {
+  auto retire = [&](s16x8 (&ra)[NA], s16x8 (&rb)[NB], bool newer) {
+    if (newer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[i]));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(rb[i]));
+  };
+  auto swrite = [&](int buf, const s16x8 (&ra)[NA], const s16x8 (&rb)[NB]) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int pl = prA + i * RPA;
@@ -714,14 +723,7 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // the step count is workgroup-uniform (both groups run the same barriers); a group whose range is shorter loads zeros
-  const int nsteps = (half + 63) / 64;
-  gload(pstart);
-  swrite(0);
-  __syncthreads();
-  for (int t = 0; t < nsteps; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nsteps) gload(pstart + (t + 1) * 64);
+  auto compute = [&](int cur) {
     const char* cA = sA + cur * (64 * PA);
     const char* cB = sB + cur * (64 * PB);
 #pragma unroll
@@ -737,9 +739,27 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = wg_mfma<F16>(af[i], bfr[j], acc[i][j]);
     }
-    if (t + 1 < nsteps) swrite(cur ^ 1);
+  };
+  // the step count is workgroup-uniform (both groups run the same barriers); a group whose range is shorter loads zeros
+  const int nsteps = (half + 63) / 64;
+  gload(pstart, ra0, rb0);
+  if (nsteps > 1) gload(pstart + 64, ra1, rb1);
+  retire(ra0, rb0, nsteps > 1);
+  swrite(0, ra0, rb0);
+  __syncthreads();
+  for (int t = 0; t < nsteps; t += 2) {
+    if (t + 2 < nsteps) gload(pstart + (t + 2) * 64, ra0, rb0);
+    compute(0);
+    if (t + 1 < nsteps) { retire(ra1, rb1, t + 2 < nsteps); swrite(1, ra1, rb1); }
     __syncthreads();
+    if (t + 1 < nsteps) {
+      if (t + 3 < nsteps) gload(pstart + (t + 3) * 64, ra1, rb1);
+      compute(1);
+      if (t + 2 < nsteps) { retire(ra0, rb0, t + 3 < nsteps); swrite(0, ra0, rb0); }
+      __syncthreads();
+    }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // group 1 hands its partial tile to group 0 through LDS (the operand buffers are free now: BK_*BC_*4 <= 2*GBYTES)
   float* xch = reinterpret_cast<float*>(smem);
