@@ -41,7 +41,7 @@ def main():
         dz = torch.randn(M, N, device="cuda").bfloat16()
         out = torch.zeros(N, K, device="cuda")
         t = G.pick_tile(N, K, M, torch.bfloat16)
-        t = 0 if t == 4 else t
+        t = 0 if t in (4, 10) else t                     # as ops.gemm.gemm maps the ping-pong tiles for the layout-aware kernels
         sp = G.pick_splits(N, K, M, t, torch.bfloat16)
         heur = graph_time(lambda: G.gemm(dz.t(), x.t(), out=out, splits=sp, accum=True))
         best = min((graph_time(lambda: G.gemm(dz.t(), x.t(), out=out, splits=s, accum=True)), s) for s in (1, 2, 4, 8, 16, 32))
