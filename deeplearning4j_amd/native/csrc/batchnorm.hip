@@ -395,8 +395,15 @@ __global__ void bn_infer_coeffs_kernel(const float* __restrict__ gamma, const fl
 // registers (HOIST): the loop body is then pure streaming (loads, FMAs, stores) instead of
 // issuing 16-40 scalar coefficient loads per vector.
 // ---------------------------------------------------------------------------------------
+// Grid of the streaming passes. In isolation (tools/stream_lab: y = relu(x * s + b), bf16, rotating buffers) 8192 blocks stream at
+// 5.65 TB/s against 5.2 at 2048 blocks (206 MB), but inside the training step the larger grids are slower (8.59 ms at 2048, 8.62 at
+// 8192, 8.66 at 16384): the default stays at 8 blocks per CU.
+static int bn_stream_blocks() { static int v = bn_env_int("DL4J_BN_STREAM_BLOCKS", 2048); return v < 256 ? 256 : v; }
 static inline int hoist_grid(int64_t nvec, int cv, bool* hoist) {
-  int g = launch_grid(LS_BATCHNORM, grid_for(nvec, 256));
+  int64_t want = (nvec + 255) / 256;
+  if (want < 1) want = 1;
+  if (want > bn_stream_blocks()) want = bn_stream_blocks();
+  int g = launch_grid(LS_BATCHNORM, (int)want);
   *hoist = false;
   if (cv <= 256) {
     if (256 % cv == 0) *hoist = true;
