@@ -115,3 +115,40 @@ def test_matmul_and_batched_gemm_ops_take_every_layout_without_copies(monkeypatc
     for k in range(3):
         ref = 2.0 * loose[k].float().t() @ looseB[k].float().t()
         assert float((outs[k].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 200), (1000, 1300, 72), (2048, 2048, 1024), (300, 260, 8)])
+def test_pingpong_deep_loop_matches_fp32_and_the_drain_form_bitwise(M, N, K):
+    """256 x 256 ping-pong GEMM with half-tile staging and counted vmcnt waits (tile 10, gemm_core.h mainloop_pingpong_deep) against fp32
+    PyTorch; the MFMA order is the one of the drain-per-tile loop (tile 4), so repeated runs must agree with it BITWISE - a staged
+    half-tile read before it landed (or re-staged too early) shows up as a differing run. Tails in M, N and K, K < one tile."""
+    from deeplearning4j_amd.ops import gemm as G
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+    ref = x.float() @ w.float().t()
+    y4 = G.gemm_nt(x, w, tile=4)
+    for _ in range(8):
+        y10 = G.gemm_nt(x, w, tile=10)
+        assert torch.equal(y10, y4)
+    assert float((y10.float() - ref).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("act", [None, "relu", "gelu", "gelu_erf", "tanh", "sigmoid"])
+@pytest.mark.parametrize("tile", [2, 0, 10])
+def test_every_epilogue_activation_body_on_small_and_pingpong_tiles(act, tile):
+    """gemm_epilogue.h has one straight-line body per activation kind (linear / ReLU share the branch-free one): each of them, with bias
+    and residual, on a 64 x 64 tile, the 128 x 128 tile and the 256 x 256 ping-pong tile."""
+    from deeplearning4j_amd.ops import gemm as G
+    g = torch.Generator(device="cuda").manual_seed(7)
+    M, N, K = 520, 384, 192
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    r = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    z = x.float() @ w.float().t() + b
+    f = {None: lambda t: t, "relu": torch.relu, "gelu": lambda t: torch.nn.functional.gelu(t, approximate="tanh"),
+         "gelu_erf": torch.nn.functional.gelu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act]
+    ref = f(z).bfloat16().float() + r.float()
+    y = G.gemm_nt(x, w, bias=b, act=act, residual=r, tile=tile)
+    assert float((y.float() - ref).abs().max()) <= 3e-2 * max(1.0, float(ref.abs().max()))
