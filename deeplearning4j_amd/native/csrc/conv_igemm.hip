@@ -598,6 +598,13 @@ struct WGradP {
   int ktiles, ctiles, splits, pps;   // pps: pixels per split (multiple of 64)
   int use_atomic;
   FastDiv d_ohw, d_ow;
+  // Piggy-backed second stage of a BatchNorm backward reduction: `tail_blocks` extra workgroups behind the `main_blocks` of the weight
+  // gradient sum the [tail_gy][2][tail_C] partial rows that the preceding data-gradient launch emitted (bn_sum_partials_kernel's work).
+  // The two jobs are independent and adjacent in the backward pass, so one launch does both and the 5-6 us dependent launch per
+  // BatchNorm disappears (52 per ResNet-50 step).
+  int main_blocks, tail_blocks, tail_gy, tail_C;
+  const float* tail_partial;
+  float* tail_sums; float* tail_out0; float* tail_out1;
 };
 
 template <int PITCH>
@@ -647,12 +654,41 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
   constexpr int TM = BK_ / 64, TN = BC_ / 64;
   constexpr int GBYTES = 2 * 64 * (PA + PB);         // double-buffered operands of one group
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x >= p.main_blocks) {
+    // tail workgroup: 32 columns x 16 row groups of the partial rows (columns [0, C) = sum dz, [C, 2C) = sum dz * xhat)
+    float* red = reinterpret_cast<float*>(smem);
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int C = p.tail_C, col = ((int)blockIdx.x - p.main_blocks) * 32 + cl;
+    float a = 0.f;
+    if (col < 2 * C) {
+      const float* q = p.tail_partial + col;          // row stride 2C: column `col` of row y is partial[y][col / C][col % C]
+      float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int y = rg;
+      for (; y + 48 < p.tail_gy; y += 64) {
+        a += q[(int64_t)y * 2 * C]; a1 += q[(int64_t)(y + 16) * 2 * C];
+        a2 += q[(int64_t)(y + 32) * 2 * C]; a3 += q[(int64_t)(y + 48) * 2 * C];
+      }
+      for (; y < p.tail_gy; y += 16) a += q[(int64_t)y * 2 * C];
+      a += a1 + a2 + a3;
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (rg == 0 && col < 2 * C) {
+      a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a += red[k * 32 + cl];
+      p.tail_sums[col] = a;
+      if (col < C) { if (p.tail_out0) p.tail_out0[col] = a; }
+      else if (p.tail_out1) p.tail_out1[col - C] = a;
+    }
+    return;
+  }
   const int grp = threadIdx.x >> 8;
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
   char* sA = smem + grp * GBYTES;
   char* sB = sA + 2 * 64 * PA;
 
-  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int lid = xcd_remap(blockIdx.x, p.main_blocks);
   const int RS = p.R * p.S;
   const int ct = lid % p.ctiles; lid /= p.ctiles;
   const int kt = lid % p.ktiles; lid /= p.ktiles;
@@ -838,7 +874,8 @@ static int launch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream_t
   static_assert(BK_ * BC_ * 4 <= 2 * 2 * 64 * (BK_ + BC_) * 2, "exchange tile must fit the operand buffers");
   static DeviceOnceLds lds_attr;
   lds_attr.ensure(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BK_, BC_, F16>), smem);
-  hipLaunchKernelGGL((igemm_wgrad_kernel<BK_, BC_, F16>), dim3(tiles * splits), dim3(512), smem, st, p);
+  p.main_blocks = tiles * splits;
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BK_, BC_, F16>), dim3(p.main_blocks + p.tail_blocks), dim3(512), smem, st, p);
   DL4J_RET_LAST();
 }
 
@@ -854,9 +891,18 @@ static int dispatch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream
   return launch_wgrad<64, 64, F16>(p, target_blocks, prezeroed, st);
 }
 
+struct WGradTail {
+  const float* partial; int gy, C; float* sums; float* out0; float* out1;
+};
 static int wgrad_entry(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks, int prezeroed, int f16,
-                       hipStream_t st) {
+                       hipStream_t st, const WGradTail* tail = nullptr) {
   WGradP p;
+  p.tail_blocks = 0; p.tail_gy = 0; p.tail_C = 0; p.tail_partial = nullptr; p.tail_sums = p.tail_out0 = p.tail_out1 = nullptr;
+  if (tail != nullptr) {
+    if (!tail->partial || !tail->sums || tail->gy <= 0 || tail->C <= 0) return -2;
+    p.tail_blocks = (2 * tail->C + 31) / 32; p.tail_gy = tail->gy; p.tail_C = tail->C;
+    p.tail_partial = tail->partial; p.tail_sums = tail->sums; p.tail_out0 = tail->out0; p.tail_out1 = tail->out1;
+  }
   p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw_out;
   p.N = g[0]; p.H = g[1]; p.W = g[2]; p.C = g[3]; p.OH = g[4]; p.OW = g[5]; p.K = g[6]; p.R = g[7]; p.S = g[8];
   p.sh = g[9]; p.sw = g[10]; p.ph = g[11]; p.pw = g[12]; p.dh = g[13]; p.dw_ = g[14];
@@ -875,6 +921,15 @@ DL4J_API int dl4j_igemm_wgrad_dt(const void* dy, const void* x, float* dw_out, c
                                  int dtype, hipStream_t st) {
   if (dtype != 0 && dtype != 1) return -2;
   return wgrad_entry(dy, x, dw_out, g, target_blocks, prezeroed, dtype, st);
+}
+
+// dl4j_igemm_wgrad_dt + the piggy-backed partial-row reduction (WGradP::tail_*): partial [gy][2][C] -> sums [2C], and the dbeta (out0)
+// / dgamma (out1) gradient views when given
+DL4J_API int dl4j_igemm_wgrad_tail(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks, int prezeroed,
+                                   int dtype, const float* partial, int gy, int C, float* sums, float* out0, float* out1, hipStream_t st) {
+  if (dtype != 0 && dtype != 1) return -2;
+  WGradTail t{partial, gy, C, sums, out0, out1};
+  return wgrad_entry(dy, x, dw_out, g, target_blocks, prezeroed, dtype, st, &t);
 }
 
 // fp32 [K][RS][C] -> [K][C][RS]  (OHWI -> DL4J OIHW gradient view)

@@ -376,8 +376,10 @@ class BatchNormalizationImpl(LayerImpl):
             return None
         from ...ops.conv_igemm import BnBackwardSink
         mc = getattr(self, "_mask_coeffs", None)
+        dg = self.grads["gamma"].reshape(-1) if "gamma" in self.grads else None
+        db = self.grads["beta"].reshape(-1) if "beta" in self.grads else None
         return BnBackwardSink(x2, self._mean, self._invstd, mc[0] if mc else None, mc[1] if mc else None,
-                              getattr(self, "_mask_bits", None))
+                              getattr(self, "_mask_bits", None), dbeta_out=db, dgamma_out=dg)
 
     def backward(self, eps, return_dz=False, lazy_dz=False, ext_mask_bits=None):
         """``lazy_dz``: return dz = eps * [out > 0] as a MaskedGrad (eps + the saved mask bits) instead of writing it.
@@ -399,7 +401,7 @@ class BatchNormalizationImpl(LayerImpl):
         want_dz = return_dz or self._want_dz
         lazy = lazy_dz and want_dz and bits is not None and MaskedGrad.ok(eps, bits)
         sink, self._bwd_sink = getattr(self, "_bwd_sink", None), None
-        pre = (sink.partial, sink.gy) if (sink is not None and sink.partial is not None) else None
+        pre = (sink.partial, sink.gy, sink.sums) if (sink is not None and sink.partial is not None) else None
         dx2, dz2 = BN.backward(self._x2, d2, self._out2, self._mean, self._invstd, gamma, dg, db,
                                want_dz=want_dz and not lazy, mask_coeffs=getattr(self, "_mask_coeffs", None),
                                mask_bits=bits, pre_partials=pre)

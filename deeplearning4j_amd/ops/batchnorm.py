@@ -243,10 +243,14 @@ def backward(x2d, dy2d, out2d, mean, invstd, gamma, dgamma_out, dbeta_out, want_
         if pre_partials is not None:
             # (partial [gy, 2, C], gy): per-tile sum dz / sum dz*xhat rows emitted by the epilogue of the data-gradient launch
             # that produced dy (ops/conv_igemm.BnBackwardSink): only the tiny second stage runs here
-            part, gy = pre_partials
+            part, gy = pre_partials[0], pre_partials[1]
             assert part.numel() >= gy * 2 * C
-            L.check(h.dl4j_bn_sum_partials(L.ptr(part), L.c_int(gy), L.c_int(C), L.ptr(sums), L.ptr(dbeta_out if direct else None),
-                                           L.ptr(dgamma_out if direct else None), L.stream()), "bn_sum_partials")
+            done = pre_partials[2] if len(pre_partials) > 2 else None
+            if done is not None and direct:
+                sums = done                      # second stage already ran inside the weight-gradient launch (and wrote dbeta / dgamma)
+            else:
+                L.check(h.dl4j_bn_sum_partials(L.ptr(part), L.c_int(gy), L.c_int(C), L.ptr(sums), L.ptr(dbeta_out if direct else None),
+                                               L.ptr(dgamma_out if direct else None), L.stream()), "bn_sum_partials")
         elif mask_bits is not None:
             L.check(h.dl4j_bn_bwd_reduce_mask(L.ptr(x2d), L.ptr(dy2d), L.ptr(mask_bits), L.ptr(mean), L.ptr(invstd), L.ptr(ws),
                                               L.ptr(sums), L.ptr(dbeta_out if direct else None), L.ptr(dgamma_out if direct else None),

@@ -141,15 +141,20 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
         dx = dW = db = None
         if need_db:
             db = dz.float().sum((0, 2, 3))
-        if need_dw:
+        def _wgrad(tail=None):
             from . import streams
             if (streams.active() and dw_out is not None and dw_out.dtype == torch.float32 and dw_out.is_contiguous()
                     and dz.is_contiguous(memory_format=torch.channels_last)):
                 # dW goes straight into the flat gradient view and is not read before the updater: side stream
                 with streams.side_region(streams.fork(dz, x, dw_out), 'convolution weight-gradient'):
                     IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
-            else:
-                dW = IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed)
+                return None
+            return IG.wgrad(dz, x, w.shape, stride, padding, dilation, dw_out=dw_out, prezeroed=dw_prezeroed, tail=tail)
+        # with a BatchNorm sink the data gradient runs FIRST: its epilogue emits the partial rows and the weight-gradient launch
+        # (independent of them, next in the stream) sums them in extra workgroups - no separate second-stage launch
+        wgrad_late = need_dw and need_dx and bn_sink is not None
+        if need_dw and not wgrad_late:
+            dW = _wgrad()
         if need_dx:
             if w_dgrad is not None and IG.dgrad_supported(w, stride, padding, dz):
                 acc = dx_accum if IG.accum_ok(dx_accum, x.shape) else None
@@ -165,6 +170,8 @@ def conv2d_backward(dz, x, w, stride, padding, dilation, need_dx=True, need_dw=T
                     list(dilation), False, [0, 0], 1, [True, False, False])[0]
                 if dx_accum is not None:
                     dx = dx_accum + dx
+        if wgrad_late:
+            dW = _wgrad(tail=bn_sink if (bn_sink is not None and bn_sink.partial is not None) else None)
         return dx, dW, db
     if dz.dtype == torch.bfloat16 and _stem_eligible(x, w, stride, padding, dilation):
         from . import conv_stem

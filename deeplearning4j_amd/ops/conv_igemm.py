@@ -137,11 +137,18 @@ class BnBackwardSink:
     ``y`` is the BatchNorm input as [M, C] (the memory of the channels-last tensor), ``ms``/``mt`` recompute a fused ReLU's
     mask from y, ``bits`` is the saved mask of a residual block. After the launch ``partial`` ([gy, 2, C] fp32: per-tile sum dz and
     sum dz * xhat) and ``gy`` are set; ops/batchnorm.backward(pre_partials=...) then skips its column-reduction pass."""
-    __slots__ = ("y", "mean", "invstd", "ms", "mt", "bits", "partial", "gy")
+    __slots__ = ("y", "mean", "invstd", "ms", "mt", "bits", "partial", "gy", "dbeta_out", "dgamma_out", "sums")
 
-    def __init__(self, y, mean, invstd, ms=None, mt=None, bits=None):
+    def __init__(self, y, mean, invstd, ms=None, mt=None, bits=None, dbeta_out=None, dgamma_out=None):
         self.y, self.mean, self.invstd, self.ms, self.mt, self.bits = y, mean, invstd, ms, mt, bits
         self.partial, self.gy = None, 0
+        # where the finished sums go (fp32 contiguous gradient views or None); ``sums`` ([2C]) is set by whoever ran the second stage
+        # of the reduction - the weight-gradient launch that follows the data-gradient launch piggy-backs it (wgrad(tail=...))
+        self.dbeta_out, self.dgamma_out, self.sums = dbeta_out, dgamma_out, None
+
+    def tail_ok(self):
+        return (self.partial is not None and self.sums is None
+                and all(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda) for t in (self.dbeta_out, self.dgamma_out)))
 
     def ok(self, x_shape):
         N, C, H, W = x_shape
@@ -302,7 +309,25 @@ def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation, accum_into=None, acc_
     return dx
 
 
-def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=0, prezeroed=False):
+TAIL_SUMS = __import__("os").environ.get("DL4J_AMD_WGRAD_TAIL", "1") == "1"
+
+
+def _wgrad_launch(dz, x, tgt, g, target_blocks, prezeroed, dt, tail):
+    """bf16 / fp16 weight-gradient launch; with ``tail`` (a BnBackwardSink holding partial rows) the same launch also finishes that
+    BatchNorm's backward sums (dl4j_igemm_wgrad_tail) and the sink is marked done (``sums`` set)."""
+    if tail is not None and TAIL_SUMS and tail.tail_ok():
+        C = tail.y.shape[-1]
+        sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        L.check(L.hip().dl4j_igemm_wgrad_tail(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.c_int(prezeroed), dt,
+                                              L.ptr(tail.partial), L.c_int(tail.gy), L.c_int(C), L.ptr(sums), L.ptr(tail.dbeta_out),
+                                              L.ptr(tail.dgamma_out), L.stream()), "igemm_wgrad_tail")
+        tail.sums = sums
+        return
+    L.check(L.hip().dl4j_igemm_wgrad_dt(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.c_int(prezeroed), dt, L.stream()),
+            "igemm_wgrad")
+
+
+def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=0, prezeroed=False, tail=None):
     """dW. If ``dw_out`` (fp32, contiguous, logical [K,C,R,S]) is given the result is written there and
     None is returned; otherwise a new fp32 [K,C,R,S] tensor is returned. ``prezeroed``: dw_out is known to be all
     zeros (the network clears the flat gradient vector once per iteration), so no per-layer memset is issued."""
@@ -333,13 +358,11 @@ def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=
             L.check(L.hip().dl4j_ohwi_to_oihw(L.ptr(scratch), L.ptr(tgt), L.c_int(K), L.c_int(R * S), L.c_int(C), L.c_int(1),
                                               L.stream()), "ohwi_to_oihw")
     elif R * S == 1:
-        L.check(L.hip().dl4j_igemm_wgrad_dt(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks),
-                                            L.c_int(1 if (prezeroed and tgt is dw_out) else 0), dt, L.stream()), "igemm_wgrad")
+        _wgrad_launch(dz, x, tgt, g, target_blocks, 1 if (prezeroed and tgt is dw_out) else 0, dt, tail)
     else:
         # scratch starts zeroed and the layout transposer re-zeroes exactly what it read: no memset per layer
         scratch = _ws(K * R * S * C, x.device, "igemm_wgrad")
-        L.check(L.hip().dl4j_igemm_wgrad_dt(L.ptr(dz), L.ptr(x), L.ptr(scratch), g, L.c_int(target_blocks), L.c_int(1), dt,
-                                            L.stream()), "igemm_wgrad")
+        _wgrad_launch(dz, x, scratch, g, target_blocks, 1, dt, tail)
         L.check(L.hip().dl4j_ohwi_to_oihw(L.ptr(scratch), L.ptr(tgt), L.c_int(K), L.c_int(R * S), L.c_int(C), L.c_int(1),
                                           L.stream()), "ohwi_to_oihw")
     if ret is not None and dw_out is not None:
