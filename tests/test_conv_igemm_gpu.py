@@ -349,3 +349,31 @@ def test_forward_and_dgrad_with_more_than_2_31_operand_elements():
     for n in (0, 63):
         d1 = IG.dgrad(y[n:n + 1].contiguous(memory_format=torch.channels_last), (1, C, H, H), w_dgrad, (1, 1), (0, 0), (1, 1))
         assert torch.equal(dx[n:n + 1], d1), n
+
+
+@pytest.mark.parametrize("R,C,K,gy", [(1, 256, 64, 37), (3, 64, 64, 200), (1, 512, 2048, 9)])
+def test_wgrad_launch_also_finishes_a_batchnorm_backward_reduction(R, C, K, gy):
+    """dl4j_igemm_wgrad_tail: extra workgroups of the weight-gradient launch sum [gy][2][Cb] partial rows into sums[2 Cb] and the
+    dbeta / dgamma views (the second stage of the BatchNorm backward that the preceding data-gradient launch started); dW itself must
+    be what the plain launch produces."""
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    g = torch.Generator(device="cuda").manual_seed(R * 1000 + C + K)
+    N, H = 4, 14
+    x = torch.randn(N, C, H, H, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    p = R // 2
+    dz = torch.randn(N, K, H, H, device="cuda", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    dw_plain = IG.wgrad(dz, x, (K, C, R, R), (1, 1), (p, p), (1, 1))
+    Cb = C                                            # the BatchNorm in front of this convolution has C channels
+    part = torch.randn(gy, 2, Cb, device="cuda", generator=g)
+    y2 = torch.empty(8, Cb, device="cuda", dtype=torch.bfloat16)
+    db, dg = torch.full((Cb,), 7.0, device="cuda"), torch.full((Cb,), 7.0, device="cuda")
+    sink = IG.BnBackwardSink(y2, None, None, dbeta_out=db, dgamma_out=dg)
+    sink.partial, sink.gy = part.reshape(-1), gy
+    assert sink.tail_ok()
+    dw_tail = IG.wgrad(dz, x, (K, C, R, R), (1, 1), (p, p), (1, 1), tail=sink)
+    assert sink.sums is not None and not sink.tail_ok()
+    want = part.double().sum(0)
+    assert torch.allclose(sink.sums.double(), want.reshape(-1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(db.double(), want[0], rtol=1e-5, atol=1e-4) and torch.allclose(dg.double(), want[1], rtol=1e-5, atol=1e-4)
+    sc = dw_plain.abs().max().item()
+    assert (dw_tail - dw_plain).abs().max().item() <= 2e-3 * sc       # split-K atomics: order of the fp32 adds differs between runs
