@@ -602,6 +602,13 @@ struct WGradP {
   // gradient sum the [tail_gy][2][tail_C] partial rows that the preceding data-gradient launch emitted (bn_sum_partials_kernel's work).
   // The two jobs are independent and adjacent in the backward pass, so one launch does both and the 5-6 us dependent launch per
   // BatchNorm disappears (52 per ResNet-50 step).
+  // Column sums of dy (the bias gradient of a dense layer = 1x1 convolution over "pixels") accumulated from the operand tiles that pass
+  // through the registers anyway: db[k] += sum over pixels of dy[p][k] (fp32 atomics into a pre-zeroed / accumulating vector). Every
+  // (k-tile, pixel step) is summed by exactly one of the workgroups that load it (the one with ct == step % ctiles). Replaces one
+  // 5-6 us launch per linear layer of the BERT step.
+  float* db;
+  int db_mode;       // 1: column sums of the dy operand -> db[K];  2: column sums of the x operand -> db[C] (callers that pass the
+                     // activations in the dy slot and the gradient in the x slot to get the transposed dW: ops/linear.py)
   int main_blocks, tail_blocks, tail_gy, tail_C;
   const float* tail_partial;
   float* tail_sums; float* tail_out0; float* tail_out1;
@@ -778,20 +785,42 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
   };
   // the step count is workgroup-uniform (both groups run the same barriers); a group whose range is shorter loads zeros
   const int nsteps = (half + 63) / 64;
+  float cs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+  const bool want_db = p.db != nullptr && rs == 0;
+  const int db_mode = p.db_mode;
+  auto colsum = [&](int t, const s16x8 (&ra)[NA], const s16x8 (&rb)[NB]) {          // rows past the range were loaded from the zero page
+    if (!want_db) return;
+    if (db_mode == 1) {
+      if ((t % p.ctiles) == ct) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cs[j] += F16 ? (float)__builtin_bit_cast(_Float16, ra[i][j]) : bf2f((bf16_t)ra[i][j]);
+      }
+    } else if ((t % p.ktiles) == kt) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += F16 ? (float)__builtin_bit_cast(_Float16, rb[i][j]) : bf2f((bf16_t)rb[i][j]);
+    }
+  };
   gload(pstart, ra0, rb0);
   if (nsteps > 1) gload(pstart + 64, ra1, rb1);
   retire(ra0, rb0, nsteps > 1);
+  colsum(0, ra0, rb0);
   swrite(0, ra0, rb0);
   __syncthreads();
   for (int t = 0; t < nsteps; t += 2) {
     if (t + 2 < nsteps) gload(pstart + (t + 2) * 64, ra0, rb0);
     compute(0);
-    if (t + 1 < nsteps) { retire(ra1, rb1, t + 2 < nsteps); swrite(1, ra1, rb1); }
+    if (t + 1 < nsteps) { retire(ra1, rb1, t + 2 < nsteps); colsum(t + 1, ra1, rb1); swrite(1, ra1, rb1); }
     __syncthreads();
     if (t + 1 < nsteps) {
       if (t + 3 < nsteps) gload(pstart + (t + 3) * 64, ra1, rb1);
       compute(1);
-      if (t + 2 < nsteps) { retire(ra0, rb0, t + 3 < nsteps); swrite(0, ra0, rb0); }
+      if (t + 2 < nsteps) { retire(ra0, rb0, t + 3 < nsteps); colsum(t + 2, ra0, rb0); swrite(0, ra0, rb0); }
       __syncthreads();
     }
   }
@@ -799,6 +828,18 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
 
   // group 1 hands its partial tile to group 0 through LDS (the operand buffers are free now: BK_*BC_*4 <= 2*GBYTES)
   float* xch = reinterpret_cast<float*>(smem);
+  float* cred = reinterpret_cast<float*>(smem + BK_ * BC_ * 4);      // [2 groups][RPA rows][BK_] (or [RPB][BC_]) behind the exchange tile
+  static_assert(BK_ * BC_ * 4 + 2 * RPA * BK_ * 4 <= 2 * GBYTES && BK_ * BC_ * 4 + 2 * RPB * BC_ * 4 <= 2 * GBYTES,
+                "column-sum scratch must fit behind the exchange tile");
+  if (want_db) {
+    if (db_mode == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cred[(grp * RPA + prA) * BK_ + chA * 8 + j] = cs[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cred[(grp * RPB + prB) * BC_ + chB * 8 + j] = cs[j];
+    }
+  }
   if (grp == 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -808,6 +849,19 @@ __global__ void __launch_bounds__(512) igemm_wgrad_kernel(const WGradP p) {
         for (int e = 0; e < 16; ++e) xch[(((i * TN + j) * 16 + e) * 4 + wid) * 64 + lane] = acc[i][j][e];
   }
   __syncthreads();
+  if (want_db && grp == 0) {
+    if (db_mode == 1) {
+      if (tid < BK_ && k0 + tid < p.K) {
+        float a = 0.f;
+        for (int r2 = 0; r2 < 2 * RPA; ++r2) a += cred[r2 * BK_ + tid];
+        atomicAdd(p.db + k0 + tid, a);
+      }
+    } else if (tid < BC_ && c0 + tid < p.C) {
+      float a = 0.f;
+      for (int r2 = 0; r2 < 2 * RPB; ++r2) a += cred[r2 * BC_ + tid];
+      atomicAdd(p.db + c0 + tid, a);
+    }
+  }
   if (grp == 1) return;
   const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -891,12 +945,15 @@ static int dispatch_wgrad(WGradP& p, int target_blocks, int prezeroed, hipStream
   return launch_wgrad<64, 64, F16>(p, target_blocks, prezeroed, st);
 }
 
+static thread_local float* g_wgrad_db = nullptr;
+static thread_local int g_wgrad_db_mode = 1;
 struct WGradTail {
   const float* partial; int gy, C; float* sums; float* out0; float* out1;
 };
 static int wgrad_entry(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks, int prezeroed, int f16,
                        hipStream_t st, const WGradTail* tail = nullptr) {
   WGradP p;
+  p.db = g_wgrad_db; p.db_mode = g_wgrad_db_mode;
   p.tail_blocks = 0; p.tail_gy = 0; p.tail_C = 0; p.tail_partial = nullptr; p.tail_sums = p.tail_out0 = p.tail_out1 = nullptr;
   if (tail != nullptr) {
     if (!tail->partial || !tail->sums || tail->gy <= 0 || tail->C <= 0) return -2;
@@ -921,6 +978,18 @@ DL4J_API int dl4j_igemm_wgrad_dt(const void* dy, const void* x, float* dw_out, c
                                  int dtype, hipStream_t st) {
   if (dtype != 0 && dtype != 1) return -2;
   return wgrad_entry(dy, x, dw_out, g, target_blocks, prezeroed, dtype, st);
+}
+
+// dl4j_igemm_wgrad_dt for a 1x1 problem that also accumulates the column sums of dy into db [K] (fp32, atomics: zeroed or accumulating)
+// mode 1: sums of the dy operand -> db[K]; mode 2: sums of the x operand -> db[C] (stride 1, no padding: every pixel row is read once)
+DL4J_API int dl4j_igemm_wgrad_db(const void* dy, const void* x, float* dw_out, const int* g, int target_blocks, int prezeroed,
+                                 int dtype, float* db, int mode, hipStream_t st) {
+  if ((dtype != 0 && dtype != 1) || db == nullptr || g[7] != 1 || g[8] != 1 || (mode != 1 && mode != 2)) return -2;
+  if (mode == 2 && (g[9] != 1 || g[10] != 1 || g[11] != 0 || g[12] != 0)) return -2;
+  g_wgrad_db = db; g_wgrad_db_mode = mode;
+  const int rc = wgrad_entry(dy, x, dw_out, g, target_blocks, prezeroed, dtype, st);
+  g_wgrad_db = nullptr; g_wgrad_db_mode = 1;
+  return rc;
 }
 
 // dl4j_igemm_wgrad_dt + the piggy-backed partial-row reduction (WGradP::tail_*): partial [gy][2][C] -> sums [2C], and the dbeta (out0)

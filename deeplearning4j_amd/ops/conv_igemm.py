@@ -312,9 +312,15 @@ def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation, accum_into=None, acc_
 TAIL_SUMS = __import__("os").environ.get("DL4J_AMD_WGRAD_TAIL", "1") == "1"
 
 
-def _wgrad_launch(dz, x, tgt, g, target_blocks, prezeroed, dt, tail):
+def _wgrad_launch(dz, x, tgt, g, target_blocks, prezeroed, dt, tail, db_out=None, db_of_x=False):
     """bf16 / fp16 weight-gradient launch; with ``tail`` (a BnBackwardSink holding partial rows) the same launch also finishes that
-    BatchNorm's backward sums (dl4j_igemm_wgrad_tail) and the sink is marked done (``sums`` set)."""
+    BatchNorm's backward sums (dl4j_igemm_wgrad_tail) and the sink is marked done (``sums`` set). ``db_out`` (1x1 problems): fp32 [K]
+    vector that receives += the column sums of dz (a dense layer's bias gradient) from the same launch."""
+    if db_out is not None:
+        assert tail is None and db_out.dtype == torch.float32 and db_out.is_contiguous() and db_out.numel() == (g[3] if db_of_x else g[6])
+        L.check(L.hip().dl4j_igemm_wgrad_db(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.c_int(prezeroed), dt,
+                                            L.ptr(db_out), L.c_int(2 if db_of_x else 1), L.stream()), "igemm_wgrad_db")
+        return
     if tail is not None and TAIL_SUMS and tail.tail_ok():
         C = tail.y.shape[-1]
         sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
@@ -327,7 +333,8 @@ def _wgrad_launch(dz, x, tgt, g, target_blocks, prezeroed, dt, tail):
             "igemm_wgrad")
 
 
-def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=0, prezeroed=False, tail=None):
+def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=0, prezeroed=False, tail=None, db_out=None,
+          db_of_x=False):
     """dW. If ``dw_out`` (fp32, contiguous, logical [K,C,R,S]) is given the result is written there and
     None is returned; otherwise a new fp32 [K,C,R,S] tensor is returned. ``prezeroed``: dw_out is known to be all
     zeros (the network clears the flat gradient vector once per iteration), so no per-layer memset is issued."""
@@ -358,14 +365,21 @@ def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=
             L.check(L.hip().dl4j_ohwi_to_oihw(L.ptr(scratch), L.ptr(tgt), L.c_int(K), L.c_int(R * S), L.c_int(C), L.c_int(1),
                                               L.stream()), "ohwi_to_oihw")
     elif R * S == 1:
-        _wgrad_launch(dz, x, tgt, g, target_blocks, 1 if (prezeroed and tgt is dw_out) else 0, dt, tail)
+        _wgrad_launch(dz, x, tgt, g, target_blocks, 1 if (prezeroed and tgt is dw_out) else 0, dt, tail, db_out, db_of_x)
+        db_out = None
     else:
         # scratch starts zeroed and the layout transposer re-zeroes exactly what it read: no memset per layer
         scratch = _ws(K * R * S * C, x.device, "igemm_wgrad")
         _wgrad_launch(dz, x, scratch, g, target_blocks, 1, dt, tail)
         L.check(L.hip().dl4j_ohwi_to_oihw(L.ptr(scratch), L.ptr(tgt), L.c_int(K), L.c_int(R * S), L.c_int(C), L.c_int(1),
                                           L.stream()), "ohwi_to_oihw")
+    assert db_out is None, "db_out is served by the 1x1 bf16 / fp16 launch only (see db_fusable)"
     if ret is not None and dw_out is not None:
         dw_out.copy_(ret)
         return None
     return ret
+
+
+def db_fusable(x, w_shape):
+    """Can wgrad(..., db_out=...) take the bias gradient along? (1x1 problem on the bf16 / fp16 split-K kernel)"""
+    return x.dtype in (torch.bfloat16, torch.float16) and w_shape[2] * w_shape[3] == 1

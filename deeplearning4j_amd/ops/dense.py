@@ -48,12 +48,23 @@ def _tn_core_wins(nOut, nIn, dtype):
     return dtype in (torch.bfloat16, torch.float16) and ((nOut + 127) // 128) * ((nIn + 127) // 128) >= 128
 
 
-def dw(dz2, x2, dw_t, prezeroed):
+def dw_takes_db(dz2, x2):
+    """True when dw(..., db_out=...) can accumulate the bias gradient (column sums of dz) in the same launch."""
+    nIn, nOut = x2.shape[1], dz2.shape[1]
+    return (x2.dtype in (torch.bfloat16, torch.float16)
+            and not (_tn_core_wins(nOut, nIn, x2.dtype) and G.supported_ex(dz2.t(), x2.t())))
+
+
+def dw(dz2, x2, dw_t, prezeroed, db_out=None, db_of_x=False):
+    """``db_out`` (fp32, accumulated into): column sums of dz2 - or of x2 with ``db_of_x`` (ops/linear.py passes the gradient in the
+    x2 slot to get the [nIn, nOut] image of dW) - from the same launch; only when dw_takes_db()."""
     M, nIn = x2.shape
     nOut = dz2.shape[1]
+    if db_out is not None:
+        assert dw_takes_db(dz2, x2)
     if _tn_core_wins(nOut, nIn, x2.dtype) and G.supported_ex(dz2.t(), x2.t()):
         # dW[nOut, nIn] = dz^T . x with both operands read K-major (no transposes); accumulates like the atomics of the other path
         G.gemm(dz2.t(), x2.t(), out=dw_t, splits=1, accum=bool(prezeroed))
         return
     IG.wgrad(dz2.view(M, nOut, 1, 1), x2.view(M, nIn, 1, 1), (nOut, nIn, 1, 1), (1, 1), (0, 0), (1, 1), dw_out=dw_t.view(nOut, nIn, 1, 1),
-             prezeroed=prezeroed)
+             prezeroed=prezeroed, db_out=db_out, db_of_x=db_of_x)

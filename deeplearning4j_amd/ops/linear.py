@@ -137,6 +137,9 @@ def activation(x, name):
     return act_fwd(x, a)
 
 
+FUSE_DB = __import__("os").environ.get("DL4J_AMD_DENSE_FUSE_DB", "1") == "1"
+
+
 class FusedDenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, residual, act_id):
@@ -178,7 +181,16 @@ class FusedDenseFn(torch.autograd.Function):
         dres = dy.reshape(ctx.rshape) if (ctx.rshape is not None and ctx.needs_input_grad[3]) else None
         dx = dw = db = None
         want_b = ctx.bias_meta is not None and ctx.needs_input_grad[2]
-        if want_b or z is not None:
+        lw = ctx.wlink
+        # linear layer whose dW goes straight into the flat gradient vector on the split-K kernel: that launch also sums the columns of dy
+        # into the bias gradient (no separate bias-gradient pass)
+        db_fused = None
+        if (want_b and z is None and FUSE_DB and ctx.bias_meta[2] is not None and ctx.needs_input_grad[1] and lw is not None and lw.hits == 0
+                and not STREAMS.dense_active() and d2.is_cuda and DENSE.dw_ok(x2, d2, lw.grad.view(K, N)) and DENSE.dw_takes_db(x2, d2)
+                and ctx.bias_meta[2].grad.dtype == torch.float32 and ctx.bias_meta[2].grad.is_contiguous()):
+            db_fused = ctx.bias_meta[2].grad.reshape(-1)
+            ctx.bias_meta[2].hits += 1
+        if (want_b and db_fused is None) or z is not None:
             tgt = None
             if want_b:
                 bl = ctx.bias_meta[2]
@@ -191,7 +203,6 @@ class FusedDenseFn(torch.autograd.Function):
             d2 = act_bwd_colsum(z, d2, ctx.act_id, tgt)
             if db is not None:
                 db = db.to(ctx.bias_meta[0]).reshape(ctx.bias_meta[1])
-        lw = ctx.wlink
         direct = ctx.needs_input_grad[1] and lw is not None and lw.hits == 0 and DENSE.dw_ok(x2, d2, lw.grad.view(K, N))
         side = direct and STREAMS.dense_active()
         if side:
@@ -205,7 +216,8 @@ class FusedDenseFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not side:
             if direct:
                 lw.hits += 1
-                DENSE.dw(x2, d2, lw.grad.view(K, N), True)         # x^T . dy -> [K, N] fp32, straight into the flat gradient vector
+                # x^T . dy -> [K, N] fp32, straight into the flat gradient vector (+ the bias gradient when fused)
+                DENSE.dw(x2, d2, lw.grad.view(K, N), True, db_out=db_fused, db_of_x=db_fused is not None)
             else:
                 if lw is not None:
                     STREAMS.join()                                 # an earlier use of this weight may still be accumulating on the side stream

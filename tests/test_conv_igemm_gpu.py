@@ -377,3 +377,24 @@ def test_wgrad_launch_also_finishes_a_batchnorm_backward_reduction(R, C, K, gy):
     assert torch.allclose(db.double(), want[0], rtol=1e-5, atol=1e-4) and torch.allclose(dg.double(), want[1], rtol=1e-5, atol=1e-4)
     sc = dw_plain.abs().max().item()
     assert (dw_tail - dw_plain).abs().max().item() <= 2e-3 * sc       # split-K atomics: order of the fp32 adds differs between runs
+
+
+@pytest.mark.parametrize("M,nIn,nOut", [(4096, 768, 768), (1000, 256, 64), (520, 64, 136)])
+@pytest.mark.parametrize("of_x", [False, True])
+def test_wgrad_launch_also_sums_the_bias_gradient(M, nIn, nOut, of_x):
+    """dl4j_igemm_wgrad_db: the dense-layer (1x1) weight-gradient launch accumulates the column sums of the gradient operand into db from
+    the operand tiles it loads anyway - of the dy slot (mode 1) or of the x slot (mode 2: ops/linear.py passes the operands swapped to
+    get the [nIn, nOut] image of dW). db is accumulated into (atomics), dW must be what the plain launch produces."""
+    from deeplearning4j_amd.ops import conv_igemm as IG
+    g = torch.Generator(device="cuda").manual_seed(M + nIn + nOut)
+    x = torch.randn(M, nIn, device="cuda", generator=g).bfloat16()
+    dz = torch.randn(M, nOut, device="cuda", generator=g).bfloat16()
+    a, b = (x, dz) if of_x else (dz, x)              # (dy slot, x slot)
+    ka, kb = a.shape[1], b.shape[1]
+    plain = IG.wgrad(a.view(M, ka, 1, 1), b.view(M, kb, 1, 1), (ka, kb, 1, 1), (1, 1), (0, 0), (1, 1))
+    db = torch.full((nOut,), 3.0, device="cuda")
+    fused = IG.wgrad(a.view(M, ka, 1, 1), b.view(M, kb, 1, 1), (ka, kb, 1, 1), (1, 1), (0, 0), (1, 1), db_out=db, db_of_x=of_x)
+    want = 3.0 + dz.double().sum(0)
+    assert torch.allclose(db.double(), want, rtol=1e-4, atol=2e-3 * float(dz.float().abs().sum(0).max()) / 100 + 1e-3), (db.double() - want).abs().max()
+    sc = plain.abs().max().item()
+    assert (fused - plain).abs().max().item() <= 2e-3 * sc
