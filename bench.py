@@ -9,6 +9,7 @@ Weak scaling: per-GPU batch fixed. Launch for N>1:
       bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -80,6 +81,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     score = net.score()
+    if not math.isfinite(float(score)):
+        # a step that produced a non-finite loss did not do the work being timed: refuse to report it
+        raise RuntimeError(f"non-finite training score after {args.warmup + args.steps} steps: {score}")
     # verification block (outside the timed region): what the collectives saw and whether the replicas still agree bit for bit
     if pw is not None:
         comm_rep = pw.comm_report(steps=args.steps)

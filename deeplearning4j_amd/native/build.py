@@ -39,6 +39,12 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+# Per-file compiler flags. conv_igemm.hip keeps its in-flight loads in accumulation registers that only inline asm names, so the
+# compiler must keep the MFMA accumulators in vector registers there (with accumulation registers in the clobber lists it would
+# otherwise select the accumulation-register form of the MFMAs). tools/check_async_loads.py verifies the generated code.
+EXTRA_FLAGS = {"conv_igemm.hip": ("-mllvm", "-amdgpu-mfma-vgpr-form")}
+
+
 def _newer(src: Path, dst: Path, extra=()) -> bool:
     if not dst.exists():
         return True
@@ -67,7 +73,8 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
         o = OBJ / (s.stem + ".hip.o")
         if force or _newer(s, o, headers):
             tasks.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
-                          "-Wno-unused-result", "-Wno-unused-value", "-I", str(CSRC), "-c", str(s), "-o", str(o)])
+                          "-Wno-unused-result", "-Wno-unused-value", *EXTRA_FLAGS.get(s.name, ()), "-I", str(CSRC), "-c", str(s),
+                          "-o", str(o)])
     for s in cpp_srcs:
         o = OBJ / (s.stem + ".cpp.o")
         if force or _newer(s, o, headers):

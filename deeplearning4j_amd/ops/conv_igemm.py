@@ -312,25 +312,61 @@ def dgrad(dz, x_shape, w_dgrad, stride, padding, dilation, accum_into=None, acc_
 TAIL_SUMS = __import__("os").environ.get("DL4J_AMD_WGRAD_TAIL", "1") == "1"
 
 
+class PendingSums:
+    """Second stages of column reductions that nobody reads before the optimizer step (layer-norm gain / bias gradients): instead of a
+    5 us launch each they wait here and ride on the next weight-gradient launch as extra workgroups (WGradP::tail_*). ``flush`` runs
+    what is left as ordinary launches; ops/helpers.layer_norm_bwd registers it as an end-of-backward callback of the autograd engine."""
+    items = []                       # (partial [gy, 2, C] fp32, gy, C, sums [2C] fp32 destination)
+    armed = False
+
+    @classmethod
+    def push(cls, partial, gy, C, sums):
+        cls.items.append((partial, gy, C, sums))
+        if not cls.armed:
+            cls.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+
+    @classmethod
+    def pop(cls, device):
+        for k, it in enumerate(cls.items):
+            if it[0].device == device:
+                return cls.items.pop(k)
+        return None
+
+    @classmethod
+    def flush(cls):
+        cls.armed = False
+        items, cls.items = cls.items, []
+        for partial, gy, C, sums in items:
+            with torch.cuda.device(partial.device):
+                L.check(L.hip().dl4j_bn_sum_partials(L.ptr(partial), L.c_int(gy), L.c_int(C), L.ptr(sums), None, None, L.stream()),
+                        "pending_param_sums")
+
+
 def _wgrad_launch(dz, x, tgt, g, target_blocks, prezeroed, dt, tail, db_out=None, db_of_x=False):
     """bf16 / fp16 weight-gradient launch; with ``tail`` (a BnBackwardSink holding partial rows) the same launch also finishes that
-    BatchNorm's backward sums (dl4j_igemm_wgrad_tail) and the sink is marked done (``sums`` set). ``db_out`` (1x1 problems): fp32 [K]
-    vector that receives += the column sums of dz (a dense layer's bias gradient) from the same launch."""
-    if db_out is not None:
-        assert tail is None and db_out.dtype == torch.float32 and db_out.is_contiguous() and db_out.numel() == (g[3] if db_of_x else g[6])
-        L.check(L.hip().dl4j_igemm_wgrad_db(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.c_int(prezeroed), dt,
-                                            L.ptr(db_out), L.c_int(2 if db_of_x else 1), L.stream()), "igemm_wgrad_db")
-        return
+    BatchNorm's backward sums and the sink is marked done (``sums`` set); without one, a pending deferred reduction (PendingSums) rides
+    along. ``db_out`` (1x1 problems): fp32 vector that receives += the column sums of the gradient operand (a dense layer's bias
+    gradient) from the same launch - of dz, or of x with ``db_of_x``."""
+    part = gy = C = sums = o0 = o1 = None
     if tail is not None and TAIL_SUMS and tail.tail_ok():
         C = tail.y.shape[-1]
         sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-        L.check(L.hip().dl4j_igemm_wgrad_tail(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.c_int(prezeroed), dt,
-                                              L.ptr(tail.partial), L.c_int(tail.gy), L.c_int(C), L.ptr(sums), L.ptr(tail.dbeta_out),
-                                              L.ptr(tail.dgamma_out), L.stream()), "igemm_wgrad_tail")
+        part, gy, o0, o1 = tail.partial, tail.gy, tail.dbeta_out, tail.dgamma_out
         tail.sums = sums
+    elif PendingSums.items and TAIL_SUMS:
+        it = PendingSums.pop(x.device)
+        if it is not None:
+            part, gy, C, sums = it
+    if db_out is not None:
+        assert db_out.dtype == torch.float32 and db_out.is_contiguous() and db_out.numel() == (g[3] if db_of_x else g[6])
+    if part is None and db_out is None:
+        L.check(L.hip().dl4j_igemm_wgrad_dt(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.c_int(prezeroed), dt, L.stream()),
+                "igemm_wgrad")
         return
-    L.check(L.hip().dl4j_igemm_wgrad_dt(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.c_int(prezeroed), dt, L.stream()),
-            "igemm_wgrad")
+    L.check(L.hip().dl4j_igemm_wgrad_riders(L.ptr(dz), L.ptr(x), L.ptr(tgt), g, L.c_int(target_blocks), L.c_int(prezeroed), dt,
+                                            L.ptr(db_out), L.c_int(2 if db_of_x else 1), L.ptr(part), L.c_int(gy or 0), L.c_int(C or 0),
+                                            L.ptr(sums), L.ptr(o0), L.ptr(o1), L.stream()), "igemm_wgrad_riders")
 
 
 def wgrad(dz, x, w_shape, stride, padding, dilation, dw_out=None, target_blocks=0, prezeroed=False, tail=None, db_out=None,

@@ -66,7 +66,7 @@ def layer_norm(x, gamma=None, beta=None, eps=1e-5, want_stats=False):
     return (y, mean, rstd) if want_stats else y
 
 
-def layer_norm_bwd(x, g, gamma, mean, rstd, want_param_grads=True, sums_out=None):
+def layer_norm_bwd(x, g, gamma, mean, rstd, want_param_grads=True, sums_out=None, defer_sums=False):
     """Returns (dx, dgamma, dbeta) — dgamma/dbeta fp32 [cols] (None unless want_param_grads). ``sums_out``: fp32 [2 * cols] the
     finishing kernel writes [dgamma | dbeta] into (adjacent views of a flat gradient vector)."""
     cols = x.shape[-1]
@@ -81,6 +81,11 @@ def layer_norm_bwd(x, g, gamma, mean, rstd, want_param_grads=True, sums_out=None
     L.check(L.hip().dl4j_layer_norm_bwd(L.ptr(x), L.ptr(g), L.ptr(ga), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(partial),
                                         L.c_int64(rows), L.c_int(cols), L.c_int(L.dtype_code(x)), L.stream()), "layer_norm_bwd")
     if not want_param_grads:
+        return dx, None, None
+    if defer_sums and sums_out is not None:
+        # nobody reads the sums before the optimizer: they ride on a later weight-gradient launch (or the end-of-backward flush)
+        from .conv_igemm import PendingSums
+        PendingSums.push(partial, gy, cols, sums)
         return dx, None, None
     L.check(L.hip().dl4j_bn_sum_partials(L.ptr(partial), L.c_int(gy), L.c_int(cols), L.ptr(sums), None, None, L.stream()),
             "layer_norm_param_sums")
@@ -433,6 +438,9 @@ def strided_slice_nd(x, begins, steps, counts):
     return index_map(x, out, maps)
 
 
+DEFER_LN_SUMS = __import__("os").environ.get("DL4J_AMD_LN_DEFER_SUMS", "1") == "1"
+
+
 class LayerNormFn(torch.autograd.Function):
     """Differentiable layer norm over the last axis: HIP kernels in both directions (one pass forward with saved mean / rstd,
     dx pass + partial column reduction backward). Used by the layer_norm platform helper while SameDiff records a training graph."""
@@ -460,7 +468,7 @@ class LayerNormFn(torch.autograd.Function):
             gl.hits += 1
             bl.hits += 1
             dx, _, _ = layer_norm_bwd(x, g.to(x.dtype).contiguous(), gamma, mean, rstd, True,
-                                      sums_out=torch.as_strided(gl.grad, (2 * cols,), (1,)))
+                                      sums_out=torch.as_strided(gl.grad, (2 * cols,), (1,)), defer_sums=DEFER_LN_SUMS)
             return dx, None, None, None
         dx, dg, db = layer_norm_bwd(x, g.to(x.dtype).contiguous(), gamma, mean, rstd, want_param_grads=need_p)
         dgamma = dg.reshape(gamma.shape).to(gamma.dtype) if (dg is not None and ctx.needs_input_grad[1]) else None

@@ -16,6 +16,12 @@ CASES = [
     (2, 64, 12, 12, 64, 3, 1, 2, 2),
     (2, 128, 8, 8, 128, 3, 2, 1, 1),
     (16, 64, 28, 28, 64, 3, 1, 1, 1),
+    # network-scale launches: the 128-row / 128-column tile instantiations and their fused data-gradient epilogues are only chosen
+    # from these sizes up (ResNet-50 at batch 256: the first of them once ran with a loader that the small cases never reached)
+    (256, 256, 7, 7, 256, 3, 1, 1, 1),
+    (32, 128, 28, 28, 128, 3, 1, 1, 1),
+    (64, 1024, 7, 7, 256, 1, 1, 0, 1),
+    (16, 256, 28, 28, 512, 1, 2, 0, 1),
 ]
 
 

@@ -44,7 +44,8 @@ def test_training_iterations_allocate_from_the_workspace_pool_and_reuse_it():
     # an allocation made while the scope is open lands in the pool, one made outside does not
     with mgr.notifyScopeEntered(ArrayType.ACTIVATIONS):
         assert mgr.isWorkspaceOpen(ArrayType.ACTIVATIONS)
-        t = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+        # larger than the whole pool (other networks of this process grew the per-thread workspace too), so no cached block can serve it
+        t = torch.empty(size2 + (64 << 20), dtype=torch.uint8, device="cuda")
         assert ws.getCurrentSize() >= size2 + (64 << 20)
     del t
     out = net.output(x)                                                         # inference scope: result outlives the scope
