@@ -648,6 +648,327 @@ __global__ void __launch_bounds__(STEP_THREADS) lstm_step_bwd_kernel(LstmBwdP p)
 }
 
 
+// ------------------------------------------------------------------------------------------------------------ diagonal kernels
+// A stack of L layers over T steps is a wavefront: (layer l, step t) needs (l, t - 1) and (l - 1, t). All cells of one anti-diagonal
+// d = l + t are independent, so ONE launch runs them all (blockIdx.y = layer) and a pass over the stack is T + L - 1 launches instead
+// of L * T step launches plus the per-chunk projection GEMMs, stream forks and events of the chunked pipeline. The input projection
+// of the upper layers is folded into the step as a second K segment: gates = b + H_below[t] . W + h[t-1] . RW (the first layer's
+// projection does not depend on the recurrence and stays one GEMM over the whole sequence). Backward mirrors it:
+// dL/dh(l, t) = E_ext + dG(l, t+1) . RW^T + dG(l+1, t) . W(l+1)^T, diagonals processed from (L-1, T-1) down.
+#define DIAG_MAXL 4
+struct LstmDiagLayerF {
+  const bf16_t* xw;        // [T, mb, 4n] projection + bias of the whole sequence (first layer), or null
+  const bf16_t* rw4;       // [4n, ld_rw]
+  int64_t ld_rw;
+  const bf16_t* w2;        // [4n, ld_w2] input weights, row = gate column (layers without xw)
+  int64_t ld_w2;
+  const bf16_t* x2;        // [T, mb, nIn] activations of the layer below
+  const float* bias;       // [4n]
+  const bf16_t* h0;
+  const bf16_t* c0;
+  const float* pf;
+  const float* po;
+  const float* pg;
+  bf16_t* H;
+  bf16_t* Cs;
+  bf16_t* SV;
+  int nIn;
+};
+struct LstmDiagFwdP {
+  LstmDiagLayerF lay[DIAG_MAXL];
+  int nl, d, T, mb, n;
+};
+
+__global__ void __launch_bounds__(STEP_THREADS) lstm_diag_fwd_kernel(LstmDiagFwdP p) {
+  __shared__ __attribute__((aligned(16))) f32x16 red[3 * 4 * 64];
+  const int li = blockIdx.y, t = p.d - li;
+  if (li >= p.nl || t < 0 || t >= p.T) return;                          // uniform per workgroup
+  const LstmDiagLayerF& q = p.lay[li];
+  const int n = p.n, mb = p.mb;
+  const int64_t hn = (int64_t)mb * n;
+  const bf16_t* hprev = t == 0 ? q.h0 : q.H + (t - 1) * hn;
+  const bf16_t* cprev = t == 0 ? q.c0 : q.Cs + (t - 1) * hn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = wave & 3, kp = wave >> 2;
+  const int u0 = blockIdx.x * 8;
+  const int row = tile * 32 + (lane & 31);
+  const int kq = lane >> 5;
+  const int uq = u0 + kq * 4;
+  const bool tile_on = tile * 32 < mb;
+  const bool row_ok = row < mb;
+  const bool cell_lane = tile_on && row_ok && kp == 0;
+  uint64_t xwv[4] = {0, 0, 0, 0}, cpv = 0;
+  float bv[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[g][j] = 0.f;
+  if (cell_lane) {
+    if (q.xw != nullptr) {
+      const bf16_t* xr = q.xw + ((int64_t)t * mb + row) * 4 * n + uq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xwv[g] = *(const uint64_t*)(xr + (int64_t)g * n);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *(const f32x4*)(q.bias + (int64_t)g * n + uq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[g][j] = b4[j];
+      }
+    }
+    cpv = *(const uint64_t*)(cprev + (int64_t)row * n + uq);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (tile_on) {
+    const int gc = lane & 31;
+    const bf16x8_t zero = {};
+    const int64_t wrow = (int64_t)(gc >> 3) * n + u0 + (gc & 7);
+    {
+      const int Kq = n >> 2;
+      const bf16_t* ap = q.rw4 + wrow * q.ld_rw + kp * Kq + kq * 8;
+      const bf16_t* bp = hprev + (int64_t)(row_ok ? row : 0) * n + kp * Kq + kq * 8;
+      for (int k0 = 0; k0 < Kq; k0 += 16 * STEP_KSTEPS) {
+        bf16x8_t a[STEP_KSTEPS], b[STEP_KSTEPS];
+#pragma unroll
+        for (int i = 0; i < STEP_KSTEPS; ++i) {
+          const int k = k0 + 16 * i;
+          a[i] = k < Kq ? *(const bf16x8_t*)(ap + k) : zero;
+          b[i] = (k < Kq && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < STEP_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+      }
+    }
+    if (q.xw == nullptr) {
+      const int Kq = q.nIn >> 2;
+      const bf16_t* ap = q.w2 + wrow * q.ld_w2 + kp * Kq + kq * 8;
+      const bf16_t* bp = q.x2 + ((int64_t)t * mb + (row_ok ? row : 0)) * q.nIn + kp * Kq + kq * 8;
+      for (int k0 = 0; k0 < Kq; k0 += 16 * STEP_KSTEPS) {
+        bf16x8_t a[STEP_KSTEPS], b[STEP_KSTEPS];
+#pragma unroll
+        for (int i = 0; i < STEP_KSTEPS; ++i) {
+          const int k = k0 + 16 * i;
+          a[i] = k < Kq ? *(const bf16x8_t*)(ap + k) : zero;
+          b[i] = (k < Kq && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < STEP_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+      }
+    }
+    if (kp > 0) red[((kp - 1) * 4 + tile) * 64 + lane] = acc;
+  }
+  __syncthreads();
+  if (!cell_lane) return;
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const f32x16 part = red[(kk * 4 + tile) * 64 + lane];
+    acc += part;
+  }
+  float c_state[4];
+  unpack4(cpv, c_state);
+  float wpf[4] = {0, 0, 0, 0}, wpo[4] = {0, 0, 0, 0}, wpg[4] = {0, 0, 0, 0};
+  if (q.pf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wpf[j] = q.pf[uq + j]; wpo[j] = q.po[uq + j]; wpg[j] = q.pg[uq + j]; }
+  }
+  float xa[4], xf[4], xo[4], xg[4];
+  unpack4(xwv[0], xa); unpack4(xwv[1], xf); unpack4(xwv[2], xo); unpack4(xwv[3], xg);
+  float hn4[4], cn[4], va[4], vf[4], vo[4], vg[4], vac[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float cp = c_state[j];
+    const float za = acc[j] + xa[j] + bv[0][j];
+    float zf = acc[4 + j] + xf[j] + bv[1][j], zo = acc[8 + j] + xo[j] + bv[2][j], zg = acc[12 + j] + xg[j] + bv[3][j];
+    if (q.pf) { zf += cp * wpf[j]; zg += cp * wpg[j]; }
+    const float a = tanh_fast(za), f = sigm(zf), g = sigm(zg);
+    const float c = f * cp + g * a;
+    if (q.pf) zo += c * wpo[j];
+    const float o = sigm(zo), ac = tanh_fast(c);
+    va[j] = a; vf[j] = f; vo[j] = o; vg[j] = g; vac[j] = ac;
+    cn[j] = c;
+    hn4[j] = o * ac;
+  }
+  const int64_t o_idx = (int64_t)t * hn + (int64_t)row * n + uq;
+  *(uint64_t*)(q.H + o_idx) = pack4(hn4[0], hn4[1], hn4[2], hn4[3]);
+  *(uint64_t*)(q.Cs + o_idx) = pack4(cn[0], cn[1], cn[2], cn[3]);
+  if (q.SV) {
+    bf16_t* sv = q.SV + ((int64_t)t * mb + row) * 6 * n + uq;
+    *(uint64_t*)(sv) = pack4(va[0], va[1], va[2], va[3]);
+    *(uint64_t*)(sv + n) = pack4(vf[0], vf[1], vf[2], vf[3]);
+    *(uint64_t*)(sv + 2 * (int64_t)n) = pack4(vo[0], vo[1], vo[2], vo[3]);
+    *(uint64_t*)(sv + 3 * (int64_t)n) = pack4(vg[0], vg[1], vg[2], vg[3]);
+    *(uint64_t*)(sv + 4 * (int64_t)n) = pack4(cn[0], cn[1], cn[2], cn[3]);
+    *(uint64_t*)(sv + 5 * (int64_t)n) = pack4(vac[0], vac[1], vac[2], vac[3]);
+  }
+}
+
+struct LstmDiagLayerB {
+  const bf16_t* E;         // [T, mb, n] dL/dh from outside the stack (top layer), or null
+  const bf16_t* rw4t;      // [n, ld_rwt]
+  int64_t ld_rwt;
+  const bf16_t* wct;       // input weights of the layer ABOVE [n, ld_wct] (row = this layer's unit), or null
+  int64_t ld_wct;
+  const bf16_t* dG_above;  // [T, mb, 4n] gate gradients of the layer above
+  const bf16_t* SV;
+  const bf16_t* Cs;
+  const bf16_t* c0;
+  const float* pf;
+  const float* po;
+  const float* pg;
+  bf16_t* dG;              // [T, mb, 4n]
+  float* dpeep;
+  float* dc_ws;            // [2, mb, n]
+};
+struct LstmDiagBwdP {
+  LstmDiagLayerB lay[DIAG_MAXL];
+  int nl, d, T, mb, n;
+};
+
+// One workgroup = 16 hidden units x 16 batch rows of one (layer, step) cell: ONE 16x16 MFMA tile whose K range (4n gate gradients of
+// the next step, then 4n of the layer above) is split over the 16 waves; the partial tiles meet in LDS and wave 0 runs the cell
+// backward. Sized by what bounds this kernel - operand bytes per CU (every byte comes from L2, a wave-load of 1 KB costs ~60 cycles of
+// L1 fill): the 8-unit x all-rows form of lstm_step_bwd_kernel moved 768 KB per workgroup, with half of every MFMA's rows duplicates,
+// and took 32 us per diagonal; this one moves 256 KB per workgroup over twice as many workgroups.
+__global__ void __launch_bounds__(STEP_THREADS) lstm_diag_bwd_kernel(LstmDiagBwdP p) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[15 * 64];
+  const int kk_l = blockIdx.z;                                          // 0 = top layer
+  const int li = p.nl - 1 - kk_l, t = p.T - 1 - (p.d - kk_l);
+  if (li < 0 || t < 0 || t >= p.T) return;
+  const LstmDiagLayerB& L = p.lay[li];
+  const int n = p.n, mb = p.mb, K = 4 * p.n;
+  const int64_t hn = (int64_t)mb * n;
+  const bf16_t* dG_next = t == p.T - 1 ? nullptr : L.dG + 4 * (t + 1) * hn;
+  const bf16_t* dG_up = L.dG_above ? L.dG_above + 4 * t * hn : nullptr;
+  const float* dc_in = t == p.T - 1 ? nullptr : L.dc_ws + (int64_t)((p.T - 2 - t) & 1) * hn;
+  float* dc_out = L.dc_ws + (int64_t)((p.T - 1 - t) & 1) * hn;
+  const bf16_t* cprev = t == 0 ? L.c0 : L.Cs + (t - 1) * hn;
+  const bf16_t* SVt = L.SV + 6 * t * hn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
+  const int bcol = lane & 15, q = lane >> 4;
+  const int row = r0 + bcol;
+  const bool row_ok = row < mb;
+  const int uq = u0 + q * 4;
+  const int Kw = K >> 4;                                                // K range of this wave (a multiple of 32: n % 128 == 0)
+  const bool any_k = dG_next != nullptr || dG_up != nullptr;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const bf16x8_t zero = {};
+  const int64_t koff = (int64_t)wave * Kw + q * 8;
+  // both segments' operands are requested before the first MFMA (Kw / 32 k-steps each: 4 at n = 512)
+  if (dG_next != nullptr) {
+    const bf16_t* ap = L.rw4t + (int64_t)(u0 + bcol) * L.ld_rwt + koff;
+    const bf16_t* bp = dG_next + (int64_t)(row_ok ? row : 0) * K + koff;
+    for (int k0 = 0; k0 < Kw; k0 += 32 * STEP_KSTEPS) {
+      bf16x8_t a[STEP_KSTEPS], b[STEP_KSTEPS];
+#pragma unroll
+      for (int i = 0; i < STEP_KSTEPS; ++i) {
+        const int k = k0 + 32 * i;
+        a[i] = k < Kw ? *(const bf16x8_t*)(ap + k) : zero;
+        b[i] = (k < Kw && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < STEP_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[i], acc, 0, 0, 0);
+    }
+  }
+  if (dG_up != nullptr) {
+    const bf16_t* ap = L.wct + (int64_t)(u0 + bcol) * L.ld_wct + koff;
+    const bf16_t* bp = dG_up + (int64_t)(row_ok ? row : 0) * K + koff;
+    for (int k0 = 0; k0 < Kw; k0 += 32 * STEP_KSTEPS) {
+      bf16x8_t a[STEP_KSTEPS], b[STEP_KSTEPS];
+#pragma unroll
+      for (int i = 0; i < STEP_KSTEPS; ++i) {
+        const int k = k0 + 32 * i;
+        a[i] = k < Kw ? *(const bf16x8_t*)(ap + k) : zero;
+        b[i] = (k < Kw && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < STEP_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[i], acc, 0, 0, 0);
+    }
+  }
+  // wave 0 owns the cell: its operands travel while the other waves hand their partial tiles over
+  uint64_t ev = 0, sva = 0, svf = 0, svo = 0, svg = 0, svc = 0, svac = 0, cpv = 0;
+  float dcn[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool cell_lane = wave == 0 && row_ok;
+  if (cell_lane) {
+    const int64_t hidx = (int64_t)row * n + uq;
+    if (L.E) ev = *(const uint64_t*)(L.E + t * hn + hidx);
+    const bf16_t* sv = SVt + (int64_t)row * 6 * n + uq;
+    sva = *(const uint64_t*)(sv); svf = *(const uint64_t*)(sv + n); svo = *(const uint64_t*)(sv + 2 * (int64_t)n);
+    svg = *(const uint64_t*)(sv + 3 * (int64_t)n); svc = *(const uint64_t*)(sv + 4 * (int64_t)n);
+    svac = *(const uint64_t*)(sv + 5 * (int64_t)n);
+    cpv = *(const uint64_t*)(cprev + hidx);
+    if (dc_in) {
+      const f32x4 d = *(const f32x4*)(dc_in + hidx);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dcn[j] = d[j];
+    }
+  }
+  if (any_k && wave > 0) red[(wave - 1) * 64 + lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  if (any_k) {
+#pragma unroll
+    for (int w = 0; w < 15; ++w) {
+      const f32x4 part = red[w * 64 + lane];
+      acc += part;
+    }
+  }
+  float apf[4] = {0, 0, 0, 0}, apo[4] = {0, 0, 0, 0}, apg[4] = {0, 0, 0, 0};
+  float wpf[4] = {0, 0, 0, 0}, wpo[4] = {0, 0, 0, 0}, wpg[4] = {0, 0, 0, 0};
+  if (L.pf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wpf[j] = L.pf[uq + j]; wpo[j] = L.po[uq + j]; wpg[j] = L.pg[uq + j]; }
+  }
+  if (row_ok) {
+    float e4[4], a4[4], f4[4], o4[4], g4[4], c4[4], ac4[4], cp4[4];
+    unpack4(ev, e4); unpack4(sva, a4); unpack4(svf, f4); unpack4(svo, o4); unpack4(svg, g4); unpack4(svc, c4);
+    unpack4(svac, ac4); unpack4(cpv, cp4);
+    float dza[4], dzf[4], dzo[4], dzg[4];
+    f32x4 dco;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d_h = e4[j] + acc[j];
+      const float d_cn = dcn[j];
+      const float a = a4[j], f = f4[j], o = o4[j], g = g4[j], ac = ac4[j], cp = cp4[j];
+      dzo[j] = d_h * ac * o * (1.f - o);
+      float dc = d_cn + d_h * o * (1.f - ac * ac);
+      if (L.pf) dc += dzo[j] * wpo[j];
+      dza[j] = dc * g * (1.f - a * a);
+      dzf[j] = dc * cp * f * (1.f - f);
+      dzg[j] = dc * a * g * (1.f - g);
+      float dcp = dc * f;
+      if (L.pf) {
+        dcp += dzf[j] * wpf[j] + dzg[j] * wpg[j];
+        apf[j] += dzf[j] * cp; apo[j] += dzo[j] * c4[j]; apg[j] += dzg[j] * cp;
+      }
+      dco[j] = dcp;
+    }
+    const int64_t hidx = (int64_t)row * n + uq;
+    *(f32x4*)(dc_out + hidx) = dco;
+    bf16_t* dg = L.dG + 4 * t * hn + (int64_t)row * K + uq;
+    *(uint64_t*)(dg) = pack4(dza[0], dza[1], dza[2], dza[3]);
+    *(uint64_t*)(dg + n) = pack4(dzf[0], dzf[1], dzf[2], dzf[3]);
+    *(uint64_t*)(dg + 2 * (int64_t)n) = pack4(dzo[0], dzo[1], dzo[2], dzo[3]);
+    *(uint64_t*)(dg + 3 * (int64_t)n) = pack4(dzg[0], dzg[1], dzg[2], dzg[3]);
+  }
+  if (L.pf && L.dpeep) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float vf = apf[j], vo = apo[j], vg = apg[j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { vf += __shfl_xor(vf, o, 64); vo += __shfl_xor(vo, o, 64); vg += __shfl_xor(vg, o, 64); }
+      if (bcol == 0) {
+        atomicAdd(L.dpeep + uq + j, vf);
+        atomicAdd(L.dpeep + n + uq + j, vo);
+        atomicAdd(L.dpeep + 2 * n + uq + j, vg);
+      }
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------------------ fp32 step kernels
 // The same one-launch-per-step decomposition for fp32 networks (the reference's default data type): v_mfma_f32_32x32x2_f32 forward,
 // v_mfma_f32_16x16x4_f32 backward. A 16-byte operand load holds 4 consecutive K values per lane and feeds 4 MFMAs; A and B use the same
@@ -1022,6 +1343,78 @@ DL4J_API int dl4j_lstm_steps_bwd(const void* E, const void* rw4t, int64_t ld_rwt
                                  const float* pf, const float* po, const float* pg, const float* maskT, void* dG, float* dpeep, unsigned* bar,
                                  float* dc_ws, const float* dc_last, int T, int mb, int n, int reverse, hipStream_t st) {
   return dl4j_lstm_steps_bwd_range(E, rw4t, ld_rwt, SV, Cs, c0, pf, po, pg, maskT, dG, dpeep, bar, dc_ws, dc_last, T, mb, n, reverse, 0, T, st);
+}
+
+// Diagonal passes over a stack of nl <= DIAG_MAXL layers with the same width n (see lstm_diag_fwd_kernel). Per-layer pointers come as
+// arrays of nl entries; xw[0] is the first layer's projection of the whole sequence, w2 / x2 / bias are used by layers 1.. (entry 0 is
+// ignored). nIn[l] = width of layer l's input. Every launch covers the cells of one anti-diagonal: T + nl - 1 launches.
+DL4J_API int dl4j_lstm_diag_supported(int mb, int n, int nl) {
+  return (nl >= 2 && nl <= DIAG_MAXL && n % 128 == 0 && n / 8 <= 256 && mb > 0 && mb <= 128) ? 1 : 0;    // n % 128: whole k-steps per wave
+}
+
+DL4J_API int dl4j_lstm_diag_fwd(const void* xw0, const void* const* rw4, const void* const* w2, const void* const* x2, const float* const* bias,
+                                const void* const* h0, const void* const* c0, const float* const* pf, const float* const* po,
+                                const float* const* pg, void* const* H, void* const* Cs, void* const* SV, const int* nIn, int nl, int T, int mb,
+                                int n, hipStream_t st) {
+  if (T <= 0) return 0;
+  if (!dl4j_lstm_diag_supported(mb, n, nl) || xw0 == nullptr || ((uintptr_t)xw0 & 7)) return -2;
+  LstmDiagFwdP p;
+  p.nl = nl; p.T = T; p.mb = mb; p.n = n; p.d = 0;
+  for (int l = 0; l < nl; ++l) {
+    LstmDiagLayerF& q = p.lay[l];
+    q.xw = l == 0 ? (const bf16_t*)xw0 : nullptr;
+    q.rw4 = (const bf16_t*)rw4[l]; q.ld_rw = n;
+    q.w2 = l == 0 ? nullptr : (const bf16_t*)w2[l]; q.ld_w2 = l == 0 ? 0 : nIn[l];
+    q.x2 = l == 0 ? nullptr : (const bf16_t*)x2[l];
+    q.bias = l == 0 ? nullptr : bias[l];
+    q.h0 = (const bf16_t*)h0[l]; q.c0 = (const bf16_t*)c0[l];
+    q.pf = pf ? pf[l] : nullptr; q.po = po ? po[l] : nullptr; q.pg = pg ? pg[l] : nullptr;
+    q.H = (bf16_t*)H[l]; q.Cs = (bf16_t*)Cs[l]; q.SV = SV ? (bf16_t*)SV[l] : nullptr;
+    q.nIn = l == 0 ? 0 : nIn[l];
+    if (((uintptr_t)q.rw4 & 15) || ((uintptr_t)q.h0 & 15) || ((uintptr_t)q.H & 15) || ((uintptr_t)q.c0 & 7) || ((uintptr_t)q.Cs & 7)) return -2;
+    if ((q.pf != nullptr) != (q.po != nullptr) || (q.pf != nullptr) != (q.pg != nullptr)) return -2;
+    if (l > 0 && (q.w2 == nullptr || q.x2 == nullptr || q.bias == nullptr || q.nIn % 64 != 0 || ((uintptr_t)q.w2 & 15) || ((uintptr_t)q.x2 & 15) ||
+                  ((uintptr_t)q.bias & 15)))
+      return -2;
+  }
+  for (int l = nl; l < DIAG_MAXL; ++l) p.lay[l] = p.lay[0];
+  for (int d = 0; d < T + nl - 1; ++d) {
+    p.d = d;
+    hipLaunchKernelGGL(lstm_diag_fwd_kernel, dim3(n / 8, nl), dim3(STEP_THREADS), 0, st, p);
+  }
+  DL4J_RET_LAST();
+}
+
+// E_top: [T, mb, n] gradient entering the top layer's activations. wct[l] = input weights of layer l + 1 as [n, 4n] rows (null for the top
+// layer); dc_ws[l]: [2, mb, n] fp32 scratch; dpeep[l]: [3, n] fp32 zeroed by the caller, or null.
+DL4J_API int dl4j_lstm_diag_bwd(const void* E_top, const void* const* rw4t, const void* const* wct, const void* const* SV, const void* const* Cs,
+                                const void* const* c0, const float* const* pf, const float* const* po, const float* const* pg,
+                                void* const* dG, float* const* dpeep, float* const* dc_ws, int nl, int T, int mb, int n, hipStream_t st) {
+  if (T <= 0) return 0;
+  if (!dl4j_lstm_diag_supported(mb, n, nl) || E_top == nullptr || ((uintptr_t)E_top & 7)) return -2;
+  LstmDiagBwdP p;
+  p.nl = nl; p.T = T; p.mb = mb; p.n = n; p.d = 0;
+  for (int l = 0; l < nl; ++l) {
+    LstmDiagLayerB& q = p.lay[l];
+    q.E = l == nl - 1 ? (const bf16_t*)E_top : nullptr;
+    q.rw4t = (const bf16_t*)rw4t[l]; q.ld_rwt = 4 * (int64_t)n;
+    q.wct = l == nl - 1 ? nullptr : (const bf16_t*)wct[l]; q.ld_wct = 4 * (int64_t)n;
+    q.dG_above = l == nl - 1 ? nullptr : (const bf16_t*)dG[l + 1];
+    q.SV = (const bf16_t*)SV[l]; q.Cs = (const bf16_t*)Cs[l]; q.c0 = (const bf16_t*)c0[l];
+    q.pf = pf ? pf[l] : nullptr; q.po = po ? po[l] : nullptr; q.pg = pg ? pg[l] : nullptr;
+    q.dG = (bf16_t*)dG[l]; q.dpeep = dpeep ? dpeep[l] : nullptr; q.dc_ws = dc_ws[l];
+    if (((uintptr_t)q.rw4t & 15) || ((uintptr_t)q.dG & 15) || ((uintptr_t)q.SV & 7) || ((uintptr_t)q.Cs & 7) || ((uintptr_t)q.c0 & 7) ||
+        q.dc_ws == nullptr || ((uintptr_t)q.dc_ws & 15))
+      return -2;
+    if (l < nl - 1 && (q.wct == nullptr || ((uintptr_t)q.wct & 15))) return -2;
+    if ((q.pf != nullptr) != (q.po != nullptr) || (q.pf != nullptr) != (q.pg != nullptr)) return -2;
+  }
+  for (int l = nl; l < DIAG_MAXL; ++l) p.lay[l] = p.lay[0];
+  for (int d = 0; d < T + nl - 1; ++d) {
+    p.d = d;
+    hipLaunchKernelGGL(lstm_diag_bwd_kernel, dim3(n / 16, (mb + 15) / 16, nl), dim3(STEP_THREADS), 0, st, p);
+  }
+  DL4J_RET_LAST();
 }
 
 // ---------------------------------------------------------------------------------------------------------------- fp32 entry points

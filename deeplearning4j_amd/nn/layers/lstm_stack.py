@@ -37,6 +37,7 @@ from ...nd4j.activations import ActivationSigmoid, ActivationTanH
 from ...ops import lstm as LSTMOP
 
 ENABLED = os.environ.get("DL4J_AMD_LSTM_STACK", "1") != "0"
+DIAG = os.environ.get("DL4J_AMD_LSTM_DIAG", "1") != "0"          # bf16 stacks of equal width: one launch per anti-diagonal (see _diag_ok)
 CHUNK = int(os.environ.get("DL4J_AMD_LSTM_STACK_CHUNK", "0"))     # 0: about a sixth of the sequence, at least 4 steps
 _TLS = threading.local()      # side streams and the event pool are per host thread (ParallelWrapper / ParallelInference workers share a device)
 
@@ -132,6 +133,22 @@ def _sp(stream):
     return L.c_void_p(stream.cuda_stream)
 
 
+def _parr(ts):
+    """C array of device pointers (null for None)."""
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def _diag_ok(lay, mb, bf16):
+    """One launch per anti-diagonal of the layer x time wavefront (native/csrc/lstm_persist.hip lstm_diag_*_kernel): bf16 stacks of
+    2-4 layers of the same width whose upper layers read an input that is a multiple of 64 wide."""
+    if not (DIAG and bf16 and 2 <= len(lay) <= 4):
+        return False
+    n = lay[0]["n"]
+    if any(d["n"] != n for d in lay) or any(d["nIn"] % 64 != 0 for d in lay[1:]):
+        return False
+    return bool(L.hip().dl4j_lstm_diag_supported(L.c_int(mb), L.c_int(n), L.c_int(len(lay))))
+
+
 def _gemm_nt_on(stream, x, w, y, bias):
     """y [M, N] = x [M, K] . w [N, K]^T (+ fp32 bias) with the in-tree MFMA GEMM on an explicit stream; nothing is allocated."""
     M, K = x.shape
@@ -181,6 +198,24 @@ def forward(layers, x, train, mode=None):
                  nIn=nIn if li == 0 else lay[li - 1]["n"])
         lay.append(d)
     torch.addmm(lay[0]["b"], xt, lay[0]["W"], out=lay[0]["xw"].view(T * mb, -1))
+    diag = _diag_ok(lay, mb, bf16)
+    if diag:
+        has_peep = lay[0]["pf"] is not None
+        if any((d["pf"] is not None) != has_peep for d in lay):
+            diag = False
+    if diag:
+        for d in lay[1:]:
+            d["Wnt_c"] = d["Wnt"] if d["Wnt"].is_contiguous() else d["Wnt"].contiguous()
+        nins = (ctypes.c_int * nl)(*[d["nIn"] for d in lay])
+        L.check(L.hip().dl4j_lstm_diag_fwd(
+            L.ptr(lay[0]["xw"]), _parr([d["RW4"] for d in lay]), _parr([None] + [d["Wnt_c"] for d in lay[1:]]),
+            _parr([None] + [lay[i - 1]["H"] for i in range(1, nl)]), _parr([None] + [d["bf"] for d in lay[1:]]),
+            _parr([d["h0"] for d in lay]), _parr([d["c0"] for d in lay]),
+            _parr([d["pf"] for d in lay]) if has_peep else None, _parr([d["po"] for d in lay]) if has_peep else None,
+            _parr([d["pg"] for d in lay]) if has_peep else None, _parr([d["H"] for d in lay]), _parr([d["Cs"] for d in lay]),
+            _parr([d["SV"] for d in lay]) if train else None, nins, L.c_int(nl), L.c_int(T), L.c_int(mb), L.c_int(lay[0]["n"]), _sp(cur)),
+            "lstm_diag_fwd")
+        return _finish_forward(lay, train, mode, mb, T)
     rec = [[None] * nc for _ in range(nl)]
     proj = [[None] * nc for _ in range(nl)]
     e0 = ev.record(cur)
@@ -225,6 +260,10 @@ def forward(layers, x, train, mode=None):
     finally:
         for st in S:
             cur.wait_stream(st)
+    return _finish_forward(lay, train, mode, mb, T)
+
+
+def _finish_forward(lay, train, mode, mb, T):
     for d in lay:
         l = d["l"]
         st = {"H": d["H"], "Cs": d["Cs"], "SV": d["SV"], "h0": d["h0"], "c0": d["c0"], "peep": (d["pf"], d["po"], d["pg"]), "maskT": None,
@@ -270,6 +309,19 @@ def backward(layers, eps):
                         dpeep=torch.zeros(3, n, device=dev, dtype=torch.float32) if pf is not None else None,
                         bar=torch.empty(2, device=dev, dtype=torch.int32),
                         E=eps.permute(2, 0, 1).to(cd).contiguous() if li == nl - 1 else torch.empty(T, mb, n, device=dev, dtype=cd)))
+    if _diag_ok(lay, mb, bf16) and len({d["pf"] is not None for d in lay}) == 1:
+        has_peep = lay[0]["pf"] is not None
+        for li in range(nl - 1):
+            up = lay[li + 1]
+            lay[li]["wct"] = up["Wc"] if up["Wc"] is not None else up["W"].contiguous()
+        L.check(L.hip().dl4j_lstm_diag_bwd(
+            L.ptr(lay[-1]["E"]), _parr([d["rw4t"] for d in lay]), _parr([lay[li].get("wct") for li in range(nl)]),
+            _parr([d["st"]["SV"] for d in lay]), _parr([d["st"]["Cs"] for d in lay]), _parr([d["st"]["c0"] for d in lay]),
+            _parr([d["pf"] for d in lay]) if has_peep else None, _parr([d["po"] for d in lay]) if has_peep else None,
+            _parr([d["pg"] for d in lay]) if has_peep else None, _parr([d["dG"] for d in lay]),
+            _parr([d["dpeep"] for d in lay]) if has_peep else None, _parr([d["dc"] for d in lay]), L.c_int(nl), L.c_int(T), L.c_int(mb),
+            L.c_int(lay[0]["n"]), _sp(cur)), "lstm_diag_bwd")
+        return _finish_backward(lay, nl)
     e0 = ev.record(cur)
     done = [[None] * nc for _ in range(nl)]        # dG of (layer, chunk) is complete
     ready = [[None] * nc for _ in range(nl)]       # E of (layer, chunk) is complete (library hand-off)
@@ -314,6 +366,10 @@ def backward(layers, eps):
     finally:
         for st in S:
             cur.wait_stream(st)
+    return _finish_backward(lay, nl)
+
+
+def _finish_backward(lay, nl):
     dx = None
     for li in range(nl - 1, -1, -1):
         d = lay[li]

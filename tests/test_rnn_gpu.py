@@ -413,6 +413,74 @@ def test_lstm_stack_pipeline_matches_layer_by_layer(monkeypatch, kind, dtype):
     assert (ga - gb).abs().max().item() < tol * max(1.0, ga.abs().max().item())
 
 
+def _equal_stack_net(kind, dtype, n=128, nIn=12, T=24, seed=5, tbptt=None):
+    from deeplearning4j_amd.nd4j.learning import Sgd
+    from deeplearning4j_amd.nn.conf.base import InputType, BackpropType
+    from deeplearning4j_amd.nn.conf.configuration import NeuralNetConfiguration
+    from deeplearning4j_amd.nn.conf.layers import LSTM, GravesLSTM, RnnOutputLayer
+    from deeplearning4j_amd.nn.multilayer import MultiLayerNetwork
+    b = NeuralNetConfiguration.Builder().seed(seed).updater(Sgd(0.05)).weightInit("XAVIER")
+    if dtype:
+        b = b.computeDataType(dtype)
+    Lc = {"lstm": LSTM, "graves": GravesLSTM}[kind]
+    lb = b.list().layer(Lc(nIn=nIn, nOut=n, activation="TANH")).layer(Lc(nIn=n, nOut=n, activation="TANH")).layer(Lc(nIn=n, nOut=n, activation="TANH"))
+    lb = lb.layer(RnnOutputLayer(nIn=n, nOut=5, activation="SOFTMAX", lossFunction="MCXENT"))
+    if tbptt:
+        lb = lb.backpropType(BackpropType.TruncatedBPTT).tBPTTForwardLength(tbptt).tBPTTBackwardLength(tbptt)
+    return MultiLayerNetwork(lb.setInputType(InputType.recurrent(nIn, T)).build(), device="cuda").init()
+
+
+@pytest.mark.parametrize("kind", ["lstm", "graves"])
+@pytest.mark.parametrize("mb,T", [(8, 24), (40, 11)])
+def test_lstm_stack_diagonal_launches_match_chunk_pipeline_and_fp32(monkeypatch, kind, mb, T):
+    """bf16 stacks of equal width run one launch per anti-diagonal of the layer x time wavefront, the upper layers' input projection
+    folded into the step as a second K segment (lstm_diag_fwd_kernel / lstm_diag_bwd_kernel). Against the chunked multi-stream pipeline
+    (same bf16 math, projections rounded to bf16 once more) and against the fp32 layer-by-layer schedule."""
+    from deeplearning4j_amd.nn.layers import lstm_stack
+    used = {"n": 0}
+    inner = lstm_stack._diag_ok
+    monkeypatch.setattr(lstm_stack, "_diag_ok", lambda *a, **k: (lambda r: (used.__setitem__("n", used["n"] + int(r)), r)[1])(inner(*a, **k)))
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(mb, 12, T, generator=g).cuda()
+    y = torch.nn.functional.one_hot(torch.randint(0, 5, (mb, T), generator=g), 5).permute(0, 2, 1).float().cuda()
+    res = {}
+    for name, dtype, diag in (("diag", "BFLOAT16", True), ("chunks", "BFLOAT16", False), ("fp32", None, False)):
+        monkeypatch.setattr(lstm_stack, "DIAG", diag)
+        monkeypatch.setattr(lstm_stack, "ENABLED", name != "fp32")
+        net = _equal_stack_net(kind, dtype, T=T)
+        out = net.output(x).float()
+        net.computeGradientAndScore(x, y)
+        torch.cuda.synchronize()
+        res[name] = (out, float(net._score), net._grads.float().clone())
+    assert used["n"] == 3, used                      # inference forward, training forward, backward
+    for ref, tol, cos in (("chunks", 1e-2, 0.9995), ("fp32", 3e-2, 0.999)):
+        assert (res["diag"][0] - res[ref][0]).abs().max().item() < tol
+        assert abs(res["diag"][1] - res[ref][1]) < tol * max(1.0, abs(res[ref][1]))
+        ga, gb = res[ref][2].double(), res["diag"][2].double()
+        assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > cos
+        assert (ga - gb).abs().max().item() < tol * max(1.0, ga.abs().max().item())
+
+
+def test_lstm_stack_diagonal_tbptt_fit_under_graph_capture(monkeypatch):
+    """Truncated BPTT with the diagonal launches captured in a hipGraph: state carried between segments and parameters after three
+    fits equal the eager run bit for bit."""
+    from deeplearning4j_amd.nn.layers import lstm_stack
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(8, 12, 48, generator=g).cuda()
+    y = torch.nn.functional.one_hot(torch.randint(0, 5, (8, 48), generator=g), 5).permute(0, 2, 1).float().cuda()
+    res = {}
+    for capture in (False, True):
+        net = _equal_stack_net("graves", "BFLOAT16", T=48, tbptt=16)
+        if capture:
+            net.enableGraphCapture(True)
+        for _ in range(3):
+            net.fit(x, y)
+        torch.cuda.synchronize()
+        res[capture] = (net.params().clone(), float(net.score()))
+    assert torch.isfinite(res[True][0]).all()
+    assert torch.equal(res[True][0], res[False][0])
+
+
 @pytest.mark.parametrize("capture", [False, True])
 def test_lstm_stack_pipeline_tbptt_fit(monkeypatch, capture):
     """Truncated BPTT over the pipelined stack: the state carried between segments and the parameters after two fits match the
