@@ -679,9 +679,17 @@ struct LstmDiagFwdP {
   int nl, d, T, mb, n;
 };
 
-__global__ void __launch_bounds__(STEP_THREADS) lstm_diag_fwd_kernel(LstmDiagFwdP p) {
-  __shared__ __attribute__((aligned(16))) f32x16 red[3 * 4 * 64];
-  const int li = blockIdx.y, t = p.d - li;
+// One workgroup = 8 hidden units (32 gate columns) x 32 batch rows of one (layer, step) cell: one 32x32 MFMA tile whose K range (h[t-1],
+// then the layer below's h[t]) is split over the DIAG_WAVES waves in 16-wide k-steps; the partial tiles meet in LDS and wave 0 runs the cell.
+// (The 4 batch tiles x 4 K quarters form of lstm_step_fwd_kernel leaves half of its waves idle at mb = 64 and moves twice the bytes
+// per workgroup; this kernel is bound by operand bytes per CU like the backward one.)
+#define DIAG_WAVES 8         // waves per workgroup = K slices (char-RNN fit: 16 waves 7.64 ms, 8 waves 7.22, 4 waves 7.25)
+#define DIAG_LOG2W 3
+#define DIAG_THREADS (64 * DIAG_WAVES)
+#define DIAG_FK 4            // k-steps per wave held in registers at once (n <= 512 in one pass)
+__global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwdP p) {
+  __shared__ __attribute__((aligned(16))) f32x16 red[(DIAG_WAVES - 1) * 64];
+  const int li = blockIdx.z, t = p.d - li;
   if (li >= p.nl || t < 0 || t >= p.T) return;                          // uniform per workgroup
   const LstmDiagLayerF& q = p.lay[li];
   const int n = p.n, mb = p.mb;
@@ -689,14 +697,51 @@ __global__ void __launch_bounds__(STEP_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
   const bf16_t* hprev = t == 0 ? q.h0 : q.H + (t - 1) * hn;
   const bf16_t* cprev = t == 0 ? q.c0 : q.Cs + (t - 1) * hn;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = wave & 3, kp = wave >> 2;
   const int u0 = blockIdx.x * 8;
-  const int row = tile * 32 + (lane & 31);
+  const int row = blockIdx.y * 32 + (lane & 31);
   const int kq = lane >> 5;
   const int uq = u0 + kq * 4;
-  const bool tile_on = tile * 32 < mb;
   const bool row_ok = row < mb;
-  const bool cell_lane = tile_on && row_ok && kp == 0;
+  const bool cell_lane = wave == 0 && row_ok;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int gc = lane & 31;
+  const bf16x8_t zero = {};
+  const int64_t wrow = (int64_t)(gc >> 3) * n + u0 + (gc & 7);
+  {
+    const int S = n >> 4, s0 = (wave * S) >> DIAG_LOG2W, s1 = ((wave + 1) * S) >> DIAG_LOG2W;       // this wave's 16-wide k-steps of segment 1
+    const bf16_t* ap = q.rw4 + wrow * q.ld_rw + kq * 8;
+    const bf16_t* bp = hprev + (int64_t)(row_ok ? row : 0) * n + kq * 8;
+    for (int sb = s0; sb < s1; sb += DIAG_FK) {
+      bf16x8_t a[DIAG_FK], b[DIAG_FK];
+#pragma unroll
+      for (int i = 0; i < DIAG_FK; ++i) {
+        const int k = (sb + i) << 4;
+        a[i] = sb + i < s1 ? *(const bf16x8_t*)(ap + k) : zero;
+        b[i] = (sb + i < s1 && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < DIAG_FK; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+    }
+  }
+  if (q.xw == nullptr) {
+    const int S = q.nIn >> 4, s0 = (wave * S) >> DIAG_LOG2W, s1 = ((wave + 1) * S) >> DIAG_LOG2W;
+    const bf16_t* ap = q.w2 + wrow * q.ld_w2 + kq * 8;
+    const bf16_t* bp = q.x2 + ((int64_t)t * mb + (row_ok ? row : 0)) * q.nIn + kq * 8;
+    for (int sb = s0; sb < s1; sb += DIAG_FK) {
+      bf16x8_t a[DIAG_FK], b[DIAG_FK];
+#pragma unroll
+      for (int i = 0; i < DIAG_FK; ++i) {
+        const int k = (sb + i) << 4;
+        a[i] = sb + i < s1 ? *(const bf16x8_t*)(ap + k) : zero;
+        b[i] = (sb + i < s1 && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < DIAG_FK; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+    }
+  }
+  // wave 0 owns the cell: its operands travel while the other waves hand their partial tiles over
   uint64_t xwv[4] = {0, 0, 0, 0}, cpv = 0;
   float bv[4][4];
 #pragma unroll
@@ -718,52 +763,12 @@ __global__ void __launch_bounds__(STEP_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
     }
     cpv = *(const uint64_t*)(cprev + (int64_t)row * n + uq);
   }
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  if (tile_on) {
-    const int gc = lane & 31;
-    const bf16x8_t zero = {};
-    const int64_t wrow = (int64_t)(gc >> 3) * n + u0 + (gc & 7);
-    {
-      const int Kq = n >> 2;
-      const bf16_t* ap = q.rw4 + wrow * q.ld_rw + kp * Kq + kq * 8;
-      const bf16_t* bp = hprev + (int64_t)(row_ok ? row : 0) * n + kp * Kq + kq * 8;
-      for (int k0 = 0; k0 < Kq; k0 += 16 * STEP_KSTEPS) {
-        bf16x8_t a[STEP_KSTEPS], b[STEP_KSTEPS];
-#pragma unroll
-        for (int i = 0; i < STEP_KSTEPS; ++i) {
-          const int k = k0 + 16 * i;
-          a[i] = k < Kq ? *(const bf16x8_t*)(ap + k) : zero;
-          b[i] = (k < Kq && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
-        }
-#pragma unroll
-        for (int i = 0; i < STEP_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
-      }
-    }
-    if (q.xw == nullptr) {
-      const int Kq = q.nIn >> 2;
-      const bf16_t* ap = q.w2 + wrow * q.ld_w2 + kp * Kq + kq * 8;
-      const bf16_t* bp = q.x2 + ((int64_t)t * mb + (row_ok ? row : 0)) * q.nIn + kp * Kq + kq * 8;
-      for (int k0 = 0; k0 < Kq; k0 += 16 * STEP_KSTEPS) {
-        bf16x8_t a[STEP_KSTEPS], b[STEP_KSTEPS];
-#pragma unroll
-        for (int i = 0; i < STEP_KSTEPS; ++i) {
-          const int k = k0 + 16 * i;
-          a[i] = k < Kq ? *(const bf16x8_t*)(ap + k) : zero;
-          b[i] = (k < Kq && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
-        }
-#pragma unroll
-        for (int i = 0; i < STEP_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
-      }
-    }
-    if (kp > 0) red[((kp - 1) * 4 + tile) * 64 + lane] = acc;
-  }
+  if (wave > 0) red[(wave - 1) * 64 + lane] = acc;
   __syncthreads();
   if (!cell_lane) return;
-#pragma unroll
-  for (int kk = 0; kk < 3; ++kk) {
-    const f32x16 part = red[(kk * 4 + tile) * 64 + lane];
+#pragma unroll 3        // (fully unrolled the 15 partial tiles are all read ahead: 240 registers, scratch spills)
+  for (int w = 0; w < DIAG_WAVES - 1; ++w) {
+    const f32x16 part = red[w * 64 + lane];
     acc += part;
   }
   float c_state[4];
@@ -827,12 +832,12 @@ struct LstmDiagBwdP {
 };
 
 // One workgroup = 16 hidden units x 16 batch rows of one (layer, step) cell: ONE 16x16 MFMA tile whose K range (4n gate gradients of
-// the next step, then 4n of the layer above) is split over the 16 waves; the partial tiles meet in LDS and wave 0 runs the cell
+// the next step, then 4n of the layer above) is split over the DIAG_WAVES waves; the partial tiles meet in LDS and wave 0 runs the cell
 // backward. Sized by what bounds this kernel - operand bytes per CU (every byte comes from L2, a wave-load of 1 KB costs ~60 cycles of
 // L1 fill): the 8-unit x all-rows form of lstm_step_bwd_kernel moved 768 KB per workgroup, with half of every MFMA's rows duplicates,
 // and took 32 us per diagonal; this one moves 256 KB per workgroup over twice as many workgroups.
-__global__ void __launch_bounds__(STEP_THREADS) lstm_diag_bwd_kernel(LstmDiagBwdP p) {
-  __shared__ __attribute__((aligned(16))) f32x4 red[15 * 64];
+__global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwdP p) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[(DIAG_WAVES - 1) * 64];
   const int kk_l = blockIdx.z;                                          // 0 = top layer
   const int li = p.nl - 1 - kk_l, t = p.T - 1 - (p.d - kk_l);
   if (li < 0 || t < 0 || t >= p.T) return;
@@ -851,7 +856,7 @@ __global__ void __launch_bounds__(STEP_THREADS) lstm_diag_bwd_kernel(LstmDiagBwd
   const int row = r0 + bcol;
   const bool row_ok = row < mb;
   const int uq = u0 + q * 4;
-  const int Kw = K >> 4;                                                // K range of this wave (a multiple of 32: n % 128 == 0)
+  const int Kw = K >> DIAG_LOG2W;                                                // K range of this wave (a multiple of 32: n % 128 == 0)
   const bool any_k = dG_next != nullptr || dG_up != nullptr;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const bf16x8_t zero = {};
@@ -910,7 +915,7 @@ __global__ void __launch_bounds__(STEP_THREADS) lstm_diag_bwd_kernel(LstmDiagBwd
   if (wave != 0) return;
   if (any_k) {
 #pragma unroll
-    for (int w = 0; w < 15; ++w) {
+    for (int w = 0; w < DIAG_WAVES - 1; ++w) {
       const f32x4 part = red[w * 64 + lane];
       acc += part;
     }
@@ -1380,7 +1385,7 @@ DL4J_API int dl4j_lstm_diag_fwd(const void* xw0, const void* const* rw4, const v
   for (int l = nl; l < DIAG_MAXL; ++l) p.lay[l] = p.lay[0];
   for (int d = 0; d < T + nl - 1; ++d) {
     p.d = d;
-    hipLaunchKernelGGL(lstm_diag_fwd_kernel, dim3(n / 8, nl), dim3(STEP_THREADS), 0, st, p);
+    hipLaunchKernelGGL(lstm_diag_fwd_kernel, dim3(n / 8, (mb + 31) / 32, nl), dim3(DIAG_THREADS), 0, st, p);
   }
   DL4J_RET_LAST();
 }
@@ -1412,7 +1417,7 @@ DL4J_API int dl4j_lstm_diag_bwd(const void* E_top, const void* const* rw4t, cons
   for (int l = nl; l < DIAG_MAXL; ++l) p.lay[l] = p.lay[0];
   for (int d = 0; d < T + nl - 1; ++d) {
     p.d = d;
-    hipLaunchKernelGGL(lstm_diag_bwd_kernel, dim3(n / 16, (mb + 15) / 16, nl), dim3(STEP_THREADS), 0, st, p);
+    hipLaunchKernelGGL(lstm_diag_bwd_kernel, dim3(n / 16, (mb + 15) / 16, nl), dim3(DIAG_THREADS), 0, st, p);
   }
   DL4J_RET_LAST();
 }

@@ -148,11 +148,32 @@ class LSTMImpl(LayerImpl):
         W = self._p("W")
         dG2 = dG.view(T * mb, 4 * n)
         gW, gRW, gb = self.grads["W" + k], self.grads["RW" + k], self.grads["b" + k]
-        gW.copy_(torch.matmul(self._xt.t(), dG2))
-        gRW[:, :4 * n].copy_(torch.matmul(Hprev.view(T * mb, n).t(), dG2))
+        # 16-bit GPU layers: the in-tree split-K weight-gradient kernel writes fp32 straight into the gradient views (no library GEMM, no
+        # conversion pass) and the first launch also accumulates the bias gradient (column sums of dG) from the tiles it loads anyway
+        from ...ops import dense as DENSE
+        db_done = False
+
+        def own(x2, g):
+            nonlocal db_done
+            gt = g.t()
+            if not (dG2.is_cuda and dG2.dtype in (torch.bfloat16, torch.float16) and x2.dtype == dG2.dtype and DENSE.dw_ok(dG2, x2, gt)):
+                return False
+            take_db = (not db_done and gb.dtype == torch.float32 and gb.is_contiguous() and DENSE.dw_takes_db(dG2, x2))
+            if take_db:
+                gb.zero_()
+            DENSE.dw(dG2, x2, gt, False, db_out=gb.view(-1) if take_db else None)
+            db_done = db_done or take_db
+            return True
+        xt = self._xt if self._xt.is_contiguous() else None
+        if xt is None or not own(xt, gW):
+            gW.copy_(torch.matmul(self._xt.t(), dG2))
+        hp2 = Hprev.view(T * mb, n)
+        if dpeep is not None or not own(hp2, gRW):
+            gRW[:, :4 * n].copy_(torch.matmul(hp2.t(), dG2))
         if dpeep is not None:
             gRW[:, 4 * n].copy_(dpeep[0]); gRW[:, 4 * n + 1].copy_(dpeep[1]); gRW[:, 4 * n + 2].copy_(dpeep[2])
-        gb.copy_(dG2.sum(0, dtype=torch.float32).reshape(1, -1))
+        if not db_done:
+            gb.copy_(dG2.sum(0, dtype=torch.float32).reshape(1, -1))
         self._saved = None
         if not want_dx or not getattr(self, "needs_input_grad", True):
             return None
