@@ -656,27 +656,59 @@ __global__ void __launch_bounds__(STEP_THREADS) lstm_step_bwd_kernel(LstmBwdP p)
 // projection does not depend on the recurrence and stays one GEMM over the whole sequence). Backward mirrors it:
 // dL/dh(l, t) = E_ext + dG(l, t+1) . RW^T + dG(l+1, t) . W(l+1)^T, diagonals processed from (L-1, T-1) down.
 #define DIAG_MAXL 4
+template <typename T>
 struct LstmDiagLayerF {
-  const bf16_t* xw;        // [T, mb, 4n] projection + bias of the whole sequence (first layer), or null
-  const bf16_t* rw4;       // [4n, ld_rw]
+  const T* xw;        // [T, mb, 4n] projection + bias of the whole sequence (first layer), or null
+  const T* rw4;       // [4n, ld_rw]
   int64_t ld_rw;
-  const bf16_t* w2;        // [4n, ld_w2] input weights, row = gate column (layers without xw)
+  const T* w2;        // [4n, ld_w2] input weights, row = gate column (layers without xw)
   int64_t ld_w2;
-  const bf16_t* x2;        // [T, mb, nIn] activations of the layer below
+  const T* x2;        // [T, mb, nIn] activations of the layer below
   const float* bias;       // [4n]
-  const bf16_t* h0;
-  const bf16_t* c0;
+  const T* h0;
+  const T* c0;
   const float* pf;
   const float* po;
   const float* pg;
-  bf16_t* H;
-  bf16_t* Cs;
-  bf16_t* SV;
+  T* H;
+  T* Cs;
+  T* SV;
   int nIn;
 };
+template <typename E>
 struct LstmDiagFwdP {
-  LstmDiagLayerF lay[DIAG_MAXL];
+  LstmDiagLayerF<E> lay[DIAG_MAXL];
   int nl, d, T, mb, n;
+};
+
+// element-type traits of the diagonal kernels: bf16 (MFMA 32x32x16 / 16x16x32, 16-byte loads = 8 K values per lane) and fp32 (MFMA
+// 32x32x2 / 16x16x4: a 16-byte load holds 4 K values per lane and feeds 4 MFMAs; A and B use the same permuted K order)
+struct DiagBf16 {
+  typedef bf16_t T;
+  typedef bf16x8_t vec;
+  static constexpr int FSTEP = 16, FLANE = 8, BSTEP = 32, BLANE = 8, FK = 4, BK = STEP_KSTEPS;
+  static __device__ __forceinline__ void mfma_f(f32x16& acc, const vec& a, const vec& b) { acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0); }
+  static __device__ __forceinline__ void mfma_b(f32x4& acc, const vec& a, const vec& b) { acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0); }
+  static __device__ __forceinline__ void ld4(const T* p, float o[4]) { unpack4(*(const uint64_t*)p, o); }
+  static __device__ __forceinline__ void st4(T* p, float a, float b, float c, float d) { *(uint64_t*)p = pack4(a, b, c, d); }
+};
+struct DiagF32 {
+  typedef float T;
+  typedef f32x4 vec;
+  static constexpr int FSTEP = 8, FLANE = 4, BSTEP = 16, BLANE = 4, FK = 8, BK = STEP_KSTEPS;
+  static __device__ __forceinline__ void mfma_f(f32x16& acc, const vec& a, const vec& b) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], b[c], acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void mfma_b(f32x4& acc, const vec& a, const vec& b) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void ld4(const T* p, float o[4]) {
+    const f32x4 v = *(const f32x4*)p;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+  static __device__ __forceinline__ void st4(T* p, float a, float b, float c, float d) { *(f32x4*)p = f32x4{a, b, c, d}; }
 };
 
 // One workgroup = 8 hidden units (32 gate columns) x 32 batch rows of one (layer, step) cell: one 32x32 MFMA tile whose K range (h[t-1],
@@ -687,15 +719,18 @@ struct LstmDiagFwdP {
 #define DIAG_LOG2W 3
 #define DIAG_THREADS (64 * DIAG_WAVES)
 #define DIAG_FK 4            // k-steps per wave held in registers at once (n <= 512 in one pass)
-__global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwdP p) {
+template <typename TR>
+__global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwdP<typename TR::T> p) {
+  typedef typename TR::T T;
+  typedef typename TR::vec vec;
   __shared__ __attribute__((aligned(16))) f32x16 red[(DIAG_WAVES - 1) * 64];
   const int li = blockIdx.z, t = p.d - li;
   if (li >= p.nl || t < 0 || t >= p.T) return;                          // uniform per workgroup
-  const LstmDiagLayerF& q = p.lay[li];
+  const LstmDiagLayerF<T>& q = p.lay[li];
   const int n = p.n, mb = p.mb;
   const int64_t hn = (int64_t)mb * n;
-  const bf16_t* hprev = t == 0 ? q.h0 : q.H + (t - 1) * hn;
-  const bf16_t* cprev = t == 0 ? q.c0 : q.Cs + (t - 1) * hn;
+  const T* hprev = t == 0 ? q.h0 : q.H + (t - 1) * hn;
+  const T* cprev = t == 0 ? q.c0 : q.Cs + (t - 1) * hn;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * 8;
   const int row = blockIdx.y * 32 + (lane & 31);
@@ -707,61 +742,60 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const int gc = lane & 31;
-  const bf16x8_t zero = {};
+  const vec zero = {};
   const int64_t wrow = (int64_t)(gc >> 3) * n + u0 + (gc & 7);
   {
-    const int S = n >> 4, s0 = (wave * S) >> DIAG_LOG2W, s1 = ((wave + 1) * S) >> DIAG_LOG2W;       // this wave's 16-wide k-steps of segment 1
-    const bf16_t* ap = q.rw4 + wrow * q.ld_rw + kq * 8;
-    const bf16_t* bp = hprev + (int64_t)(row_ok ? row : 0) * n + kq * 8;
-    for (int sb = s0; sb < s1; sb += DIAG_FK) {
-      bf16x8_t a[DIAG_FK], b[DIAG_FK];
+    const int S = n / TR::FSTEP, s0 = (wave * S) >> DIAG_LOG2W, s1 = ((wave + 1) * S) >> DIAG_LOG2W;       // this wave's 16-wide k-steps of segment 1
+    const T* ap = q.rw4 + wrow * q.ld_rw + kq * TR::FLANE;
+    const T* bp = hprev + (int64_t)(row_ok ? row : 0) * n + kq * TR::FLANE;
+    for (int sb = s0; sb < s1; sb += TR::FK) {
+      vec a[TR::FK], b[TR::FK];
 #pragma unroll
-      for (int i = 0; i < DIAG_FK; ++i) {
-        const int k = (sb + i) << 4;
-        a[i] = sb + i < s1 ? *(const bf16x8_t*)(ap + k) : zero;
-        b[i] = (sb + i < s1 && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      for (int i = 0; i < TR::FK; ++i) {
+        const int k = (sb + i) * TR::FSTEP;
+        a[i] = sb + i < s1 ? *(const vec*)(ap + k) : zero;
+        b[i] = (sb + i < s1 && row_ok) ? *(const vec*)(bp + k) : zero;
       }
 #pragma unroll
-      for (int i = 0; i < DIAG_FK; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+      for (int i = 0; i < TR::FK; ++i) TR::mfma_f(acc, a[i], b[i]);
     }
   }
   if (q.xw == nullptr) {
-    const int S = q.nIn >> 4, s0 = (wave * S) >> DIAG_LOG2W, s1 = ((wave + 1) * S) >> DIAG_LOG2W;
-    const bf16_t* ap = q.w2 + wrow * q.ld_w2 + kq * 8;
-    const bf16_t* bp = q.x2 + ((int64_t)t * mb + (row_ok ? row : 0)) * q.nIn + kq * 8;
-    for (int sb = s0; sb < s1; sb += DIAG_FK) {
-      bf16x8_t a[DIAG_FK], b[DIAG_FK];
+    const int S = q.nIn / TR::FSTEP, s0 = (wave * S) >> DIAG_LOG2W, s1 = ((wave + 1) * S) >> DIAG_LOG2W;
+    const T* ap = q.w2 + wrow * q.ld_w2 + kq * TR::FLANE;
+    const T* bp = q.x2 + ((int64_t)t * mb + (row_ok ? row : 0)) * q.nIn + kq * TR::FLANE;
+    for (int sb = s0; sb < s1; sb += TR::FK) {
+      vec a[TR::FK], b[TR::FK];
 #pragma unroll
-      for (int i = 0; i < DIAG_FK; ++i) {
-        const int k = (sb + i) << 4;
-        a[i] = sb + i < s1 ? *(const bf16x8_t*)(ap + k) : zero;
-        b[i] = (sb + i < s1 && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      for (int i = 0; i < TR::FK; ++i) {
+        const int k = (sb + i) * TR::FSTEP;
+        a[i] = sb + i < s1 ? *(const vec*)(ap + k) : zero;
+        b[i] = (sb + i < s1 && row_ok) ? *(const vec*)(bp + k) : zero;
       }
 #pragma unroll
-      for (int i = 0; i < DIAG_FK; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+      for (int i = 0; i < TR::FK; ++i) TR::mfma_f(acc, a[i], b[i]);
     }
   }
   // wave 0 owns the cell: its operands travel while the other waves hand their partial tiles over
-  uint64_t xwv[4] = {0, 0, 0, 0}, cpv = 0;
-  float bv[4][4];
+  float xg4[4][4], c_state[4] = {0.f, 0.f, 0.f, 0.f};         // gate pre-activations from outside the K loop: xw (first layer) or the bias
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bv[g][j] = 0.f;
+    for (int j = 0; j < 4; ++j) xg4[g][j] = 0.f;
   if (cell_lane) {
     if (q.xw != nullptr) {
-      const bf16_t* xr = q.xw + ((int64_t)t * mb + row) * 4 * n + uq;
+      const T* xr = q.xw + ((int64_t)t * mb + row) * 4 * n + uq;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) xwv[g] = *(const uint64_t*)(xr + (int64_t)g * n);
+      for (int g = 0; g < 4; ++g) TR::ld4(xr + (int64_t)g * n, xg4[g]);
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 b4 = *(const f32x4*)(q.bias + (int64_t)g * n + uq);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[g][j] = b4[j];
+        for (int j = 0; j < 4; ++j) xg4[g][j] = b4[j];
       }
     }
-    cpv = *(const uint64_t*)(cprev + (int64_t)row * n + uq);
+    TR::ld4(cprev + (int64_t)row * n + uq, c_state);
   }
   if (wave > 0) red[(wave - 1) * 64 + lane] = acc;
   __syncthreads();
@@ -771,21 +805,17 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
     const f32x16 part = red[w * 64 + lane];
     acc += part;
   }
-  float c_state[4];
-  unpack4(cpv, c_state);
   float wpf[4] = {0, 0, 0, 0}, wpo[4] = {0, 0, 0, 0}, wpg[4] = {0, 0, 0, 0};
   if (q.pf) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { wpf[j] = q.pf[uq + j]; wpo[j] = q.po[uq + j]; wpg[j] = q.pg[uq + j]; }
   }
-  float xa[4], xf[4], xo[4], xg[4];
-  unpack4(xwv[0], xa); unpack4(xwv[1], xf); unpack4(xwv[2], xo); unpack4(xwv[3], xg);
   float hn4[4], cn[4], va[4], vf[4], vo[4], vg[4], vac[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float cp = c_state[j];
-    const float za = acc[j] + xa[j] + bv[0][j];
-    float zf = acc[4 + j] + xf[j] + bv[1][j], zo = acc[8 + j] + xo[j] + bv[2][j], zg = acc[12 + j] + xg[j] + bv[3][j];
+    const float za = acc[j] + xg4[0][j];
+    float zf = acc[4 + j] + xg4[1][j], zo = acc[8 + j] + xg4[2][j], zg = acc[12 + j] + xg4[3][j];
     if (q.pf) { zf += cp * wpf[j]; zg += cp * wpg[j]; }
     const float a = tanh_fast(za), f = sigm(zf), g = sigm(zg);
     const float c = f * cp + g * a;
@@ -796,38 +826,40 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
     hn4[j] = o * ac;
   }
   const int64_t o_idx = (int64_t)t * hn + (int64_t)row * n + uq;
-  *(uint64_t*)(q.H + o_idx) = pack4(hn4[0], hn4[1], hn4[2], hn4[3]);
-  *(uint64_t*)(q.Cs + o_idx) = pack4(cn[0], cn[1], cn[2], cn[3]);
+  TR::st4(q.H + o_idx, hn4[0], hn4[1], hn4[2], hn4[3]);
+  TR::st4(q.Cs + o_idx, cn[0], cn[1], cn[2], cn[3]);
   if (q.SV) {
-    bf16_t* sv = q.SV + ((int64_t)t * mb + row) * 6 * n + uq;
-    *(uint64_t*)(sv) = pack4(va[0], va[1], va[2], va[3]);
-    *(uint64_t*)(sv + n) = pack4(vf[0], vf[1], vf[2], vf[3]);
-    *(uint64_t*)(sv + 2 * (int64_t)n) = pack4(vo[0], vo[1], vo[2], vo[3]);
-    *(uint64_t*)(sv + 3 * (int64_t)n) = pack4(vg[0], vg[1], vg[2], vg[3]);
-    *(uint64_t*)(sv + 4 * (int64_t)n) = pack4(cn[0], cn[1], cn[2], cn[3]);
-    *(uint64_t*)(sv + 5 * (int64_t)n) = pack4(vac[0], vac[1], vac[2], vac[3]);
+    T* sv = q.SV + ((int64_t)t * mb + row) * 6 * n + uq;
+    TR::st4(sv, va[0], va[1], va[2], va[3]);
+    TR::st4(sv + n, vf[0], vf[1], vf[2], vf[3]);
+    TR::st4(sv + 2 * (int64_t)n, vo[0], vo[1], vo[2], vo[3]);
+    TR::st4(sv + 3 * (int64_t)n, vg[0], vg[1], vg[2], vg[3]);
+    TR::st4(sv + 4 * (int64_t)n, cn[0], cn[1], cn[2], cn[3]);
+    TR::st4(sv + 5 * (int64_t)n, vac[0], vac[1], vac[2], vac[3]);
   }
 }
 
+template <typename T>
 struct LstmDiagLayerB {
-  const bf16_t* E;         // [T, mb, n] dL/dh from outside the stack (top layer), or null
-  const bf16_t* rw4t;      // [n, ld_rwt]
+  const T* E;         // [T, mb, n] dL/dh from outside the stack (top layer), or null
+  const T* rw4t;      // [n, ld_rwt]
   int64_t ld_rwt;
-  const bf16_t* wct;       // input weights of the layer ABOVE [n, ld_wct] (row = this layer's unit), or null
+  const T* wct;       // input weights of the layer ABOVE [n, ld_wct] (row = this layer's unit), or null
   int64_t ld_wct;
-  const bf16_t* dG_above;  // [T, mb, 4n] gate gradients of the layer above
-  const bf16_t* SV;
-  const bf16_t* Cs;
-  const bf16_t* c0;
+  const T* dG_above;  // [T, mb, 4n] gate gradients of the layer above
+  const T* SV;
+  const T* Cs;
+  const T* c0;
   const float* pf;
   const float* po;
   const float* pg;
-  bf16_t* dG;              // [T, mb, 4n]
+  T* dG;              // [T, mb, 4n]
   float* dpeep;
   float* dc_ws;            // [2, mb, n]
 };
+template <typename E>
 struct LstmDiagBwdP {
-  LstmDiagLayerB lay[DIAG_MAXL];
+  LstmDiagLayerB<E> lay[DIAG_MAXL];
   int nl, d, T, mb, n;
 };
 
@@ -836,20 +868,23 @@ struct LstmDiagBwdP {
 // backward. Sized by what bounds this kernel - operand bytes per CU (every byte comes from L2, a wave-load of 1 KB costs ~60 cycles of
 // L1 fill): the 8-unit x all-rows form of lstm_step_bwd_kernel moved 768 KB per workgroup, with half of every MFMA's rows duplicates,
 // and took 32 us per diagonal; this one moves 256 KB per workgroup over twice as many workgroups.
-__global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwdP p) {
+template <typename TR>
+__global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwdP<typename TR::T> p) {
+  typedef typename TR::T T;
+  typedef typename TR::vec vec;
   __shared__ __attribute__((aligned(16))) f32x4 red[(DIAG_WAVES - 1) * 64];
   const int kk_l = blockIdx.z;                                          // 0 = top layer
   const int li = p.nl - 1 - kk_l, t = p.T - 1 - (p.d - kk_l);
   if (li < 0 || t < 0 || t >= p.T) return;
-  const LstmDiagLayerB& L = p.lay[li];
+  const LstmDiagLayerB<T>& L = p.lay[li];
   const int n = p.n, mb = p.mb, K = 4 * p.n;
   const int64_t hn = (int64_t)mb * n;
-  const bf16_t* dG_next = t == p.T - 1 ? nullptr : L.dG + 4 * (t + 1) * hn;
-  const bf16_t* dG_up = L.dG_above ? L.dG_above + 4 * t * hn : nullptr;
+  const T* dG_next = t == p.T - 1 ? nullptr : L.dG + 4 * (t + 1) * hn;
+  const T* dG_up = L.dG_above ? L.dG_above + 4 * t * hn : nullptr;
   const float* dc_in = t == p.T - 1 ? nullptr : L.dc_ws + (int64_t)((p.T - 2 - t) & 1) * hn;
   float* dc_out = L.dc_ws + (int64_t)((p.T - 1 - t) & 1) * hn;
-  const bf16_t* cprev = t == 0 ? L.c0 : L.Cs + (t - 1) * hn;
-  const bf16_t* SVt = L.SV + 6 * t * hn;
+  const T* cprev = t == 0 ? L.c0 : L.Cs + (t - 1) * hn;
+  const T* SVt = L.SV + 6 * t * hn;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
   const int bcol = lane & 15, q = lane >> 4;
@@ -859,51 +894,51 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwd
   const int Kw = K >> DIAG_LOG2W;                                                // K range of this wave (a multiple of 32: n % 128 == 0)
   const bool any_k = dG_next != nullptr || dG_up != nullptr;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const bf16x8_t zero = {};
-  const int64_t koff = (int64_t)wave * Kw + q * 8;
+  const vec zero = {};
+  const int64_t koff = (int64_t)wave * Kw + q * TR::BLANE;
   // both segments' operands are requested before the first MFMA (Kw / 32 k-steps each: 4 at n = 512)
   if (dG_next != nullptr) {
-    const bf16_t* ap = L.rw4t + (int64_t)(u0 + bcol) * L.ld_rwt + koff;
-    const bf16_t* bp = dG_next + (int64_t)(row_ok ? row : 0) * K + koff;
-    for (int k0 = 0; k0 < Kw; k0 += 32 * STEP_KSTEPS) {
-      bf16x8_t a[STEP_KSTEPS], b[STEP_KSTEPS];
+    const T* ap = L.rw4t + (int64_t)(u0 + bcol) * L.ld_rwt + koff;
+    const T* bp = dG_next + (int64_t)(row_ok ? row : 0) * K + koff;
+    for (int k0 = 0; k0 < Kw; k0 += TR::BSTEP * TR::BK) {
+      vec a[TR::BK], b[TR::BK];
 #pragma unroll
-      for (int i = 0; i < STEP_KSTEPS; ++i) {
-        const int k = k0 + 32 * i;
-        a[i] = k < Kw ? *(const bf16x8_t*)(ap + k) : zero;
-        b[i] = (k < Kw && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      for (int i = 0; i < TR::BK; ++i) {
+        const int k = k0 + TR::BSTEP * i;
+        a[i] = k < Kw ? *(const vec*)(ap + k) : zero;
+        b[i] = (k < Kw && row_ok) ? *(const vec*)(bp + k) : zero;
       }
 #pragma unroll
-      for (int i = 0; i < STEP_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[i], acc, 0, 0, 0);
+      for (int i = 0; i < TR::BK; ++i) TR::mfma_b(acc, a[i], b[i]);
     }
   }
   if (dG_up != nullptr) {
-    const bf16_t* ap = L.wct + (int64_t)(u0 + bcol) * L.ld_wct + koff;
-    const bf16_t* bp = dG_up + (int64_t)(row_ok ? row : 0) * K + koff;
-    for (int k0 = 0; k0 < Kw; k0 += 32 * STEP_KSTEPS) {
-      bf16x8_t a[STEP_KSTEPS], b[STEP_KSTEPS];
+    const T* ap = L.wct + (int64_t)(u0 + bcol) * L.ld_wct + koff;
+    const T* bp = dG_up + (int64_t)(row_ok ? row : 0) * K + koff;
+    for (int k0 = 0; k0 < Kw; k0 += TR::BSTEP * TR::BK) {
+      vec a[TR::BK], b[TR::BK];
 #pragma unroll
-      for (int i = 0; i < STEP_KSTEPS; ++i) {
-        const int k = k0 + 32 * i;
-        a[i] = k < Kw ? *(const bf16x8_t*)(ap + k) : zero;
-        b[i] = (k < Kw && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      for (int i = 0; i < TR::BK; ++i) {
+        const int k = k0 + TR::BSTEP * i;
+        a[i] = k < Kw ? *(const vec*)(ap + k) : zero;
+        b[i] = (k < Kw && row_ok) ? *(const vec*)(bp + k) : zero;
       }
 #pragma unroll
-      for (int i = 0; i < STEP_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[i], acc, 0, 0, 0);
+      for (int i = 0; i < TR::BK; ++i) TR::mfma_b(acc, a[i], b[i]);
     }
   }
   // wave 0 owns the cell: its operands travel while the other waves hand their partial tiles over
-  uint64_t ev = 0, sva = 0, svf = 0, svo = 0, svg = 0, svc = 0, svac = 0, cpv = 0;
+  float e4[4] = {0, 0, 0, 0}, a4[4] = {0, 0, 0, 0}, f4[4] = {0, 0, 0, 0}, o4[4] = {0, 0, 0, 0}, g4[4] = {0, 0, 0, 0}, c4[4] = {0, 0, 0, 0};
+  float ac4[4] = {0, 0, 0, 0}, cp4[4] = {0, 0, 0, 0};
   float dcn[4] = {0.f, 0.f, 0.f, 0.f};
   const bool cell_lane = wave == 0 && row_ok;
   if (cell_lane) {
     const int64_t hidx = (int64_t)row * n + uq;
-    if (L.E) ev = *(const uint64_t*)(L.E + t * hn + hidx);
-    const bf16_t* sv = SVt + (int64_t)row * 6 * n + uq;
-    sva = *(const uint64_t*)(sv); svf = *(const uint64_t*)(sv + n); svo = *(const uint64_t*)(sv + 2 * (int64_t)n);
-    svg = *(const uint64_t*)(sv + 3 * (int64_t)n); svc = *(const uint64_t*)(sv + 4 * (int64_t)n);
-    svac = *(const uint64_t*)(sv + 5 * (int64_t)n);
-    cpv = *(const uint64_t*)(cprev + hidx);
+    if (L.E) TR::ld4(L.E + t * hn + hidx, e4);
+    const T* sv = SVt + (int64_t)row * 6 * n + uq;
+    TR::ld4(sv, a4); TR::ld4(sv + n, f4); TR::ld4(sv + 2 * (int64_t)n, o4); TR::ld4(sv + 3 * (int64_t)n, g4);
+    TR::ld4(sv + 4 * (int64_t)n, c4); TR::ld4(sv + 5 * (int64_t)n, ac4);
+    TR::ld4(cprev + hidx, cp4);
     if (dc_in) {
       const f32x4 d = *(const f32x4*)(dc_in + hidx);
 #pragma unroll
@@ -927,9 +962,6 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwd
     for (int j = 0; j < 4; ++j) { wpf[j] = L.pf[uq + j]; wpo[j] = L.po[uq + j]; wpg[j] = L.pg[uq + j]; }
   }
   if (row_ok) {
-    float e4[4], a4[4], f4[4], o4[4], g4[4], c4[4], ac4[4], cp4[4];
-    unpack4(ev, e4); unpack4(sva, a4); unpack4(svf, f4); unpack4(svo, o4); unpack4(svg, g4); unpack4(svc, c4);
-    unpack4(svac, ac4); unpack4(cpv, cp4);
     float dza[4], dzf[4], dzo[4], dzg[4];
     f32x4 dco;
 #pragma unroll
@@ -952,11 +984,11 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwd
     }
     const int64_t hidx = (int64_t)row * n + uq;
     *(f32x4*)(dc_out + hidx) = dco;
-    bf16_t* dg = L.dG + 4 * t * hn + (int64_t)row * K + uq;
-    *(uint64_t*)(dg) = pack4(dza[0], dza[1], dza[2], dza[3]);
-    *(uint64_t*)(dg + n) = pack4(dzf[0], dzf[1], dzf[2], dzf[3]);
-    *(uint64_t*)(dg + 2 * (int64_t)n) = pack4(dzo[0], dzo[1], dzo[2], dzo[3]);
-    *(uint64_t*)(dg + 3 * (int64_t)n) = pack4(dzg[0], dzg[1], dzg[2], dzg[3]);
+    T* dg = L.dG + 4 * t * hn + (int64_t)row * K + uq;
+    TR::st4(dg, dza[0], dza[1], dza[2], dza[3]);
+    TR::st4(dg + n, dzf[0], dzf[1], dzf[2], dzf[3]);
+    TR::st4(dg + 2 * (int64_t)n, dzo[0], dzo[1], dzo[2], dzo[3]);
+    TR::st4(dg + 3 * (int64_t)n, dzg[0], dzg[1], dzg[2], dzg[3]);
   }
   if (L.pf && L.dpeep) {
 #pragma unroll
@@ -1357,26 +1389,28 @@ DL4J_API int dl4j_lstm_diag_supported(int mb, int n, int nl) {
   return (nl >= 2 && nl <= DIAG_MAXL && n % 128 == 0 && n / 8 <= 256 && mb > 0 && mb <= 128) ? 1 : 0;    // n % 128: whole k-steps per wave
 }
 
-DL4J_API int dl4j_lstm_diag_fwd(const void* xw0, const void* const* rw4, const void* const* w2, const void* const* x2, const float* const* bias,
-                                const void* const* h0, const void* const* c0, const float* const* pf, const float* const* po,
-                                const float* const* pg, void* const* H, void* const* Cs, void* const* SV, const int* nIn, int nl, int T, int mb,
-                                int n, hipStream_t st) {
-  if (T <= 0) return 0;
-  if (!dl4j_lstm_diag_supported(mb, n, nl) || xw0 == nullptr || ((uintptr_t)xw0 & 7)) return -2;
-  LstmDiagFwdP p;
+template <typename TR>
+static int lstm_diag_fwd_t(const void* xw0, const void* const* rw4, const void* const* w2, const void* const* x2, const float* const* bias,
+                           const void* const* h0, const void* const* c0, const float* const* pf, const float* const* po,
+                           const float* const* pg, void* const* H, void* const* Cs, void* const* SV, const int* nIn, int nl, int T, int mb,
+                           int n, hipStream_t st) {
+  typedef typename TR::T E;
+  LstmDiagFwdP<E> p;
   p.nl = nl; p.T = T; p.mb = mb; p.n = n; p.d = 0;
   for (int l = 0; l < nl; ++l) {
-    LstmDiagLayerF& q = p.lay[l];
-    q.xw = l == 0 ? (const bf16_t*)xw0 : nullptr;
-    q.rw4 = (const bf16_t*)rw4[l]; q.ld_rw = n;
-    q.w2 = l == 0 ? nullptr : (const bf16_t*)w2[l]; q.ld_w2 = l == 0 ? 0 : nIn[l];
-    q.x2 = l == 0 ? nullptr : (const bf16_t*)x2[l];
+    LstmDiagLayerF<E>& q = p.lay[l];
+    q.xw = l == 0 ? (const E*)xw0 : nullptr;
+    q.rw4 = (const E*)rw4[l]; q.ld_rw = n;
+    q.w2 = l == 0 ? nullptr : (const E*)w2[l]; q.ld_w2 = l == 0 ? 0 : nIn[l];
+    q.x2 = l == 0 ? nullptr : (const E*)x2[l];
     q.bias = l == 0 ? nullptr : bias[l];
-    q.h0 = (const bf16_t*)h0[l]; q.c0 = (const bf16_t*)c0[l];
+    q.h0 = (const E*)h0[l]; q.c0 = (const E*)c0[l];
     q.pf = pf ? pf[l] : nullptr; q.po = po ? po[l] : nullptr; q.pg = pg ? pg[l] : nullptr;
-    q.H = (bf16_t*)H[l]; q.Cs = (bf16_t*)Cs[l]; q.SV = SV ? (bf16_t*)SV[l] : nullptr;
+    q.H = (E*)H[l]; q.Cs = (E*)Cs[l]; q.SV = SV ? (E*)SV[l] : nullptr;
     q.nIn = l == 0 ? 0 : nIn[l];
-    if (((uintptr_t)q.rw4 & 15) || ((uintptr_t)q.h0 & 15) || ((uintptr_t)q.H & 15) || ((uintptr_t)q.c0 & 7) || ((uintptr_t)q.Cs & 7)) return -2;
+    if (((uintptr_t)q.rw4 & 15) || ((uintptr_t)q.h0 & 15) || ((uintptr_t)q.H & 15) || ((uintptr_t)q.c0 & 15) || ((uintptr_t)q.Cs & 15) ||
+        ((uintptr_t)q.SV & 15))
+      return -2;
     if ((q.pf != nullptr) != (q.po != nullptr) || (q.pf != nullptr) != (q.pg != nullptr)) return -2;
     if (l > 0 && (q.w2 == nullptr || q.x2 == nullptr || q.bias == nullptr || q.nIn % 64 != 0 || ((uintptr_t)q.w2 & 15) || ((uintptr_t)q.x2 & 15) ||
                   ((uintptr_t)q.bias & 15)))
@@ -1385,30 +1419,40 @@ DL4J_API int dl4j_lstm_diag_fwd(const void* xw0, const void* const* rw4, const v
   for (int l = nl; l < DIAG_MAXL; ++l) p.lay[l] = p.lay[0];
   for (int d = 0; d < T + nl - 1; ++d) {
     p.d = d;
-    hipLaunchKernelGGL(lstm_diag_fwd_kernel, dim3(n / 8, (mb + 31) / 32, nl), dim3(DIAG_THREADS), 0, st, p);
+    hipLaunchKernelGGL((lstm_diag_fwd_kernel<TR>), dim3(n / 8, (mb + 31) / 32, nl), dim3(DIAG_THREADS), 0, st, p);
   }
   DL4J_RET_LAST();
 }
 
-// E_top: [T, mb, n] gradient entering the top layer's activations. wct[l] = input weights of layer l + 1 as [n, 4n] rows (null for the top
-// layer); dc_ws[l]: [2, mb, n] fp32 scratch; dpeep[l]: [3, n] fp32 zeroed by the caller, or null.
-DL4J_API int dl4j_lstm_diag_bwd(const void* E_top, const void* const* rw4t, const void* const* wct, const void* const* SV, const void* const* Cs,
-                                const void* const* c0, const float* const* pf, const float* const* po, const float* const* pg,
-                                void* const* dG, float* const* dpeep, float* const* dc_ws, int nl, int T, int mb, int n, hipStream_t st) {
+// dtype: 0 = bf16, 1 = fp32 (every operand except bias / peepholes / dc_ws, which are fp32 always)
+DL4J_API int dl4j_lstm_diag_fwd(const void* xw0, const void* const* rw4, const void* const* w2, const void* const* x2, const float* const* bias,
+                                const void* const* h0, const void* const* c0, const float* const* pf, const float* const* po,
+                                const float* const* pg, void* const* H, void* const* Cs, void* const* SV, const int* nIn, int nl, int T, int mb,
+                                int n, int dtype, hipStream_t st) {
   if (T <= 0) return 0;
-  if (!dl4j_lstm_diag_supported(mb, n, nl) || E_top == nullptr || ((uintptr_t)E_top & 7)) return -2;
-  LstmDiagBwdP p;
+  if (!dl4j_lstm_diag_supported(mb, n, nl) || xw0 == nullptr || ((uintptr_t)xw0 & 15)) return -2;
+  if (dtype == 1) return lstm_diag_fwd_t<DiagF32>(xw0, rw4, w2, x2, bias, h0, c0, pf, po, pg, H, Cs, SV, nIn, nl, T, mb, n, st);
+  if (dtype == 0) return lstm_diag_fwd_t<DiagBf16>(xw0, rw4, w2, x2, bias, h0, c0, pf, po, pg, H, Cs, SV, nIn, nl, T, mb, n, st);
+  return -2;
+}
+
+template <typename TR>
+static int lstm_diag_bwd_t(const void* E_top, const void* const* rw4t, const void* const* wct, const void* const* SV, const void* const* Cs,
+                           const void* const* c0, const float* const* pf, const float* const* po, const float* const* pg, void* const* dG,
+                           float* const* dpeep, float* const* dc_ws, int nl, int T, int mb, int n, hipStream_t st) {
+  typedef typename TR::T E;
+  LstmDiagBwdP<E> p;
   p.nl = nl; p.T = T; p.mb = mb; p.n = n; p.d = 0;
   for (int l = 0; l < nl; ++l) {
-    LstmDiagLayerB& q = p.lay[l];
-    q.E = l == nl - 1 ? (const bf16_t*)E_top : nullptr;
-    q.rw4t = (const bf16_t*)rw4t[l]; q.ld_rwt = 4 * (int64_t)n;
-    q.wct = l == nl - 1 ? nullptr : (const bf16_t*)wct[l]; q.ld_wct = 4 * (int64_t)n;
-    q.dG_above = l == nl - 1 ? nullptr : (const bf16_t*)dG[l + 1];
-    q.SV = (const bf16_t*)SV[l]; q.Cs = (const bf16_t*)Cs[l]; q.c0 = (const bf16_t*)c0[l];
+    LstmDiagLayerB<E>& q = p.lay[l];
+    q.E = l == nl - 1 ? (const E*)E_top : nullptr;
+    q.rw4t = (const E*)rw4t[l]; q.ld_rwt = 4 * (int64_t)n;
+    q.wct = l == nl - 1 ? nullptr : (const E*)wct[l]; q.ld_wct = 4 * (int64_t)n;
+    q.dG_above = l == nl - 1 ? nullptr : (const E*)dG[l + 1];
+    q.SV = (const E*)SV[l]; q.Cs = (const E*)Cs[l]; q.c0 = (const E*)c0[l];
     q.pf = pf ? pf[l] : nullptr; q.po = po ? po[l] : nullptr; q.pg = pg ? pg[l] : nullptr;
-    q.dG = (bf16_t*)dG[l]; q.dpeep = dpeep ? dpeep[l] : nullptr; q.dc_ws = dc_ws[l];
-    if (((uintptr_t)q.rw4t & 15) || ((uintptr_t)q.dG & 15) || ((uintptr_t)q.SV & 7) || ((uintptr_t)q.Cs & 7) || ((uintptr_t)q.c0 & 7) ||
+    q.dG = (E*)dG[l]; q.dpeep = dpeep ? dpeep[l] : nullptr; q.dc_ws = dc_ws[l];
+    if (((uintptr_t)q.rw4t & 15) || ((uintptr_t)q.dG & 15) || ((uintptr_t)q.SV & 15) || ((uintptr_t)q.Cs & 15) || ((uintptr_t)q.c0 & 15) ||
         q.dc_ws == nullptr || ((uintptr_t)q.dc_ws & 15))
       return -2;
     if (l < nl - 1 && (q.wct == nullptr || ((uintptr_t)q.wct & 15))) return -2;
@@ -1417,9 +1461,22 @@ DL4J_API int dl4j_lstm_diag_bwd(const void* E_top, const void* const* rw4t, cons
   for (int l = nl; l < DIAG_MAXL; ++l) p.lay[l] = p.lay[0];
   for (int d = 0; d < T + nl - 1; ++d) {
     p.d = d;
-    hipLaunchKernelGGL(lstm_diag_bwd_kernel, dim3(n / 16, (mb + 15) / 16, nl), dim3(DIAG_THREADS), 0, st, p);
+    hipLaunchKernelGGL((lstm_diag_bwd_kernel<TR>), dim3(n / 16, (mb + 15) / 16, nl), dim3(DIAG_THREADS), 0, st, p);
   }
   DL4J_RET_LAST();
+}
+
+// E_top: [T, mb, n] gradient entering the top layer's activations. wct[l] = input weights of layer l + 1 as [n, 4n] rows (null for the top
+// layer); dc_ws[l]: [2, mb, n] fp32 scratch; dpeep[l]: [3, n] fp32 zeroed by the caller, or null. dtype as in dl4j_lstm_diag_fwd.
+DL4J_API int dl4j_lstm_diag_bwd(const void* E_top, const void* const* rw4t, const void* const* wct, const void* const* SV, const void* const* Cs,
+                                const void* const* c0, const float* const* pf, const float* const* po, const float* const* pg,
+                                void* const* dG, float* const* dpeep, float* const* dc_ws, int nl, int T, int mb, int n, int dtype,
+                                hipStream_t st) {
+  if (T <= 0) return 0;
+  if (!dl4j_lstm_diag_supported(mb, n, nl) || E_top == nullptr || ((uintptr_t)E_top & 15)) return -2;
+  if (dtype == 1) return lstm_diag_bwd_t<DiagF32>(E_top, rw4t, wct, SV, Cs, c0, pf, po, pg, dG, dpeep, dc_ws, nl, T, mb, n, st);
+  if (dtype == 0) return lstm_diag_bwd_t<DiagBf16>(E_top, rw4t, wct, SV, Cs, c0, pf, po, pg, dG, dpeep, dc_ws, nl, T, mb, n, st);
+  return -2;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- fp32 entry points

@@ -139,9 +139,9 @@ def _parr(ts):
 
 
 def _diag_ok(lay, mb, bf16):
-    """One launch per anti-diagonal of the layer x time wavefront (native/csrc/lstm_persist.hip lstm_diag_*_kernel): bf16 stacks of
-    2-4 layers of the same width whose upper layers read an input that is a multiple of 64 wide."""
-    if not (DIAG and bf16 and 2 <= len(lay) <= 4):
+    """One launch per anti-diagonal of the layer x time wavefront (native/csrc/lstm_persist.hip lstm_diag_*_kernel): bf16 / fp32 stacks
+    of 2-4 layers of the same width (a multiple of 128) whose upper layers read an input that is a multiple of 64 wide."""
+    if not (DIAG and 2 <= len(lay) <= 4):
         return False
     n = lay[0]["n"]
     if any(d["n"] != n for d in lay) or any(d["nIn"] % 64 != 0 for d in lay[1:]):
@@ -213,7 +213,8 @@ def forward(layers, x, train, mode=None):
             _parr([d["h0"] for d in lay]), _parr([d["c0"] for d in lay]),
             _parr([d["pf"] for d in lay]) if has_peep else None, _parr([d["po"] for d in lay]) if has_peep else None,
             _parr([d["pg"] for d in lay]) if has_peep else None, _parr([d["H"] for d in lay]), _parr([d["Cs"] for d in lay]),
-            _parr([d["SV"] for d in lay]) if train else None, nins, L.c_int(nl), L.c_int(T), L.c_int(mb), L.c_int(lay[0]["n"]), _sp(cur)),
+            _parr([d["SV"] for d in lay]) if train else None, nins, L.c_int(nl), L.c_int(T), L.c_int(mb), L.c_int(lay[0]["n"]),
+            L.c_int(0 if bf16 else 1), _sp(cur)),
             "lstm_diag_fwd")
         return _finish_forward(lay, train, mode, mb, T)
     rec = [[None] * nc for _ in range(nl)]
@@ -320,7 +321,7 @@ def backward(layers, eps):
             _parr([d["pf"] for d in lay]) if has_peep else None, _parr([d["po"] for d in lay]) if has_peep else None,
             _parr([d["pg"] for d in lay]) if has_peep else None, _parr([d["dG"] for d in lay]),
             _parr([d["dpeep"] for d in lay]) if has_peep else None, _parr([d["dc"] for d in lay]), L.c_int(nl), L.c_int(T), L.c_int(mb),
-            L.c_int(lay[0]["n"]), _sp(cur)), "lstm_diag_bwd")
+            L.c_int(lay[0]["n"]), L.c_int(0 if bf16 else 1), _sp(cur)), "lstm_diag_bwd")
         return _finish_backward(lay, nl)
     e0 = ev.record(cur)
     done = [[None] * nc for _ in range(nl)]        # dG of (layer, chunk) is complete

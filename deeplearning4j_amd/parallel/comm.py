@@ -73,7 +73,9 @@ def all_reduce_avg_(t: torch.Tensor, async_op=False):
     if world_size() == 1 and not _forced():
         return None
     if dist.get_backend() == "nccl":
-        return dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=async_op)
+        # one rank (the forced rehearsal): the average IS the sum, and SUM spares RCCL's single-rank pre-multiply kernel
+        # (oneRankReduce, 31 us per bucket in profiles/r3_final_steps.md's data-parallel twin)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM if world_size() == 1 else dist.ReduceOp.AVG, async_op=async_op)
     w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
     if async_op:
         return _ScaledWork(w, t, 1.0 / world_size())

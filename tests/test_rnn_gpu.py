@@ -461,6 +461,32 @@ def test_lstm_stack_diagonal_launches_match_chunk_pipeline_and_fp32(monkeypatch,
         assert (ga - gb).abs().max().item() < tol * max(1.0, ga.abs().max().item())
 
 
+@pytest.mark.parametrize("kind", ["lstm", "graves"])
+def test_lstm_stack_diagonal_launches_fp32_match_layer_by_layer(monkeypatch, kind):
+    """The fp32 instantiation of the diagonal kernels (MFMA 32x32x2 / 16x16x4) against the layer-by-layer schedule."""
+    from deeplearning4j_amd.nn.layers import lstm_stack
+    used = {"n": 0}
+    inner = lstm_stack._diag_ok
+    monkeypatch.setattr(lstm_stack, "_diag_ok", lambda *a, **k: (lambda r: (used.__setitem__("n", used["n"] + int(r)), r)[1])(inner(*a, **k)))
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(24, 12, 13, generator=g).cuda()
+    y = torch.nn.functional.one_hot(torch.randint(0, 5, (24, 13), generator=g), 5).permute(0, 2, 1).float().cuda()
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(lstm_stack, "ENABLED", on)
+        net = _equal_stack_net(kind, None, T=13)
+        out = net.output(x).float()
+        net.computeGradientAndScore(x, y)
+        torch.cuda.synchronize()
+        res[on] = (out, float(net._score), net._grads.float().clone())
+    assert used["n"] == 3, used
+    assert (res[True][0] - res[False][0]).abs().max().item() < 1e-4
+    assert abs(res[True][1] - res[False][1]) < 1e-4 * max(1.0, abs(res[False][1]))
+    ga, gb = res[False][2].double(), res[True][2].double()
+    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.999999
+    assert (ga - gb).abs().max().item() < 1e-4 * max(1.0, ga.abs().max().item())
+
+
 def test_lstm_stack_diagonal_tbptt_fit_under_graph_capture(monkeypatch):
     """Truncated BPTT with the diagonal launches captured in a hipGraph: state carried between segments and parameters after three
     fits equal the eager run bit for bit."""
