@@ -1382,11 +1382,12 @@ DL4J_API int dl4j_lstm_steps_bwd(const void* E, const void* rw4t, int64_t ld_rwt
   return dl4j_lstm_steps_bwd_range(E, rw4t, ld_rwt, SV, Cs, c0, pf, po, pg, maskT, dG, dpeep, bar, dc_ws, dc_last, T, mb, n, reverse, 0, T, st);
 }
 
-// Diagonal passes over a stack of nl <= DIAG_MAXL layers with the same width n (see lstm_diag_fwd_kernel). Per-layer pointers come as
+// Diagonal passes over a stack of 1 <= nl <= DIAG_MAXL layers with the same width n (see lstm_diag_fwd_kernel; nl = 1 is a plain
+// sequence of step launches in the one-tile-per-workgroup decomposition). Per-layer pointers come as
 // arrays of nl entries; xw[0] is the first layer's projection of the whole sequence, w2 / x2 / bias are used by layers 1.. (entry 0 is
 // ignored). nIn[l] = width of layer l's input. Every launch covers the cells of one anti-diagonal: T + nl - 1 launches.
 DL4J_API int dl4j_lstm_diag_supported(int mb, int n, int nl) {
-  return (nl >= 2 && nl <= DIAG_MAXL && n % 128 == 0 && n / 8 <= 256 && mb > 0 && mb <= 128) ? 1 : 0;    // n % 128: whole k-steps per wave
+  return (nl >= 1 && nl <= DIAG_MAXL && n % 128 == 0 && n / 8 <= 256 && mb > 0 && mb <= 128) ? 1 : 0;    // n % 128: whole k-steps per wave
 }
 
 template <typename TR>
