@@ -678,7 +678,8 @@ struct LstmDiagLayerF {
 template <typename E>
 struct LstmDiagFwdP {
   LstmDiagLayerF<E> lay[DIAG_MAXL];
-  int nl, d, T, mb, n;
+  const float* maskT;      // [T, mb] or null: masked steps emit h = 0 and carry c = 0 (as the step kernels)
+  int nl, d, T, mb, n, reverse;   // reverse: processing step s runs time index T - 1 - s
 };
 
 // element-type traits of the diagonal kernels: bf16 (MFMA 32x32x16 / 16x16x32, 16-byte loads = 8 K values per lane) and fp32 (MFMA
@@ -724,13 +725,14 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
   typedef typename TR::T T;
   typedef typename TR::vec vec;
   __shared__ __attribute__((aligned(16))) f32x16 red[(DIAG_WAVES - 1) * 64];
-  const int li = blockIdx.z, t = p.d - li;
-  if (li >= p.nl || t < 0 || t >= p.T) return;                          // uniform per workgroup
+  const int li = blockIdx.z, sp = p.d - li;                             // sp: processing step
+  if (li >= p.nl || sp < 0 || sp >= p.T) return;                        // uniform per workgroup
+  const int t = p.reverse ? p.T - 1 - sp : sp, tp = p.reverse ? t + 1 : t - 1;
   const LstmDiagLayerF<T>& q = p.lay[li];
   const int n = p.n, mb = p.mb;
   const int64_t hn = (int64_t)mb * n;
-  const T* hprev = t == 0 ? q.h0 : q.H + (t - 1) * hn;
-  const T* cprev = t == 0 ? q.c0 : q.Cs + (t - 1) * hn;
+  const T* hprev = sp == 0 ? q.h0 : q.H + tp * hn;
+  const T* cprev = sp == 0 ? q.c0 : q.Cs + tp * hn;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * 8;
   const int row = blockIdx.y * 32 + (lane & 31);
@@ -777,6 +779,7 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
     }
   }
   // wave 0 owns the cell: its operands travel while the other waves hand their partial tiles over
+  float mk = 1.f;
   float xg4[4][4], c_state[4] = {0.f, 0.f, 0.f, 0.f};         // gate pre-activations from outside the K loop: xw (first layer) or the bias
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -796,6 +799,7 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
       }
     }
     TR::ld4(cprev + (int64_t)row * n + uq, c_state);
+    if (p.maskT) mk = p.maskT[(int64_t)t * mb + row];
   }
   if (wave > 0) red[(wave - 1) * 64 + lane] = acc;
   __syncthreads();
@@ -823,11 +827,12 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
     const float o = sigm(zo), ac = tanh_fast(c);
     va[j] = a; vf[j] = f; vo[j] = o; vg[j] = g; vac[j] = ac;
     cn[j] = c;
-    hn4[j] = o * ac;
+    hn4[j] = o * ac * mk;
+    c_state[j] = c * mk;
   }
   const int64_t o_idx = (int64_t)t * hn + (int64_t)row * n + uq;
   TR::st4(q.H + o_idx, hn4[0], hn4[1], hn4[2], hn4[3]);
-  TR::st4(q.Cs + o_idx, cn[0], cn[1], cn[2], cn[3]);
+  TR::st4(q.Cs + o_idx, c_state[0], c_state[1], c_state[2], c_state[3]);
   if (q.SV) {
     T* sv = q.SV + ((int64_t)t * mb + row) * 6 * n + uq;
     TR::st4(sv, va[0], va[1], va[2], va[3]);
@@ -860,7 +865,8 @@ struct LstmDiagLayerB {
 template <typename E>
 struct LstmDiagBwdP {
   LstmDiagLayerB<E> lay[DIAG_MAXL];
-  int nl, d, T, mb, n;
+  const float* maskT;
+  int nl, d, T, mb, n, reverse;
 };
 
 // One workgroup = 16 hidden units x 16 batch rows of one (layer, step) cell: ONE 16x16 MFMA tile whose K range (4n gate gradients of
@@ -874,16 +880,17 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwd
   typedef typename TR::vec vec;
   __shared__ __attribute__((aligned(16))) f32x4 red[(DIAG_WAVES - 1) * 64];
   const int kk_l = blockIdx.z;                                          // 0 = top layer
-  const int li = p.nl - 1 - kk_l, t = p.T - 1 - (p.d - kk_l);
-  if (li < 0 || t < 0 || t >= p.T) return;
+  const int li = p.nl - 1 - kk_l, sp = p.T - 1 - (p.d - kk_l);          // sp: processing step of the forward pass, highest first
+  if (li < 0 || sp < 0 || sp >= p.T) return;
+  const int t = p.reverse ? p.T - 1 - sp : sp, tp = p.reverse ? t + 1 : t - 1, tn = p.reverse ? t - 1 : t + 1;
   const LstmDiagLayerB<T>& L = p.lay[li];
   const int n = p.n, mb = p.mb, K = 4 * p.n;
   const int64_t hn = (int64_t)mb * n;
-  const T* dG_next = t == p.T - 1 ? nullptr : L.dG + 4 * (t + 1) * hn;
+  const T* dG_next = sp == p.T - 1 ? nullptr : L.dG + 4 * tn * hn;
   const T* dG_up = L.dG_above ? L.dG_above + 4 * t * hn : nullptr;
-  const float* dc_in = t == p.T - 1 ? nullptr : L.dc_ws + (int64_t)((p.T - 2 - t) & 1) * hn;
-  float* dc_out = L.dc_ws + (int64_t)((p.T - 1 - t) & 1) * hn;
-  const T* cprev = t == 0 ? L.c0 : L.Cs + (t - 1) * hn;
+  const float* dc_in = sp == p.T - 1 ? nullptr : L.dc_ws + (int64_t)((p.T - 2 - sp) & 1) * hn;
+  float* dc_out = L.dc_ws + (int64_t)((p.T - 1 - sp) & 1) * hn;
+  const T* cprev = sp == 0 ? L.c0 : L.Cs + tp * hn;
   const T* SVt = L.SV + 6 * t * hn;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
@@ -931,6 +938,7 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwd
   float e4[4] = {0, 0, 0, 0}, a4[4] = {0, 0, 0, 0}, f4[4] = {0, 0, 0, 0}, o4[4] = {0, 0, 0, 0}, g4[4] = {0, 0, 0, 0}, c4[4] = {0, 0, 0, 0};
   float ac4[4] = {0, 0, 0, 0}, cp4[4] = {0, 0, 0, 0};
   float dcn[4] = {0.f, 0.f, 0.f, 0.f};
+  float mk = 1.f;
   const bool cell_lane = wave == 0 && row_ok;
   if (cell_lane) {
     const int64_t hidx = (int64_t)row * n + uq;
@@ -939,6 +947,7 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwd
     TR::ld4(sv, a4); TR::ld4(sv + n, f4); TR::ld4(sv + 2 * (int64_t)n, o4); TR::ld4(sv + 3 * (int64_t)n, g4);
     TR::ld4(sv + 4 * (int64_t)n, c4); TR::ld4(sv + 5 * (int64_t)n, ac4);
     TR::ld4(cprev + hidx, cp4);
+    if (p.maskT) mk = p.maskT[(int64_t)t * mb + row];
     if (dc_in) {
       const f32x4 d = *(const f32x4*)(dc_in + hidx);
 #pragma unroll
@@ -966,8 +975,8 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_bwd_kernel(LstmDiagBwd
     f32x4 dco;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float d_h = e4[j] + acc[j];
-      const float d_cn = dcn[j];
+      const float d_h = (e4[j] + acc[j]) * mk;
+      const float d_cn = dcn[j] * mk;
       const float a = a4[j], f = f4[j], o = o4[j], g = g4[j], ac = ac4[j], cp = cp4[j];
       dzo[j] = d_h * ac * o * (1.f - o);
       float dc = d_cn + d_h * o * (1.f - ac * ac);
@@ -1394,10 +1403,10 @@ template <typename TR>
 static int lstm_diag_fwd_t(const void* xw0, const void* const* rw4, const void* const* w2, const void* const* x2, const float* const* bias,
                            const void* const* h0, const void* const* c0, const float* const* pf, const float* const* po,
                            const float* const* pg, void* const* H, void* const* Cs, void* const* SV, const int* nIn, int nl, int T, int mb,
-                           int n, hipStream_t st) {
+                           int n, const float* maskT, int reverse, hipStream_t st) {
   typedef typename TR::T E;
   LstmDiagFwdP<E> p;
-  p.nl = nl; p.T = T; p.mb = mb; p.n = n; p.d = 0;
+  p.nl = nl; p.T = T; p.mb = mb; p.n = n; p.d = 0; p.maskT = maskT; p.reverse = reverse;
   for (int l = 0; l < nl; ++l) {
     LstmDiagLayerF<E>& q = p.lay[l];
     q.xw = l == 0 ? (const E*)xw0 : nullptr;
@@ -1429,21 +1438,22 @@ static int lstm_diag_fwd_t(const void* xw0, const void* const* rw4, const void* 
 DL4J_API int dl4j_lstm_diag_fwd(const void* xw0, const void* const* rw4, const void* const* w2, const void* const* x2, const float* const* bias,
                                 const void* const* h0, const void* const* c0, const float* const* pf, const float* const* po,
                                 const float* const* pg, void* const* H, void* const* Cs, void* const* SV, const int* nIn, int nl, int T, int mb,
-                                int n, int dtype, hipStream_t st) {
+                                int n, int dtype, const float* maskT, int reverse, hipStream_t st) {
   if (T <= 0) return 0;
+  if (reverse && nl != 1) return -2;                       // a reversed stack would need the layer below at the mirrored index
   if (!dl4j_lstm_diag_supported(mb, n, nl) || xw0 == nullptr || ((uintptr_t)xw0 & 15)) return -2;
-  if (dtype == 1) return lstm_diag_fwd_t<DiagF32>(xw0, rw4, w2, x2, bias, h0, c0, pf, po, pg, H, Cs, SV, nIn, nl, T, mb, n, st);
-  if (dtype == 0) return lstm_diag_fwd_t<DiagBf16>(xw0, rw4, w2, x2, bias, h0, c0, pf, po, pg, H, Cs, SV, nIn, nl, T, mb, n, st);
+  if (dtype == 1) return lstm_diag_fwd_t<DiagF32>(xw0, rw4, w2, x2, bias, h0, c0, pf, po, pg, H, Cs, SV, nIn, nl, T, mb, n, maskT, reverse, st);
+  if (dtype == 0) return lstm_diag_fwd_t<DiagBf16>(xw0, rw4, w2, x2, bias, h0, c0, pf, po, pg, H, Cs, SV, nIn, nl, T, mb, n, maskT, reverse, st);
   return -2;
 }
 
 template <typename TR>
 static int lstm_diag_bwd_t(const void* E_top, const void* const* rw4t, const void* const* wct, const void* const* SV, const void* const* Cs,
                            const void* const* c0, const float* const* pf, const float* const* po, const float* const* pg, void* const* dG,
-                           float* const* dpeep, float* const* dc_ws, int nl, int T, int mb, int n, hipStream_t st) {
+                           float* const* dpeep, float* const* dc_ws, int nl, int T, int mb, int n, const float* maskT, int reverse, hipStream_t st) {
   typedef typename TR::T E;
   LstmDiagBwdP<E> p;
-  p.nl = nl; p.T = T; p.mb = mb; p.n = n; p.d = 0;
+  p.nl = nl; p.T = T; p.mb = mb; p.n = n; p.d = 0; p.maskT = maskT; p.reverse = reverse;
   for (int l = 0; l < nl; ++l) {
     LstmDiagLayerB<E>& q = p.lay[l];
     q.E = l == nl - 1 ? (const E*)E_top : nullptr;
@@ -1472,11 +1482,12 @@ static int lstm_diag_bwd_t(const void* E_top, const void* const* rw4t, const voi
 DL4J_API int dl4j_lstm_diag_bwd(const void* E_top, const void* const* rw4t, const void* const* wct, const void* const* SV, const void* const* Cs,
                                 const void* const* c0, const float* const* pf, const float* const* po, const float* const* pg,
                                 void* const* dG, float* const* dpeep, float* const* dc_ws, int nl, int T, int mb, int n, int dtype,
-                                hipStream_t st) {
+                                const float* maskT, int reverse, hipStream_t st) {
   if (T <= 0) return 0;
+  if (reverse && nl != 1) return -2;
   if (!dl4j_lstm_diag_supported(mb, n, nl) || E_top == nullptr || ((uintptr_t)E_top & 15)) return -2;
-  if (dtype == 1) return lstm_diag_bwd_t<DiagF32>(E_top, rw4t, wct, SV, Cs, c0, pf, po, pg, dG, dpeep, dc_ws, nl, T, mb, n, st);
-  if (dtype == 0) return lstm_diag_bwd_t<DiagBf16>(E_top, rw4t, wct, SV, Cs, c0, pf, po, pg, dG, dpeep, dc_ws, nl, T, mb, n, st);
+  if (dtype == 1) return lstm_diag_bwd_t<DiagF32>(E_top, rw4t, wct, SV, Cs, c0, pf, po, pg, dG, dpeep, dc_ws, nl, T, mb, n, maskT, reverse, st);
+  if (dtype == 0) return lstm_diag_bwd_t<DiagBf16>(E_top, rw4t, wct, SV, Cs, c0, pf, po, pg, dG, dpeep, dc_ws, nl, T, mb, n, maskT, reverse, st);
   return -2;
 }
 

@@ -214,7 +214,7 @@ def forward(layers, x, train, mode=None):
             _parr([d["pf"] for d in lay]) if has_peep else None, _parr([d["po"] for d in lay]) if has_peep else None,
             _parr([d["pg"] for d in lay]) if has_peep else None, _parr([d["H"] for d in lay]), _parr([d["Cs"] for d in lay]),
             _parr([d["SV"] for d in lay]) if train else None, nins, L.c_int(nl), L.c_int(T), L.c_int(mb), L.c_int(lay[0]["n"]),
-            L.c_int(0 if bf16 else 1), _sp(cur)),
+            L.c_int(0 if bf16 else 1), L.ptr(None), L.c_int(0), _sp(cur)),
             "lstm_diag_fwd")
         return _finish_forward(lay, train, mode, mb, T)
     rec = [[None] * nc for _ in range(nl)]
@@ -321,7 +321,7 @@ def backward(layers, eps):
             _parr([d["pf"] for d in lay]) if has_peep else None, _parr([d["po"] for d in lay]) if has_peep else None,
             _parr([d["pg"] for d in lay]) if has_peep else None, _parr([d["dG"] for d in lay]),
             _parr([d["dpeep"] for d in lay]) if has_peep else None, _parr([d["dc"] for d in lay]), L.c_int(nl), L.c_int(T), L.c_int(mb),
-            L.c_int(lay[0]["n"]), L.c_int(0 if bf16 else 1), _sp(cur)), "lstm_diag_bwd")
+            L.c_int(lay[0]["n"]), L.c_int(0 if bf16 else 1), L.ptr(None), L.c_int(0), _sp(cur)), "lstm_diag_bwd")
         return _finish_backward(lay, nl)
     e0 = ev.record(cur)
     done = [[None] * nc for _ in range(nl)]        # dG of (layer, chunk) is complete

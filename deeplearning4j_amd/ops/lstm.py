@@ -123,10 +123,10 @@ def steps_f32_ok(xw, RW4, mb, n):
 _DIAG1 = os.environ.get("DL4J_AMD_LSTM_DIAG1", "1") != "0"
 
 
-def diag1_ok(xw, mb, n, mask, reverse):
-    """Unmasked forward-direction sequences on the one-tile-per-workgroup step kernels (lstm_diag_*_kernel with a single layer):
-    bound by operand bytes per CU, they move a third of what the 8-unit x all-rows step kernels move."""
-    return (_DIAG1 and _PERSIST and _PERSIST_MODE == "steps" and mask is None and not reverse and xw.dtype in (torch.bfloat16, torch.float32)
+def diag1_ok(xw, mb, n):
+    """Sequences on the one-tile-per-workgroup step kernels (lstm_diag_*_kernel with a single layer; masks and the reverse direction
+    included): bound by operand bytes per CU, they move a third of what the 8-unit x all-rows step kernels move."""
+    return (_DIAG1 and _PERSIST and _PERSIST_MODE == "steps" and xw.dtype in (torch.bfloat16, torch.float32)
             and bool(L.hip().dl4j_lstm_diag_supported(L.c_int(mb), L.c_int(n), L.c_int(1))))
 
 
@@ -148,14 +148,14 @@ def seq_forward(xw, RW4, h0, c0, peep, mask, train, reverse):
         pf, po, pg = (p.contiguous().float() for p in peep)
     maskT = mask.to(dev).t().contiguous().float() if mask is not None else None
     h0c, c0c = h0.to(dt).contiguous(), c0.to(dt).contiguous()
-    if diag1_ok(xw, mb, n, mask, reverse) and RW4.dtype == dt:
+    if diag1_ok(xw, mb, n) and RW4.dtype == dt:
         nins = (ctypes.c_int * 1)(0)
         L.check(L.hip().dl4j_lstm_diag_fwd(L.ptr(xw), _p1(RW4), _p1(None), _p1(None), _p1(None), _p1(h0c), _p1(c0c),
                                            _p1(pf) if pf is not None else None, _p1(po) if pf is not None else None,
                                            _p1(pg) if pf is not None else None, _p1(H), _p1(Cs), _p1(SV) if SV is not None else None, nins,
                                            L.c_int(1), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(0 if dt == torch.bfloat16 else 1),
-                                           L.stream()), "lstm_diag_fwd")
-        return H, {"H": H, "Cs": Cs, "SV": SV, "h0": h0c, "c0": c0c, "peep": (pf, po, pg), "maskT": None}
+                                           L.ptr(maskT), L.c_int(1 if reverse else 0), L.stream()), "lstm_diag_fwd")
+        return H, {"H": H, "Cs": Cs, "SV": SV, "h0": h0c, "c0": c0c, "peep": (pf, po, pg), "maskT": maskT}
     if persist_ok(xw, RW4, mb, n):
         # one launch for the whole sequence (native/csrc/lstm_persist.hip): weights resident in LDS, cell state in registers
         bar = torch.empty(2, device=dev, dtype=torch.int32)
@@ -187,13 +187,13 @@ def seq_backward(E, RW4, st, reverse, dc_last=None):
     dG = torch.empty(T, mb, 4 * n, device=dev, dtype=dt)
     pf, po, pg = st["peep"]
     dpeep = torch.zeros(3, n, device=dev, dtype=torch.float32) if pf is not None else None
-    if dcl is None and st["SV"] is not None and rw4t.dtype == dt and diag1_ok(E, mb, n, st["maskT"], reverse):
+    if dcl is None and st["SV"] is not None and rw4t.dtype == dt and diag1_ok(E, mb, n):
         dc_ws = torch.empty(2, mb, n, device=dev, dtype=torch.float32)
         L.check(L.hip().dl4j_lstm_diag_bwd(L.ptr(E), _p1(rw4t), _p1(None), _p1(st["SV"]), _p1(st["Cs"]), _p1(st["c0"]),
                                            _p1(pf) if pf is not None else None, _p1(po) if pf is not None else None,
                                            _p1(pg) if pf is not None else None, _p1(dG), _p1(dpeep) if pf is not None else None, _p1(dc_ws),
                                            L.c_int(1), L.c_int(T), L.c_int(mb), L.c_int(n), L.c_int(0 if dt == torch.bfloat16 else 1),
-                                           L.stream()), "lstm_diag_bwd")
+                                           L.ptr(st["maskT"]), L.c_int(1 if reverse else 0), L.stream()), "lstm_diag_bwd")
         st["dc0_grad"] = dc_ws[(T - 1) % 2]
         return dG, _hprev(st, reverse), (None if dpeep is None else [dpeep[0], dpeep[1], dpeep[2]])
     if persist_ok(E, rw4t, mb, n) and st["SV"] is not None:
