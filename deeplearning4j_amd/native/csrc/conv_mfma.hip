@@ -220,6 +220,9 @@ static int dispatch_gemm(GemmP& p, int tile, int batch, hipStream_t st) {
     case 7: return launch_gemm<Cfg<64, 64, 2, 2, 3, 16, DT>, OT>(p, batch, st);
     case 8: return launch_gemm<Cfg<64, 128, 2, 2, 3, 16, DT>, OT>(p, batch, st);
     case 9: return launch_gemm<Cfg<64, 64, 2, 2, 4, 16, DT>, OT>(p, batch, st);
+    // 128 x 96 (four waves stacked in M, each 32 x 96): N = 768 / 3072 are multiples of 96, and 4096 x 768 is exactly 256 workgroups
+    case 11: return launch_gemm<Cfg<128, 96, 4, 1, 2, 16, DT>, OT>(p, batch, st);
+    case 12: return launch_gemm<Cfg<96, 128, 1, 4, 2, 16, DT>, OT>(p, batch, st);
     default: return -2;
   }
 }

@@ -16,7 +16,8 @@ import torch
 
 from ..native import lib as L
 
-TILES = ((128, 128), (128, 64), (64, 64), (64, 128), (256, 256), (128, 128), (128, 64), (64, 64), (64, 128), (64, 64), (256, 256))   # 5..9: deeper pipelines of 0..3 / 2; 10: ping-pong with half-tile staging
+TILES = ((128, 128), (128, 64), (64, 64), (64, 128), (256, 256), (128, 128), (128, 64), (64, 64), (64, 128), (64, 64), (256, 256),
+         (128, 96), (96, 128))   # 5..9: deeper pipelines of 0..3 / 2; 10: ping-pong with half-tile staging; 11 / 12: 96-wide tiles (4 x 1 / 1 x 4 waves)
 _DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 ACTS = {None: 0, "identity": 0, "relu": 1, "gelu": 2, "gelu_tanh": 2, "gelu_erf": 3, "tanh": 4, "sigmoid": 5}
 
