@@ -10,11 +10,11 @@
 // Gate order [r | u | c] (libnd4j): r = sigmoid(xz_r + hz_r), u = sigmoid(xz_u + hz_u), c = tanh(xz_c + r * hz_c),
 // h = u * h_prev + (1 - u) * c, with xz = x . Wx + b (one big GEMM outside) and hz = h_prev . Wh.
 //
-// Forward step: workgroup w owns hidden units [8w, 8w + 8) = 24 gate columns {g * n + 8w + k} (rows 24..31 of the 32-row MFMA tile
-// are fed zeros); 16 waves = (K quarter) x (32-row batch tile); v_mfma_f32_32x32x16_bf16 with A = the gate rows of Wh^T [3n, n]
+// Forward step: a workgroup owns 8 hidden units = 24 gate columns {g * n + 8w + k} (rows 24..31 of the 32-row MFMA tile are fed
+// zeros) x 32 batch rows; its waves split K; v_mfma_f32_32x32x16_bf16 with A = the gate rows of Wh^T [3n, n]
 // (K-contiguous) and B = h_{t-1} rows, both straight from L2 into registers. In the accumulator layout lane l holds, for batch row
 // l % 32, the three gates (register group = gate) of units 4 * (l / 32) + j, so the cell runs in registers and h_t leaves as one
-// 8-byte store per lane. K quarters 1..3 hand their partial sums to quarter 0 through LDS.
+// 8-byte store per lane. Waves 1.. hand their partial sums to wave 0 through LDS.
 //
 // Backward step: dh_t = E_t + u_{t+1} * dh_{t+1} (carried in fp32) + dHZ_{t+1} . Wh^T (v_mfma_f32_16x16x32_bf16, K = 3n), then the
 // cell backward in registers writes dXZ_t (gradient of the input projection, = of x . Wx + b) and dHZ_t (gradient of h_{t-1} . Wh).
@@ -52,23 +52,51 @@ struct GruFwdP {
   int mb, n;
 };
 
-#define GRU_THREADS 1024
-#define GRU_KSTEPS 8         // 16-wide K-steps per wave held in registers at once (n <= 512 in one pass, longer n loops)
+// Decomposition (both kernels): ONE MFMA tile per workgroup, its K range split over the GRU_WAVES waves in whole k-steps, partial
+// tiles summed through LDS by wave 0, which runs the cell. These kernels are bound by operand bytes per CU (every byte comes from L2);
+// the first form (8 units x all batch rows per workgroup, 16 waves = K quarter x batch tile, backward K loop left rolled by the
+// compiler into load, load, wait, MFMA) moved three times the bytes per workgroup - the same finding as lstm_persist.hip's
+// lstm_diag_*_kernel, measured in profiles/r3_lstm_layer_microbench.md.
+#define GRU_WAVES 8
+#define GRU_LOG2W 3
+#define GRU_THREADS (64 * GRU_WAVES)
+#define GRU_KSTEPS 8         // k-steps per wave held in registers at once (n <= 1024 forward, n <= 680 backward in one pass)
 
+// Forward: workgroup = hidden units [8 bx, 8 bx + 8) = 24 gate rows {g * n + 8 bx + k} (rows 24..31 of the 32-row MFMA tile are fed
+// zeros) x batch rows [32 by, 32 by + 32).
 __global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP p) {
-  __shared__ __attribute__((aligned(16))) f32x16 red[3 * 4 * 64];       // partial accumulators of K quarters 1..3 [3][4 tiles][64 lanes]
+  __shared__ __attribute__((aligned(16))) f32x16 red[(GRU_WAVES - 1) * 64];
   const int n = p.n, mb = p.mb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = wave & 3, kp = wave >> 2;
   const int u0 = blockIdx.x * 8;
-  const int row = tile * 32 + (lane & 31);
+  const int row = blockIdx.y * 32 + (lane & 31);
   const int kq = lane >> 5;
   const int uq = u0 + kq * 4;
-  const bool tile_on = tile * 32 < mb;
   const bool row_ok = row < mb;
-  const bool cell_lane = tile_on && row_ok && kp == 0;
-  const int Kq = n >> 2;
-  // everything this wave needs is requested back to back: one exposed memory latency per step
+  const bool cell_lane = wave == 0 && row_ok;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  {
+    const int gc = lane & 31;                                            // row of the MFMA tile: gate * 8 + unit; gate 3 is padding
+    const bool a_on = gc < 24;
+    const bf16_t* ap = p.wh_t + ((int64_t)(a_on ? (gc >> 3) : 0) * n + u0 + (gc & 7)) * p.ld + kq * 8;
+    const bf16_t* bp = p.hprev + (int64_t)(row_ok ? row : 0) * n + kq * 8;
+    const bf16x8_t zero = {};
+    const int S = n >> 4, s0 = (wave * S) >> GRU_LOG2W, s1 = ((wave + 1) * S) >> GRU_LOG2W;
+    for (int sb = s0; sb < s1; sb += GRU_KSTEPS) {
+      bf16x8_t a[GRU_KSTEPS], b[GRU_KSTEPS];
+#pragma unroll
+      for (int i = 0; i < GRU_KSTEPS; ++i) {
+        const int k = (sb + i) << 4;
+        a[i] = (sb + i < s1 && a_on) ? *(const bf16x8_t*)(ap + k) : zero;
+        b[i] = (sb + i < s1 && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < GRU_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+    }
+  }
+  // wave 0 owns the cell: its operands travel while the other waves hand their partial tiles over
   uint64_t xr = 0, xu = 0, xc = 0, hpv = 0;
   if (cell_lane) {
     const bf16_t* xp = p.xz + (int64_t)row * 3 * n + uq;
@@ -77,33 +105,12 @@ __global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP p) {
     xc = *(const uint64_t*)(xp + 2 * (int64_t)n);
     hpv = *(const uint64_t*)(p.hprev + (int64_t)row * n + uq);
   }
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  if (tile_on) {
-    const int gc = lane & 31;                                            // row of the MFMA tile: gate * 8 + unit; gate 3 is padding
-    const bool a_on = gc < 24;
-    const bf16_t* ap = p.wh_t + ((int64_t)(a_on ? (gc >> 3) : 0) * n + u0 + (gc & 7)) * p.ld + kp * Kq + kq * 8;
-    const bf16_t* bp = p.hprev + (int64_t)(row_ok ? row : 0) * n + kp * Kq + kq * 8;
-    const bf16x8_t zero = {};
-    for (int k0 = 0; k0 < Kq; k0 += 16 * GRU_KSTEPS) {
-      bf16x8_t a[GRU_KSTEPS], b[GRU_KSTEPS];
-#pragma unroll
-      for (int i = 0; i < GRU_KSTEPS; ++i) {
-        const int k = k0 + 16 * i;
-        a[i] = (k < Kq && a_on) ? *(const bf16x8_t*)(ap + k) : zero;
-        b[i] = (k < Kq && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
-      }
-#pragma unroll
-      for (int i = 0; i < GRU_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
-    }
-    if (kp > 0) red[((kp - 1) * 4 + tile) * 64 + lane] = acc;
-  }
+  if (wave > 0) red[(wave - 1) * 64 + lane] = acc;
   __syncthreads();
   if (!cell_lane) return;
-#pragma unroll
-  for (int kk = 0; kk < 3; ++kk) {
-    const f32x16 part = red[(kk * 4 + tile) * 64 + lane];
+#pragma unroll 3
+  for (int w = 0; w < GRU_WAVES - 1; ++w) {
+    const f32x16 part = red[w * 64 + lane];
     acc += part;
   }
   float fr[4], fu[4], fc[4], hp[4], hn[4], vr[4], vu[4], vc[4], vh[4];
@@ -141,90 +148,78 @@ struct GruBwdP {
   int mb, n;
 };
 
-#define GRU_BWD_TILES 2      // 16-row batch tiles per wave: mb <= 4 waves * 2 * 16 = 128
-
+// Backward: workgroup = hidden units [16 bx, 16 bx + 16) x batch rows [16 by, 16 by + 16): one 16x16 MFMA tile, K = 3n.
 __global__ void __launch_bounds__(GRU_THREADS) gru_step_bwd_kernel(GruBwdP p) {
-  __shared__ __attribute__((aligned(16))) f32x4 red[GRU_BWD_TILES * 3 * 4 * 64];
+  __shared__ __attribute__((aligned(16))) f32x4 red[(GRU_WAVES - 1) * 64];
   const int n = p.n, mb = p.mb, K = 3 * p.n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile0 = wave & 3, kq4 = wave >> 2;
-  const int u0 = blockIdx.x * 8;
+  const int u0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
   const int bcol = lane & 15, q = lane >> 4;
-  const bool unit_lane = q < 2 && kq4 == 0;
-  const int uq = u0 + (q & 1) * 4;
-  const int Kq = K >> 2;
-  const bf16_t* ap = p.wh + (int64_t)(u0 + (bcol & 7)) * p.ld + kq4 * Kq + q * 8;
-  f32x4 acc[GRU_BWD_TILES];
-  uint64_t ev[GRU_BWD_TILES], svr[GRU_BWD_TILES], svu[GRU_BWD_TILES], svc[GRU_BWD_TILES], svh[GRU_BWD_TILES], hpv[GRU_BWD_TILES];
-  f32x4 carry[GRU_BWD_TILES];
+  const int row = r0 + bcol;
+  const bool row_ok = row < mb;
+  const int uq = u0 + q * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (p.dhz_next != nullptr) {
+    const bf16_t* ap = p.wh + (int64_t)(u0 + bcol) * p.ld + q * 8;
+    const bf16_t* bp = p.dhz_next + (int64_t)(row_ok ? row : 0) * K + q * 8;
+    const bf16x8_t zero = {};
+    const int S = K >> 5, s0 = (wave * S) >> GRU_LOG2W, s1 = ((wave + 1) * S) >> GRU_LOG2W;      // 32-wide k-steps of this wave
+    for (int sb = s0; sb < s1; sb += GRU_KSTEPS) {
+      bf16x8_t a[GRU_KSTEPS], b[GRU_KSTEPS];
 #pragma unroll
-  for (int tt = 0; tt < GRU_BWD_TILES; ++tt) {
-    const int tile = tile0 + 4 * tt;
-    acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    carry[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    ev[tt] = svr[tt] = svu[tt] = svc[tt] = svh[tt] = hpv[tt] = 0ull;
-    if (tile * 16 >= mb) continue;
-    const int row = tile * 16 + bcol;
-    const bool row_ok = row < mb;
-    if (unit_lane && row_ok) {
-      const int64_t hidx = (int64_t)row * n + uq;
-      ev[tt] = *(const uint64_t*)(p.E + hidx);
-      const bf16_t* sv = p.SV + (int64_t)row * 4 * n + uq;
-      svr[tt] = *(const uint64_t*)(sv); svu[tt] = *(const uint64_t*)(sv + n);
-      svc[tt] = *(const uint64_t*)(sv + 2 * (int64_t)n); svh[tt] = *(const uint64_t*)(sv + 3 * (int64_t)n);
-      hpv[tt] = *(const uint64_t*)(p.hprev + hidx);
-      if (p.dhp_in) carry[tt] = *(const f32x4*)(p.dhp_in + hidx);
-    }
-    if (p.dhz_next != nullptr) {
-      const bf16_t* bp = p.dhz_next + (int64_t)(row_ok ? row : 0) * K + kq4 * Kq + q * 8;
-      const bf16x8_t zero = {};
-#pragma unroll 12
-      for (int k = 0; k < Kq; k += 32) {
-        const bf16x8_t a = *(const bf16x8_t*)(ap + k);
-        bf16x8_t b = *(const bf16x8_t*)(bp + k);
-        b = row_ok ? b : zero;
-        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[tt], 0, 0, 0);
+      for (int i = 0; i < GRU_KSTEPS; ++i) {
+        const int k = (sb + i) << 5;
+        a[i] = sb + i < s1 ? *(const bf16x8_t*)(ap + k) : zero;
+        b[i] = (sb + i < s1 && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
       }
-      if (kq4 > 0) red[((tt * 3 + (kq4 - 1)) * 4 + tile0) * 64 + lane] = acc[tt];
+#pragma unroll
+      for (int i = 0; i < GRU_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[i], acc, 0, 0, 0);
     }
   }
-  __syncthreads();
-#pragma unroll
-  for (int tt = 0; tt < GRU_BWD_TILES; ++tt) {
-    const int tile = tile0 + 4 * tt;
-    if (tile * 16 >= mb) continue;
-    const int row = tile * 16 + bcol;
-    if (!(unit_lane && row < mb)) continue;
-    if (p.dhz_next != nullptr) {
-#pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        const f32x4 part = red[((tt * 3 + kk) * 4 + tile0) * 64 + lane];
-        acc[tt] += part;
-      }
-    }
-    float e4[4], r4[4], u4[4], c4[4], h4[4], hp4[4];
-    g_unpack4(ev[tt], e4); g_unpack4(svr[tt], r4); g_unpack4(svu[tt], u4); g_unpack4(svc[tt], c4); g_unpack4(svh[tt], h4);
-    g_unpack4(hpv[tt], hp4);
-    float dr[4], du[4], dc[4], dcr[4];
-    f32x4 dpo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float d = e4[j] + acc[tt][j] + carry[tt][j];
-      const float r = r4[j], u = u4[j], c = c4[j];
-      dc[j] = d * (1.f - u) * (1.f - c * c);
-      du[j] = d * (hp4[j] - c) * u * (1.f - u);
-      dr[j] = dc[j] * h4[j] * r * (1.f - r);
-      dcr[j] = dc[j] * r;
-      dpo[j] = d * u;
-    }
+  uint64_t ev = 0, svr = 0, svu = 0, svc = 0, svh = 0, hpv = 0;
+  f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+  const bool cell_lane = wave == 0 && row_ok;
+  if (cell_lane) {
     const int64_t hidx = (int64_t)row * n + uq;
-    *(f32x4*)(p.dhp_out + hidx) = dpo;
-    bf16_t* gx = p.dxz + (int64_t)row * K + uq;
-    bf16_t* gh = p.dhz + (int64_t)row * K + uq;
-    const uint64_t pr = g_pack4(dr[0], dr[1], dr[2], dr[3]), pu = g_pack4(du[0], du[1], du[2], du[3]);
-    *(uint64_t*)(gx) = pr; *(uint64_t*)(gx + n) = pu; *(uint64_t*)(gx + 2 * (int64_t)n) = g_pack4(dc[0], dc[1], dc[2], dc[3]);
-    *(uint64_t*)(gh) = pr; *(uint64_t*)(gh + n) = pu; *(uint64_t*)(gh + 2 * (int64_t)n) = g_pack4(dcr[0], dcr[1], dcr[2], dcr[3]);
+    ev = *(const uint64_t*)(p.E + hidx);
+    const bf16_t* sv = p.SV + (int64_t)row * 4 * n + uq;
+    svr = *(const uint64_t*)(sv); svu = *(const uint64_t*)(sv + n);
+    svc = *(const uint64_t*)(sv + 2 * (int64_t)n); svh = *(const uint64_t*)(sv + 3 * (int64_t)n);
+    hpv = *(const uint64_t*)(p.hprev + hidx);
+    if (p.dhp_in) carry = *(const f32x4*)(p.dhp_in + hidx);
   }
+  if (p.dhz_next != nullptr && wave > 0) red[(wave - 1) * 64 + lane] = acc;
+  __syncthreads();
+  if (!cell_lane) return;
+  if (p.dhz_next != nullptr) {
+#pragma unroll
+    for (int w = 0; w < GRU_WAVES - 1; ++w) {
+      const f32x4 part = red[w * 64 + lane];
+      acc += part;
+    }
+  }
+  float e4[4], r4[4], u4[4], c4[4], h4[4], hp4[4];
+  g_unpack4(ev, e4); g_unpack4(svr, r4); g_unpack4(svu, u4); g_unpack4(svc, c4); g_unpack4(svh, h4);
+  g_unpack4(hpv, hp4);
+  float dr[4], du[4], dc[4], dcr[4];
+  f32x4 dpo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float d = e4[j] + acc[j] + carry[j];
+    const float r = r4[j], u = u4[j], c = c4[j];
+    dc[j] = d * (1.f - u) * (1.f - c * c);
+    du[j] = d * (hp4[j] - c) * u * (1.f - u);
+    dr[j] = dc[j] * h4[j] * r * (1.f - r);
+    dcr[j] = dc[j] * r;
+    dpo[j] = d * u;
+  }
+  const int64_t hidx = (int64_t)row * n + uq;
+  *(f32x4*)(p.dhp_out + hidx) = dpo;
+  bf16_t* gx = p.dxz + (int64_t)row * K + uq;
+  bf16_t* gh = p.dhz + (int64_t)row * K + uq;
+  const uint64_t pr = g_pack4(dr[0], dr[1], dr[2], dr[3]), pu = g_pack4(du[0], du[1], du[2], du[3]);
+  *(uint64_t*)(gx) = pr; *(uint64_t*)(gx + n) = pu; *(uint64_t*)(gx + 2 * (int64_t)n) = g_pack4(dc[0], dc[1], dc[2], dc[3]);
+  *(uint64_t*)(gh) = pr; *(uint64_t*)(gh + n) = pu; *(uint64_t*)(gh + 2 * (int64_t)n) = g_pack4(dcr[0], dcr[1], dcr[2], dcr[3]);
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -244,7 +239,7 @@ DL4J_API int dl4j_gru_steps_fwd(const void* xz, const void* wh_t, int64_t ld, co
   const bf16_t* hp = (const bf16_t*)h0;
   for (int t = 0; t < T; ++t) {
     GruFwdP p{(const bf16_t*)xz + 3 * t * hn, (const bf16_t*)wh_t, ld, hp, (bf16_t*)H + t * hn, SV ? (bf16_t*)SV + 4 * t * hn : nullptr, mb, n};
-    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(n / 8), dim3(GRU_THREADS), 0, st, p);
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(n / 8, (mb + 31) / 32), dim3(GRU_THREADS), 0, st, p);
     hp = (const bf16_t*)H + t * hn;
   }
   DL4J_RET_LAST();
@@ -267,7 +262,7 @@ DL4J_API int dl4j_gru_steps_bwd(const void* E, const void* wh, int64_t ld, const
     GruBwdP p{(const bf16_t*)E + t * hn, (const bf16_t*)wh, ld, (const bf16_t*)SV + 4 * t * hn, t > 0 ? (const bf16_t*)H + (t - 1) * hn : (const bf16_t*)h0,
               t == T - 1 ? nullptr : (const bf16_t*)dHZ + 3 * (t + 1) * hn, t == T - 1 ? nullptr : carry + (size_t)(half ^ 1) * hn,
               (bf16_t*)dXZ + 3 * t * hn, (bf16_t*)dHZ + 3 * t * hn, carry + (size_t)half * hn, mb, n};
-    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(n / 8), dim3(GRU_THREADS), 0, st, p);
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(n / 16, (mb + 15) / 16), dim3(GRU_THREADS), 0, st, p);
     last = half;
   }
   const int rc = (int)hipGetLastError();
