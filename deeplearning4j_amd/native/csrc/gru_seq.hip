@@ -42,13 +42,45 @@ __device__ __forceinline__ void g_unpack4(uint64_t v, float o[4]) {
   o[2] = bf2f((bf16_t)((v >> 32) & 0xffff)); o[3] = bf2f((bf16_t)(v >> 48));
 }
 
+
+// element-type traits (as lstm_persist.hip's DiagBf16 / DiagF32): bf16 on MFMA 32x32x16 / 16x16x32, fp32 on 32x32x2 / 16x16x4 with one
+// 16-byte load (4 K values per lane) feeding 4 MFMAs
+struct GruBf16 {
+  typedef bf16_t T;
+  typedef bf16x8_t vec;
+  static constexpr int FSTEP = 16, FLANE = 8, BSTEP = 32, BLANE = 8;
+  static __device__ __forceinline__ void mfma_f(f32x16& acc, const vec& a, const vec& b) { acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0); }
+  static __device__ __forceinline__ void mfma_b(f32x4& acc, const vec& a, const vec& b) { acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0); }
+  static __device__ __forceinline__ void ld4(const T* p, float o[4]) { g_unpack4(*(const uint64_t*)p, o); }
+  static __device__ __forceinline__ void st4(T* p, float a, float b, float c, float d) { *(uint64_t*)p = g_pack4(a, b, c, d); }
+};
+struct GruF32 {
+  typedef float T;
+  typedef f32x4 vec;
+  static constexpr int FSTEP = 8, FLANE = 4, BSTEP = 16, BLANE = 4;
+  static __device__ __forceinline__ void mfma_f(f32x16& acc, const vec& a, const vec& b) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], b[c], acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void mfma_b(f32x4& acc, const vec& a, const vec& b) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void ld4(const T* p, float o[4]) {
+    const f32x4 v = *(const f32x4*)p;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+  }
+  static __device__ __forceinline__ void st4(T* p, float a, float b, float c, float d) { *(f32x4*)p = f32x4{a, b, c, d}; }
+};
+
+template <typename E>
 struct GruFwdP {
-  const bf16_t* xz;        // [mb, 3n] input projection + bias of THIS step
-  const bf16_t* wh_t;      // [3n, ld] recurrent weights transposed: row = gate column, K = n contiguous
+  const E* xz;        // [mb, 3n] input projection + bias of THIS step
+  const E* wh_t;      // [3n, ld] recurrent weights transposed: row = gate column, K = n contiguous
   int64_t ld;
-  const bf16_t* hprev;     // [mb, n]
-  bf16_t* H;               // [mb, n]
-  bf16_t* SV;              // [mb, 4n] saved r, u, c, hz_c - or null (inference)
+  const E* hprev;     // [mb, n]
+  E* H;               // [mb, n]
+  E* SV;              // [mb, 4n] saved r, u, c, hz_c - or null (inference)
   int mb, n;
 };
 
@@ -64,7 +96,10 @@ struct GruFwdP {
 
 // Forward: workgroup = hidden units [8 bx, 8 bx + 8) = 24 gate rows {g * n + 8 bx + k} (rows 24..31 of the 32-row MFMA tile are fed
 // zeros) x batch rows [32 by, 32 by + 32).
-__global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP p) {
+template <typename TR>
+__global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP<typename TR::T> p) {
+  typedef typename TR::T T;
+  typedef typename TR::vec vec;
   __shared__ __attribute__((aligned(16))) f32x16 red[(GRU_WAVES - 1) * 64];
   const int n = p.n, mb = p.mb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -80,30 +115,28 @@ __global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP p) {
   {
     const int gc = lane & 31;                                            // row of the MFMA tile: gate * 8 + unit; gate 3 is padding
     const bool a_on = gc < 24;
-    const bf16_t* ap = p.wh_t + ((int64_t)(a_on ? (gc >> 3) : 0) * n + u0 + (gc & 7)) * p.ld + kq * 8;
-    const bf16_t* bp = p.hprev + (int64_t)(row_ok ? row : 0) * n + kq * 8;
-    const bf16x8_t zero = {};
-    const int S = n >> 4, s0 = (wave * S) >> GRU_LOG2W, s1 = ((wave + 1) * S) >> GRU_LOG2W;
+    const T* ap = p.wh_t + ((int64_t)(a_on ? (gc >> 3) : 0) * n + u0 + (gc & 7)) * p.ld + kq * TR::FLANE;
+    const T* bp = p.hprev + (int64_t)(row_ok ? row : 0) * n + kq * TR::FLANE;
+    const vec zero = {};
+    const int S = n / TR::FSTEP, s0 = (wave * S) >> GRU_LOG2W, s1 = ((wave + 1) * S) >> GRU_LOG2W;
     for (int sb = s0; sb < s1; sb += GRU_KSTEPS) {
-      bf16x8_t a[GRU_KSTEPS], b[GRU_KSTEPS];
+      vec a[GRU_KSTEPS], b[GRU_KSTEPS];
 #pragma unroll
       for (int i = 0; i < GRU_KSTEPS; ++i) {
-        const int k = (sb + i) << 4;
-        a[i] = (sb + i < s1 && a_on) ? *(const bf16x8_t*)(ap + k) : zero;
-        b[i] = (sb + i < s1 && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+        const int k = (sb + i) * TR::FSTEP;
+        a[i] = (sb + i < s1 && a_on) ? *(const vec*)(ap + k) : zero;
+        b[i] = (sb + i < s1 && row_ok) ? *(const vec*)(bp + k) : zero;
       }
 #pragma unroll
-      for (int i = 0; i < GRU_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc, 0, 0, 0);
+      for (int i = 0; i < GRU_KSTEPS; ++i) TR::mfma_f(acc, a[i], b[i]);
     }
   }
   // wave 0 owns the cell: its operands travel while the other waves hand their partial tiles over
-  uint64_t xr = 0, xu = 0, xc = 0, hpv = 0;
+  float fr[4] = {0, 0, 0, 0}, fu[4] = {0, 0, 0, 0}, fc[4] = {0, 0, 0, 0}, hp[4] = {0, 0, 0, 0};
   if (cell_lane) {
-    const bf16_t* xp = p.xz + (int64_t)row * 3 * n + uq;
-    xr = *(const uint64_t*)(xp);
-    xu = *(const uint64_t*)(xp + n);
-    xc = *(const uint64_t*)(xp + 2 * (int64_t)n);
-    hpv = *(const uint64_t*)(p.hprev + (int64_t)row * n + uq);
+    const T* xp = p.xz + (int64_t)row * 3 * n + uq;
+    TR::ld4(xp, fr); TR::ld4(xp + n, fu); TR::ld4(xp + 2 * (int64_t)n, fc);
+    TR::ld4(p.hprev + (int64_t)row * n + uq, hp);
   }
   if (wave > 0) red[(wave - 1) * 64 + lane] = acc;
   __syncthreads();
@@ -113,8 +146,7 @@ __global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP p) {
     const f32x16 part = red[w * 64 + lane];
     acc += part;
   }
-  float fr[4], fu[4], fc[4], hp[4], hn[4], vr[4], vu[4], vc[4], vh[4];
-  g_unpack4(xr, fr); g_unpack4(xu, fu); g_unpack4(xc, fc); g_unpack4(hpv, hp);
+  float hn[4], vr[4], vu[4], vc[4], vh[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float r = g_sigm(fr[j] + acc[j]);
@@ -124,32 +156,36 @@ __global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP p) {
     vr[j] = r; vu[j] = u; vc[j] = c; vh[j] = hc;
     hn[j] = u * hp[j] + (1.f - u) * c;
   }
-  *(uint64_t*)(p.H + (int64_t)row * n + uq) = g_pack4(hn[0], hn[1], hn[2], hn[3]);
+  TR::st4(p.H + (int64_t)row * n + uq, hn[0], hn[1], hn[2], hn[3]);
   if (p.SV) {
-    bf16_t* sv = p.SV + (int64_t)row * 4 * n + uq;
-    *(uint64_t*)(sv) = g_pack4(vr[0], vr[1], vr[2], vr[3]);
-    *(uint64_t*)(sv + n) = g_pack4(vu[0], vu[1], vu[2], vu[3]);
-    *(uint64_t*)(sv + 2 * (int64_t)n) = g_pack4(vc[0], vc[1], vc[2], vc[3]);
-    *(uint64_t*)(sv + 3 * (int64_t)n) = g_pack4(vh[0], vh[1], vh[2], vh[3]);
+    T* sv = p.SV + (int64_t)row * 4 * n + uq;
+    TR::st4(sv, vr[0], vr[1], vr[2], vr[3]);
+    TR::st4(sv + n, vu[0], vu[1], vu[2], vu[3]);
+    TR::st4(sv + 2 * (int64_t)n, vc[0], vc[1], vc[2], vc[3]);
+    TR::st4(sv + 3 * (int64_t)n, vh[0], vh[1], vh[2], vh[3]);
   }
 }
 
+template <typename EL>
 struct GruBwdP {
-  const bf16_t* E;         // [mb, n] dL/dh_t from the layers above (this step)
-  const bf16_t* wh;        // [n, ld] row j = the 3n gate weights leaving hidden unit j (K = 3n contiguous)
+  const EL* E;         // [mb, n] dL/dh_t from the layers above (this step)
+  const EL* wh;        // [n, ld] row j = the 3n gate weights leaving hidden unit j (K = 3n contiguous)
   int64_t ld;
-  const bf16_t* SV;        // [mb, 4n] of this step
-  const bf16_t* hprev;     // [mb, n]
-  const bf16_t* dhz_next;  // [mb, 3n] gradient of hz of the step processed before this one, or null
+  const EL* SV;        // [mb, 4n] of this step
+  const EL* hprev;     // [mb, n]
+  const EL* dhz_next;  // [mb, 3n] gradient of hz of the step processed before this one, or null
   const float* dhp_in;     // [mb, n] fp32 u_{t+1} * dh_{t+1}, or null
-  bf16_t* dxz;             // [mb, 3n]
-  bf16_t* dhz;             // [mb, 3n]
+  EL* dxz;             // [mb, 3n]
+  EL* dhz;             // [mb, 3n]
   float* dhp_out;          // [mb, n] fp32
   int mb, n;
 };
 
 // Backward: workgroup = hidden units [16 bx, 16 bx + 16) x batch rows [16 by, 16 by + 16): one 16x16 MFMA tile, K = 3n.
-__global__ void __launch_bounds__(GRU_THREADS) gru_step_bwd_kernel(GruBwdP p) {
+template <typename TR>
+__global__ void __launch_bounds__(GRU_THREADS) gru_step_bwd_kernel(GruBwdP<typename TR::T> p) {
+  typedef typename TR::T T;
+  typedef typename TR::vec vec;
   __shared__ __attribute__((aligned(16))) f32x4 red[(GRU_WAVES - 1) * 64];
   const int n = p.n, mb = p.mb, K = 3 * p.n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,32 +196,31 @@ __global__ void __launch_bounds__(GRU_THREADS) gru_step_bwd_kernel(GruBwdP p) {
   const int uq = u0 + q * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (p.dhz_next != nullptr) {
-    const bf16_t* ap = p.wh + (int64_t)(u0 + bcol) * p.ld + q * 8;
-    const bf16_t* bp = p.dhz_next + (int64_t)(row_ok ? row : 0) * K + q * 8;
-    const bf16x8_t zero = {};
-    const int S = K >> 5, s0 = (wave * S) >> GRU_LOG2W, s1 = ((wave + 1) * S) >> GRU_LOG2W;      // 32-wide k-steps of this wave
+    const T* ap = p.wh + (int64_t)(u0 + bcol) * p.ld + q * TR::BLANE;
+    const T* bp = p.dhz_next + (int64_t)(row_ok ? row : 0) * K + q * TR::BLANE;
+    const vec zero = {};
+    const int S = K / TR::BSTEP, s0 = (wave * S) >> GRU_LOG2W, s1 = ((wave + 1) * S) >> GRU_LOG2W;      // 32-wide k-steps of this wave
     for (int sb = s0; sb < s1; sb += GRU_KSTEPS) {
-      bf16x8_t a[GRU_KSTEPS], b[GRU_KSTEPS];
+      vec a[GRU_KSTEPS], b[GRU_KSTEPS];
 #pragma unroll
       for (int i = 0; i < GRU_KSTEPS; ++i) {
-        const int k = (sb + i) << 5;
-        a[i] = sb + i < s1 ? *(const bf16x8_t*)(ap + k) : zero;
-        b[i] = (sb + i < s1 && row_ok) ? *(const bf16x8_t*)(bp + k) : zero;
+        const int k = (sb + i) * TR::BSTEP;
+        a[i] = sb + i < s1 ? *(const vec*)(ap + k) : zero;
+        b[i] = (sb + i < s1 && row_ok) ? *(const vec*)(bp + k) : zero;
       }
 #pragma unroll
-      for (int i = 0; i < GRU_KSTEPS; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[i], acc, 0, 0, 0);
+      for (int i = 0; i < GRU_KSTEPS; ++i) TR::mfma_b(acc, a[i], b[i]);
     }
   }
-  uint64_t ev = 0, svr = 0, svu = 0, svc = 0, svh = 0, hpv = 0;
+  float e4[4] = {0, 0, 0, 0}, r4[4] = {0, 0, 0, 0}, u4[4] = {0, 0, 0, 0}, c4[4] = {0, 0, 0, 0}, h4[4] = {0, 0, 0, 0}, hp4[4] = {0, 0, 0, 0};
   f32x4 carry = {0.f, 0.f, 0.f, 0.f};
   const bool cell_lane = wave == 0 && row_ok;
   if (cell_lane) {
     const int64_t hidx = (int64_t)row * n + uq;
-    ev = *(const uint64_t*)(p.E + hidx);
-    const bf16_t* sv = p.SV + (int64_t)row * 4 * n + uq;
-    svr = *(const uint64_t*)(sv); svu = *(const uint64_t*)(sv + n);
-    svc = *(const uint64_t*)(sv + 2 * (int64_t)n); svh = *(const uint64_t*)(sv + 3 * (int64_t)n);
-    hpv = *(const uint64_t*)(p.hprev + hidx);
+    TR::ld4(p.E + hidx, e4);
+    const T* sv = p.SV + (int64_t)row * 4 * n + uq;
+    TR::ld4(sv, r4); TR::ld4(sv + n, u4); TR::ld4(sv + 2 * (int64_t)n, c4); TR::ld4(sv + 3 * (int64_t)n, h4);
+    TR::ld4(p.hprev + hidx, hp4);
     if (p.dhp_in) carry = *(const f32x4*)(p.dhp_in + hidx);
   }
   if (p.dhz_next != nullptr && wave > 0) red[(wave - 1) * 64 + lane] = acc;
@@ -198,9 +233,6 @@ __global__ void __launch_bounds__(GRU_THREADS) gru_step_bwd_kernel(GruBwdP p) {
       acc += part;
     }
   }
-  float e4[4], r4[4], u4[4], c4[4], h4[4], hp4[4];
-  g_unpack4(ev, e4); g_unpack4(svr, r4); g_unpack4(svu, u4); g_unpack4(svc, c4); g_unpack4(svh, h4);
-  g_unpack4(hpv, hp4);
   float dr[4], du[4], dc[4], dcr[4];
   f32x4 dpo;
 #pragma unroll
@@ -215,11 +247,10 @@ __global__ void __launch_bounds__(GRU_THREADS) gru_step_bwd_kernel(GruBwdP p) {
   }
   const int64_t hidx = (int64_t)row * n + uq;
   *(f32x4*)(p.dhp_out + hidx) = dpo;
-  bf16_t* gx = p.dxz + (int64_t)row * K + uq;
-  bf16_t* gh = p.dhz + (int64_t)row * K + uq;
-  const uint64_t pr = g_pack4(dr[0], dr[1], dr[2], dr[3]), pu = g_pack4(du[0], du[1], du[2], du[3]);
-  *(uint64_t*)(gx) = pr; *(uint64_t*)(gx + n) = pu; *(uint64_t*)(gx + 2 * (int64_t)n) = g_pack4(dc[0], dc[1], dc[2], dc[3]);
-  *(uint64_t*)(gh) = pr; *(uint64_t*)(gh + n) = pu; *(uint64_t*)(gh + 2 * (int64_t)n) = g_pack4(dcr[0], dcr[1], dcr[2], dcr[3]);
+  T* gx = p.dxz + (int64_t)row * K + uq;
+  T* gh = p.dhz + (int64_t)row * K + uq;
+  TR::st4(gx, dr[0], dr[1], dr[2], dr[3]); TR::st4(gx + n, du[0], du[1], du[2], du[3]); TR::st4(gx + 2 * (int64_t)n, dc[0], dc[1], dc[2], dc[3]);
+  TR::st4(gh, dr[0], dr[1], dr[2], dr[3]); TR::st4(gh + n, du[0], du[1], du[2], du[3]); TR::st4(gh + 2 * (int64_t)n, dcr[0], dcr[1], dcr[2], dcr[3]);
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -228,43 +259,60 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 DL4J_API int dl4j_gru_steps_supported(int mb, int n) { return (mb > 0 && mb <= 128 && n > 0 && n % 128 == 0 && n / 8 <= 4096) ? 1 : 0; }
 
-// xz [T, mb, 3n], wh_t [3n, ld], h0 [mb, n] -> H [T, mb, n], SV [T, mb, 4n] (null for inference). bf16.
-DL4J_API int dl4j_gru_steps_fwd(const void* xz, const void* wh_t, int64_t ld, const void* h0, void* H, void* SV, int T, int mb, int n,
-                                hipStream_t st) {
-  if (T <= 0) return 0;
-  if (!xz || !wh_t || !h0 || !H) return -3;
-  if (!dl4j_gru_steps_supported(mb, n) || ld < n || ld % 8 != 0 || !al16(xz) || !al16(wh_t) || !al16(h0) || !al16(H) || (SV && !al16(SV)))
-    return -2;
+template <typename TR>
+static int gru_fwd_t(const void* xz, const void* wh_t, int64_t ld, const void* h0, void* H, void* SV, int T, int mb, int n, hipStream_t st) {
+  typedef typename TR::T E;
   const size_t hn = (size_t)mb * n;
-  const bf16_t* hp = (const bf16_t*)h0;
+  const E* hp = (const E*)h0;
   for (int t = 0; t < T; ++t) {
-    GruFwdP p{(const bf16_t*)xz + 3 * t * hn, (const bf16_t*)wh_t, ld, hp, (bf16_t*)H + t * hn, SV ? (bf16_t*)SV + 4 * t * hn : nullptr, mb, n};
-    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(n / 8, (mb + 31) / 32), dim3(GRU_THREADS), 0, st, p);
-    hp = (const bf16_t*)H + t * hn;
+    GruFwdP<E> p{(const E*)xz + 3 * t * hn, (const E*)wh_t, ld, hp, (E*)H + t * hn, SV ? (E*)SV + 4 * t * hn : nullptr, mb, n};
+    hipLaunchKernelGGL((gru_step_fwd_kernel<TR>), dim3(n / 8, (mb + 31) / 32), dim3(GRU_THREADS), 0, st, p);
+    hp = (const E*)H + t * hn;
   }
   DL4J_RET_LAST();
 }
 
+// xz [T, mb, 3n], wh_t [3n, ld], h0 [mb, n] -> H [T, mb, n], SV [T, mb, 4n] (null for inference). dtype: 0 = bf16, 1 = fp32.
+DL4J_API int dl4j_gru_steps_fwd(const void* xz, const void* wh_t, int64_t ld, const void* h0, void* H, void* SV, int T, int mb, int n,
+                                int dtype, hipStream_t st) {
+  if (T <= 0) return 0;
+  if (!xz || !wh_t || !h0 || !H) return -3;
+  if (!dl4j_gru_steps_supported(mb, n) || ld < n || ld % 8 != 0 || !al16(xz) || !al16(wh_t) || !al16(h0) || !al16(H) || (SV && !al16(SV)))
+    return -2;
+  if (dtype == 0) return gru_fwd_t<GruBf16>(xz, wh_t, ld, h0, H, SV, T, mb, n, st);
+  if (dtype == 1) return gru_fwd_t<GruF32>(xz, wh_t, ld, h0, H, SV, T, mb, n, st);
+  return -2;
+}
+
+template <typename TR>
+static int gru_bwd_t(const void* Eg, const void* wh, int64_t ld, const void* SV, const void* H, const void* h0, void* dXZ, void* dHZ,
+                     float* carry, int T, int mb, int n, hipStream_t st) {
+  typedef typename TR::T E;
+  const size_t hn = (size_t)mb * n;
+  int last = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    const int half = (T - 1 - t) & 1;
+    GruBwdP<E> p{(const E*)Eg + t * hn, (const E*)wh, ld, (const E*)SV + 4 * t * hn, t > 0 ? (const E*)H + (t - 1) * hn : (const E*)h0,
+                 t == T - 1 ? nullptr : (const E*)dHZ + 3 * (t + 1) * hn, t == T - 1 ? nullptr : carry + (size_t)(half ^ 1) * hn,
+                 (E*)dXZ + 3 * t * hn, (E*)dHZ + 3 * t * hn, carry + (size_t)half * hn, mb, n};
+    hipLaunchKernelGGL((gru_step_bwd_kernel<TR>), dim3(n / 16, (mb + 15) / 16), dim3(GRU_THREADS), 0, st, p);
+    last = half;
+  }
+  const int rc = (int)hipGetLastError();
+  return rc ? -100 - rc : last;
+}
+
 // E [T, mb, n] (dL/dH), wh [n, ld] (ld >= 3n), SV [T, mb, 4n], H [T, mb, n], h0 [mb, n] -> dXZ, dHZ [T, mb, 3n]; carry [2, mb, n] fp32
-// scratch: on return carry[(T - 1) & 1 ... see below] holds u_0 * dh_0, the direct part of dL/dh0 (the caller adds dHZ_0 . Wh^T).
-// Returns the index (0 / 1) of the carry half that holds it, or a negative error code.
+// scratch: on return one half of it holds u_0 * dh_0, the direct part of dL/dh0 (the caller adds dHZ_0 . Wh^T).
+// Returns the index (0 / 1) of the carry half that holds it, or a negative error code. dtype: 0 = bf16, 1 = fp32.
 DL4J_API int dl4j_gru_steps_bwd(const void* E, const void* wh, int64_t ld, const void* SV, const void* H, const void* h0, void* dXZ, void* dHZ,
-                                float* carry, int T, int mb, int n, hipStream_t st) {
+                                float* carry, int T, int mb, int n, int dtype, hipStream_t st) {
   if (T <= 0) return 0;
   if (!E || !wh || !SV || !H || !h0 || !dXZ || !dHZ || !carry) return -3;
   if (!dl4j_gru_steps_supported(mb, n) || ld < 3 * (int64_t)n || ld % 8 != 0 || !al16(E) || !al16(wh) || !al16(SV) || !al16(H) || !al16(h0) ||
       !al16(dXZ) || !al16(dHZ) || !al16(carry))
     return -2;
-  const size_t hn = (size_t)mb * n;
-  int last = 0;
-  for (int t = T - 1; t >= 0; --t) {
-    const int half = (T - 1 - t) & 1;
-    GruBwdP p{(const bf16_t*)E + t * hn, (const bf16_t*)wh, ld, (const bf16_t*)SV + 4 * t * hn, t > 0 ? (const bf16_t*)H + (t - 1) * hn : (const bf16_t*)h0,
-              t == T - 1 ? nullptr : (const bf16_t*)dHZ + 3 * (t + 1) * hn, t == T - 1 ? nullptr : carry + (size_t)(half ^ 1) * hn,
-              (bf16_t*)dXZ + 3 * t * hn, (bf16_t*)dHZ + 3 * t * hn, carry + (size_t)half * hn, mb, n};
-    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(n / 16, (mb + 15) / 16), dim3(GRU_THREADS), 0, st, p);
-    last = half;
-  }
-  const int rc = (int)hipGetLastError();
-  return rc ? -100 - rc : last;
+  if (dtype == 0) return gru_bwd_t<GruBf16>(E, wh, ld, SV, H, h0, dXZ, dHZ, carry, T, mb, n, st);
+  if (dtype == 1) return gru_bwd_t<GruF32>(E, wh, ld, SV, H, h0, dXZ, dHZ, carry, T, mb, n, st);
+  return -2;
 }

@@ -266,8 +266,8 @@ def gru_cell_backward(dh, sv, hz, hprev):
 
 
 def gru_fused_ok(xz, n):
-    """bf16 sequences whose shape the fused step kernels (native/csrc/gru_seq.hip) take: one launch per step in each direction."""
-    return (os.environ.get("DL4J_AMD_GRU_FUSED", "1") != "0" and L.use_hip(xz) and xz.dtype == torch.bfloat16 and xz.dim() == 3
+    """bf16 / fp32 sequences whose shape the fused step kernels (native/csrc/gru_seq.hip) take: one launch per step in each direction."""
+    return (os.environ.get("DL4J_AMD_GRU_FUSED", "1") != "0" and L.use_hip(xz) and xz.dtype in (torch.bfloat16, torch.float32) and xz.dim() == 3
             and bool(L.hip().dl4j_gru_steps_supported(L.c_int(xz.shape[1]), L.c_int(n))))
 
 
@@ -285,7 +285,7 @@ class _GruSeqFused(torch.autograd.Function):
         SV = torch.empty(T, mb, 4 * n, device=xz.device, dtype=xz.dtype) if train else None
         h0c, xzc = h0.contiguous(), xz.contiguous()
         L.check(L.hip().dl4j_gru_steps_fwd(L.ptr(xzc), L.ptr(wh_t), L.c_int64(n), L.ptr(h0c), L.ptr(H), L.ptr(SV), L.c_int(T), L.c_int(mb),
-                                           L.c_int(n), L.stream()), "gru_steps_fwd")
+                                           L.c_int(n), L.c_int(0 if xz.dtype == torch.bfloat16 else 1), L.stream()), "gru_steps_fwd")
         ctx.save_for_backward(H, SV, h0c, Wh)
         return H
 
@@ -300,7 +300,8 @@ class _GruSeqFused(torch.autograd.Function):
         carry = torch.empty(2, mb, n, device=H.device, dtype=torch.float32)
         whc = Wh.contiguous()                                    # [n, 3n]: row j = gate weights leaving unit j
         rc = L.hip().dl4j_gru_steps_bwd(L.ptr(dH.contiguous()), L.ptr(whc), L.c_int64(3 * n), L.ptr(SV), L.ptr(H), L.ptr(h0), L.ptr(dXZ),
-                                        L.ptr(dHZ), L.ptr(carry), L.c_int(T), L.c_int(mb), L.c_int(n), L.stream())
+                                        L.ptr(dHZ), L.ptr(carry), L.c_int(T), L.c_int(mb), L.c_int(n),
+                                        L.c_int(0 if H.dtype == torch.bfloat16 else 1), L.stream())
         if rc < 0:
             raise RuntimeError("dl4j_gru_steps_bwd failed with status %d" % rc)
         dh0 = (carry[rc] + (dHZ[0] @ whc.t()).float()).to(H.dtype)

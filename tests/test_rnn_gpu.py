@@ -91,13 +91,14 @@ def test_gru_op_native_loop_matches_reference_math(dtype):
 
 
 @pytest.mark.parametrize("T,B,nIn,n", [(6, 64, 96, 128), (9, 100, 64, 256), (5, 128, 128, 512)])
-def test_gru_fused_step_kernels_match_torch_gru_forward_and_backward(T, B, nIn, n):
-    """gru_seq.hip (one launch per step per direction, bf16) against torch.nn.GRU in fp32 with the same weights: libnd4j's gate order
-    [r | u | c] is ATen's (r, z, n) and the candidate uses r * (h . Wh_c), so the two are the same function."""
+@pytest.mark.parametrize("bf", [torch.bfloat16, torch.float32])
+def test_gru_fused_step_kernels_match_torch_gru_forward_and_backward(T, B, nIn, n, bf):
+    """gru_seq.hip (one launch per step per direction, bf16 and fp32 instantiations) against torch.nn.GRU in fp32 with the same weights:
+    libnd4j's gate order [r | u | c] is ATen's (r, z, n) and the candidate uses r * (h . Wh_c), so the two are the same function."""
     from deeplearning4j_amd.nd4j.ops.custom import exec_op
     from deeplearning4j_amd.ops import lstm as R
     g = torch.Generator(device="cuda").manual_seed(11)
-    bf = torch.bfloat16
+    f32 = bf == torch.float32
     x = torch.randn(T, B, nIn, device="cuda", generator=g).to(bf)
     h0 = (torch.randn(B, n, device="cuda", generator=g) * 0.5).to(bf)
     Wx = (torch.randn(nIn, 3 * n, device="cuda", generator=g) / nIn ** 0.5).to(bf)
@@ -115,12 +116,12 @@ def test_gru_fused_step_kernels_match_torch_gru_forward_and_backward(T, B, nIn, 
     out = exec_op("gru", ins)[0]
     assert type(out.grad_fn).__name__.startswith("_GruSeqFused")
     scale = float(ref.abs().max())
-    assert (out.float() - ref).abs().max().item() < 3e-2 * max(1.0, scale)
+    assert (out.float() - ref).abs().max().item() < (2e-4 if f32 else 3e-2) * max(1.0, scale)
     gg = torch.autograd.grad(out, ins, dH.to(bf))
     for name, a_, r_ in zip(("dx", "dh0", "dWx", "dWh", "db"), gg, (rgx, rgh, rgwi.t(), rgwh.t(), rgb)):
         err = (a_.float() - r_).abs().max().item()
         cos = float((a_.float() * r_).sum() / (a_.float().norm() * r_.norm() + 1e-12))
-        assert cos > 0.995 and err < 6e-2 * max(1.0, r_.abs().max().item()), (name, err, cos)
+        assert cos > (0.999999 if f32 else 0.995) and err < (1e-3 if f32 else 6e-2) * max(1.0, r_.abs().max().item()), (name, err, cos)
     # inference form: no saved activations
     with torch.no_grad():
         out2 = exec_op("gru", [x, h0, Wx, Wh, b])[0]

@@ -75,7 +75,7 @@ def case(T, B, n, nIn=None):
             print("variant failed:", str(e)[:120], flush=True)
             return float("inf")
     rows["ours bf16 fwd+bwd"] = safe(lambda: ours(bf))
-    rows["ours fp32 fwd+bwd (per-step loop)"] = safe(lambda: ours(torch.float32))
+    rows["ours fp32 fwd+bwd"] = safe(lambda: ours(torch.float32))
     rows["torch.nn.GRU bf16 fwd+bwd"] = safe(lambda: torch_gru(bf))
     rows["torch.nn.GRU fp32 fwd+bwd"] = safe(lambda: torch_gru(torch.float32))
     rows["ours bf16 fwd"] = safe(lambda: fwd_only(bf))
