@@ -47,7 +47,9 @@ def main():
         sys.exit(2)
     force_dp = os.environ.get("DL4J_AMD_FORCE_COLLECTIVES") == "1"      # 1-GPU rehearsal of the DP code path (debug only)
     if world > 1 or force_dp:
-        comm.init_process_group("nccl")
+        # DL4J_AMD_DP_BACKEND=gloo: rehearsal of the multi-rank code path (capture cuts, bucket launches, parameter checksums) with
+        # several ranks on ONE GPU, where RCCL refuses duplicate devices; the driver's runs use RCCL
+        comm.init_process_group(os.environ.get("DL4J_AMD_DP_BACKEND", "nccl"))
     rank = comm.rank()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())

@@ -163,10 +163,7 @@ class CommWatchdog:
             with self._lock:
                 works = list(self._works)
             for w in works:
-                try:
-                    exc = w.exception() if w.is_completed() else None
-                except Exception as e:                    # querying a broken communicator may itself raise
-                    exc = e
+                exc = self._failed(w)
                 if exc is not None:
                     reason = "collective failed: %r" % (exc,)
                     break
@@ -186,6 +183,32 @@ class CommWatchdog:
                 self.failure = reason
                 self._fail(reason)
                 return
+
+    @staticmethod
+    def _failed(w):
+        """None while ``w`` is pending or has completed without an error, else what is known about the failure.
+        ``Work.exception()`` cannot be trusted on its own: torch 2.10's binding has no converter for its return type, so the call
+        raises TypeError for EVERY completed work, failed or not (seen in a 2-rank rehearsal, where the poll caught a finished work
+        and the watchdog ended two healthy ranks). A TypeError from it therefore means "ask differently": ``is_success()``."""
+        try:
+            if not w.is_completed():
+                return None
+        except Exception as e:                        # querying a broken communicator may itself raise
+            return e
+        try:
+            return w.exception()
+        except TypeError:
+            pass
+        except Exception as e:
+            return e
+        try:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ok = w.is_success()
+        except Exception:
+            return None                               # no way to ask: c10d's own error handling (init_process_group) stays in charge
+        return None if ok else RuntimeError("the collective completed without success")
 
     def _fail(self, reason):
         import sys

@@ -386,6 +386,54 @@ def _dying_worker(rank, world, port, out_dir):
     open(os.path.join(out_dir, "unreachable"), "w").write("1")
 
 
+def test_watchdog_does_not_mistake_an_unconvertible_exception_query_for_a_failure():
+    """torch 2.10: Work.exception() raises TypeError for every completed work (no converter for std::exception_ptr). A poll that
+    lands on a finished, healthy work must not end the rank; a finished work that reports no success must."""
+    import time
+    from deeplearning4j_amd.parallel.comm import CommWatchdog
+
+    class FakeWork:
+        def __init__(self, ok):
+            self.ok = ok
+
+        def is_completed(self):
+            return True
+
+        def exception(self):
+            raise TypeError("Unable to convert function return value to a Python type!")
+
+        def is_success(self):
+            return self.ok
+
+    seen = []
+    wd = CommWatchdog(timeout_s=60.0, poll_s=0.02, on_failure=seen.append)
+    try:
+        wd.busy(True)
+        wd.watch(FakeWork(True))
+        time.sleep(0.3)
+        assert wd.failure is None and not seen
+        wd.watch(FakeWork(False))
+        deadline = time.time() + 5
+        while not seen and time.time() < deadline:
+            time.sleep(0.02)
+        assert seen and "collective failed" in seen[0]
+    finally:
+        wd.stop()
+    # and a real (gloo, single-process) completed work is healthy
+    import torch.distributed as dist
+    if dist.is_available() and not dist.is_initialized():
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = "29631"
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        try:
+            w = dist.all_reduce(torch.ones(4), async_op=True)
+            w.wait()
+            assert CommWatchdog._failed(w) is None
+        finally:
+            dist.destroy_process_group()
+
+
 def test_watchdog_ends_the_surviving_rank_with_a_clean_nonzero_exit(tmp_path):
     """A peer dies between iterations: the survivor must not sit in the collective until the 600 s process-group timeout; the
     CommWatchdog ends it with EXIT_CODE (or the backend reports the broken connection first — also a prompt non-zero exit)."""
