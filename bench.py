@@ -32,6 +32,9 @@ def main():
 
     # stdout carries exactly ONE line (the JSON result of rank 0): RCCL prints a version banner to fd 1 when its first
     # communicator comes up, so fd 1 is pointed at stderr for the duration of the run and the result goes to the saved fd.
+    if os.environ.get("DL4J_AMD_BENCH_DUMP_AFTER"):          # debugging aid: all thread stacks to stderr after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DL4J_AMD_BENCH_DUMP_AFTER"]), exit=True)
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
@@ -60,7 +63,14 @@ def main():
     net = model.init(device=dev)
     if not args.no_graph:
         net.enableGraphCapture(True)
-    pw = ParallelWrapper.Builder(net).build() if (world > 1 or force_dp) else None
+    pw = None
+    if world > 1 or force_dp:
+        b = ParallelWrapper.Builder(net)
+        if os.environ.get("DL4J_AMD_DP_OVERLAP") == "0":         # debugging aids for rehearsals: synchronous reduction / no watchdog
+            b = b.overlap(False)
+        if os.environ.get("DL4J_AMD_DP_WATCHDOG") == "0":
+            b = b.watchdogTimeout(0)
+        pw = b.build()
 
     it = BenchmarkDataSetIterator([args.batch, 3, args.image, args.image], args.classes, 1, device=dev, seed=1234 + rank)
     ds = it.next()
