@@ -100,7 +100,10 @@ template <typename TR>
 __global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP<typename TR::T> p) {
   typedef typename TR::T T;
   typedef typename TR::vec vec;
-  __shared__ __attribute__((aligned(16))) f32x16 red[(GRU_WAVES - 1) * 64];
+  // partial tiles as [wave][4 register groups][64 lanes] of 16 bytes: a lane stride of 16 bytes keeps the 128-bit LDS accesses free of
+  // bank conflicts (as [wave][lane] of 64 bytes they ran at 6x the conflict-free cycle count, profiles/r3_pmc_sq_lstm.md - though
+  // the hand-off is short enough that the step time did not change)
+  __shared__ __attribute__((aligned(16))) f32x4 red[(GRU_WAVES - 1) * 4 * 64];
   const int n = p.n, mb = p.mb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * 8;
@@ -138,13 +141,19 @@ __global__ void __launch_bounds__(GRU_THREADS) gru_step_fwd_kernel(GruFwdP<typen
     TR::ld4(xp, fr); TR::ld4(xp + n, fu); TR::ld4(xp + 2 * (int64_t)n, fc);
     TR::ld4(p.hprev + (int64_t)row * n + uq, hp);
   }
-  if (wave > 0) red[(wave - 1) * 64 + lane] = acc;
+  if (wave > 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[((wave - 1) * 4 + g) * 64 + lane] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+  }
   __syncthreads();
   if (!cell_lane) return;
 #pragma unroll 3
   for (int w = 0; w < GRU_WAVES - 1; ++w) {
-    const f32x16 part = red[w * 64 + lane];
-    acc += part;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 part = red[(w * 4 + g) * 64 + lane];
+      acc[4 * g] += part[0]; acc[4 * g + 1] += part[1]; acc[4 * g + 2] += part[2]; acc[4 * g + 3] += part[3];
+    }
   }
   float hn[4], vr[4], vu[4], vc[4], vh[4];
 #pragma unroll

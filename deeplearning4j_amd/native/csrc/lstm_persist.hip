@@ -724,7 +724,10 @@ template <typename TR>
 __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwdP<typename TR::T> p) {
   typedef typename TR::T T;
   typedef typename TR::vec vec;
-  __shared__ __attribute__((aligned(16))) f32x16 red[(DIAG_WAVES - 1) * 64];
+  // partial tiles as [wave][4 register groups][64 lanes] of 16 bytes: a lane stride of 16 bytes keeps the 128-bit LDS accesses free of
+  // bank conflicts (as [wave][lane] of 64 bytes they ran at 6x the conflict-free cycle count, profiles/r3_pmc_sq_lstm.md - though
+  // the hand-off is short enough that the step time did not change)
+  __shared__ __attribute__((aligned(16))) f32x4 red[(DIAG_WAVES - 1) * 4 * 64];
   const int li = blockIdx.z, sp = p.d - li;                             // sp: processing step
   if (li >= p.nl || sp < 0 || sp >= p.T) return;                        // uniform per workgroup
   const int t = p.reverse ? p.T - 1 - sp : sp, tp = p.reverse ? t + 1 : t - 1;
@@ -801,13 +804,19 @@ __global__ void __launch_bounds__(DIAG_THREADS) lstm_diag_fwd_kernel(LstmDiagFwd
     TR::ld4(cprev + (int64_t)row * n + uq, c_state);
     if (p.maskT) mk = p.maskT[(int64_t)t * mb + row];
   }
-  if (wave > 0) red[(wave - 1) * 64 + lane] = acc;
+  if (wave > 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[((wave - 1) * 4 + g) * 64 + lane] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+  }
   __syncthreads();
   if (!cell_lane) return;
 #pragma unroll 3        // (fully unrolled the 15 partial tiles are all read ahead: 240 registers, scratch spills)
   for (int w = 0; w < DIAG_WAVES - 1; ++w) {
-    const f32x16 part = red[w * 64 + lane];
-    acc += part;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 part = red[(w * 4 + g) * 64 + lane];
+      acc[4 * g] += part[0]; acc[4 * g + 1] += part[1]; acc[4 * g + 2] += part[2]; acc[4 * g + 3] += part[3];
+    }
   }
   float wpf[4] = {0, 0, 0, 0}, wpo[4] = {0, 0, 0, 0}, wpg[4] = {0, 0, 0, 0};
   if (q.pf) {

@@ -18,7 +18,7 @@ from prof_summary import short
 
 def main(path, table=None, top=16):
     ms = {}
-    if table:
+    if table and table != "":
         for line in open(table):
             m = re.match(r"\| (\S.*?) \| [\d.]+ \| ([\d.]+) \|", line)
             if m:
